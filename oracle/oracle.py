@@ -1,0 +1,220 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes bindings of oracle/libqsvc_oracle.so (the CPU restatement)
+and a runner for the reference's own tools compiled into oracle/_ref (when present).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (qsvc_amd/) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(_HERE, "_ref")
+_LIB = None
+
+_i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (and oracle/_ref when /root/reference exists)."""
+    so = os.path.join(_HERE, "libqsvc_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("mctf_oracle.c", "j2k_oracle.c")]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libqsvc_oracle.so"])
+    if os.path.exists("/root/reference/trunk/src/split.cpp"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        so = build()
+        L = C.CDLL(so)
+        L.qo_dwt53t_analyze.argtypes = [_i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.qo_dwt53t_synthesize.argtypes = [_i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.qo_haar_analyze.argtypes = [_i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.qo_haar_synthesize.argtypes = [_i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.qo_bordered_from_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _i16p]
+        L.qo_q1_safe.argtypes = [C.c_int, C.c_int]
+        L.qo_motion_estimate.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p]
+        L.qo_decorrelate.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p, _u8p,
+                                     C.c_char_p, _i16p, C.c_void_p, C.c_void_p]
+        L.qo_update.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _i16p, C.c_char_p, C.c_float, _u8p]
+        L.qo_entropy.argtypes = [_i32p, C.c_int]
+        L.qo_entropy.restype = C.c_float
+        L.qo_frame_type.argtypes = [_i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def frame_bytes(W, H):
+    return W * H + 2 * (W // 2) * (H // 2)
+
+
+# ------------------------------------------------------------------ restatement wrappers
+def dwt53t(plane: np.ndarray, levels: int, inverse: bool = False, H=None, W=None) -> np.ndarray:
+    p = np.ascontiguousarray(plane, dtype=np.int16).copy()
+    h, w = p.shape
+    fn = lib().qo_dwt53t_synthesize if inverse else lib().qo_dwt53t_analyze
+    fn(p, w, H or h, W or w, levels)
+    return p
+
+
+def haar(plane: np.ndarray, levels: int, inverse: bool = False) -> np.ndarray:
+    p = np.ascontiguousarray(plane, dtype=np.int16).copy()
+    h, w = p.shape
+    (lib().qo_haar_synthesize if inverse else lib().qo_haar_analyze)(p, w, h, w, levels)
+    return p
+
+
+def bordered(luma: np.ndarray, b: int) -> np.ndarray:
+    H, W = luma.shape
+    out = np.empty((H + 2 * b, W + 2 * b), dtype=np.int16)
+    assert lib().qo_bordered_from_u8(np.ascontiguousarray(luma, dtype=np.uint8), H, W, b, out) == 0
+    return out
+
+
+def motion_estimate(low: np.ndarray, W, H, bs, S) -> np.ndarray:
+    low = np.ascontiguousarray(low, dtype=np.uint8)
+    P = low.shape[0]
+    mv = np.zeros((P // 2, 4, H // bs, W // bs), dtype=np.int16)
+    assert lib().qo_motion_estimate(low, P, W, H, bs, S, mv) == 0
+    return mv
+
+
+def decorrelate(low, W, H, bs, S, mv, always_B=0, want_prediction=False, want_hists=False):
+    low = np.ascontiguousarray(low, dtype=np.uint8)
+    P = low.shape[0]
+    nB = P // 2
+    F = frame_bytes(W, H)
+    high = np.zeros((nB, F), dtype=np.uint8)
+    types = C.create_string_buffer(nB + 1)
+    mvo = np.zeros_like(mv)
+    pred = np.zeros((nB, F), dtype=np.uint8) if want_prediction else None
+    hists = np.zeros((nB, 3, 256), dtype=np.int32) if want_hists else None
+    r = lib().qo_decorrelate(low, P, W, H, bs, S, always_B, np.ascontiguousarray(mv), high, types, mvo,
+                             pred.ctypes.data if pred is not None else None,
+                             hists.ctypes.data if hists is not None else None)
+    assert r == 0
+    return dict(high=high, types=types.raw[:nB], mv=mvo, prediction=pred, hists=hists)
+
+
+def update(low, W, H, bs, high, mv, types: bytes, update_factor=0.25) -> np.ndarray:
+    low = np.ascontiguousarray(low, dtype=np.uint8)
+    P = low.shape[0]
+    out = np.zeros((P // 2 + 1, frame_bytes(W, H)), dtype=np.uint8)
+    r = lib().qo_update(low, P, W, H, bs, np.ascontiguousarray(high), np.ascontiguousarray(mv), types,
+                        update_factor, out)
+    assert r == 0
+    return out
+
+
+def analyze_step(low, W, H, bs, S, always_B=0, update_factor=0.25, want_prediction=False):
+    """One temporal level (analyze_step.py:117-232) with the restatement."""
+    mv = motion_estimate(low, W, H, bs, S)
+    d = decorrelate(low, W, H, bs, S, mv, always_B, want_prediction=want_prediction, want_hists=True)
+    lo = update(low, W, H, bs, d["high"], d["mv"], d["types"], update_factor)
+    return dict(motion=mv, motion_filtered=d["mv"], high=d["high"], frame_types=d["types"], low=lo,
+                prediction=d["prediction"], hists=d["hists"])
+
+
+def analyze(low0, W, H, TRLs, bs, S=4, bs_min=None, always_B=0, update_factor=0.25):
+    """The level loop of analyze.py:110-153."""
+    bs_min = bs if bs_min is None else min(bs_min, bs)
+    levels = []
+    low = low0
+    for t in range(1, TRLs):
+        r = analyze_step(low, W, H, bs, S, always_B, update_factor)
+        r.update(block_size=bs, search_range=S, pictures=low.shape[0])
+        levels.append(r)
+        low = r["low"]
+        S = min(2 * S, 128)
+        bs = max(bs // 2, bs_min)
+    return levels
+
+
+# ------------------------------------------------------------------ compiled reference tools
+def have_ref() -> bool:
+    return all(os.path.exists(os.path.join(REF_DIR, t)) for t in ("split", "motion_estimate", "decorrelate", "update"))
+
+
+def ref_analyze_step(low: np.ndarray, W, H, bs, S, always_B=0, update_factor=0.25, t=1, workdir=None, timing=None):
+    """Run the reference's split/motion_estimate/decorrelate/update binaries (oracle/_ref) on one level,
+    exactly as analyze_step.py:117-232 invokes them.  Default glibc malloc (no MALLOC_PERTURB_)."""
+    import time
+    low = np.ascontiguousarray(low, dtype=np.uint8)
+    P = low.shape[0]
+    F = frame_bytes(W, H)
+    own = workdir is None
+    d = workdir or tempfile.mkdtemp(prefix="qsvc_ref_")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MALLOC_")}
+    try:
+        low.tofile(os.path.join(d, f"low_{t-1}"))
+        for f in (f"motion_{t}",):
+            if os.path.exists(os.path.join(d, f)):
+                os.remove(os.path.join(d, f))  # Q8: motion_estimate exits 1 if it exists
+
+        def run(tool, *args):
+            t0 = time.perf_counter()
+            subprocess.check_call([os.path.join(REF_DIR, tool)] + [str(a) for a in args], cwd=d, env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if timing is not None:
+                timing[tool] = timing.get(tool, 0.0) + time.perf_counter() - t0
+
+        run("split", f"--even_fn=even_{t}", f"--low_fn=low_{t-1}", f"--odd_fn=odd_{t}", f"--pictures={P}",
+            f"--pixels_in_x={W}", f"--pixels_in_y={H}")
+        run("motion_estimate", f"--block_size={bs}", "--border_size=0", f"--even_fn=even_{t}",
+            f"--imotion_fn=imotion_{t}", f"--motion_fn=motion_{t}", f"--odd_fn=odd_{t}", f"--pictures={P}",
+            f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--search_range={S}", "--subpixel_accuracy=0")
+        run("decorrelate", "--block_overlaping=0", f"--block_size={bs}", f"--even_fn=even_{t}",
+            f"--frame_types_fn=frame_types_{t}", f"--high_fn=high_{t}", f"--motion_in_fn=motion_{t}",
+            f"--motion_out_fn=motion_filtered_{t}", f"--odd_fn=odd_{t}", f"--pictures={P}", f"--pixels_in_x={W}",
+            f"--pixels_in_y={H}", f"--search_range={S}", "--subpixel_accuracy=0", f"--always_B={always_B}")
+        run("update", f"--block_size={bs}", f"--even_fn=even_{t}", f"--frame_types_fn=frame_types_{t}",
+            f"--high_fn=high_{t}", f"--low_fn=low_{t}", f"--motion_fn=motion_filtered_{t}", f"--pictures={P}",
+            f"--pixels_in_x={W}", f"--pixels_in_y={H}", "--subpixel_accuracy=0", f"--update_factor={update_factor}")
+        nB = P // 2
+        BY, BX = H // bs, W // bs
+        rd = lambda n, dt=np.uint8: np.fromfile(os.path.join(d, n), dtype=dt)
+        return dict(
+            motion=rd(f"motion_{t}", np.int16).reshape(nB, 4, BY, BX),
+            motion_filtered=rd(f"motion_filtered_{t}", np.int16).reshape(nB, 4, BY, BX),
+            high=rd(f"high_{t}").reshape(nB, F),
+            frame_types=rd(f"frame_types_{t}").tobytes(),
+            low=rd(f"low_{t}").reshape(nB + 1, F),
+            prediction=rd(f"prediction_even_{t}").reshape(nB, F),
+        )
+    finally:
+        if own:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+def ref_analyze(low0, W, H, TRLs, bs, S=4, bs_min=None, always_B=0, update_factor=0.25, timing=None):
+    bs_min = bs if bs_min is None else min(bs_min, bs)
+    levels, low = [], low0
+    for t in range(1, TRLs):
+        r = ref_analyze_step(low, W, H, bs, S, always_B, update_factor, t=t, timing=timing)
+        r.update(block_size=bs, search_range=S, pictures=low.shape[0])
+        levels.append(r)
+        low = r["low"]
+        S = min(2 * S, 128)
+        bs = max(bs // 2, bs_min)
+    return levels
+
+
+def ref_dwt(plane: np.ndarray, levels: int, inverse=False, filt="53") -> np.ndarray:
+    p = np.ascontiguousarray(plane, dtype=np.int16)
+    H, W = p.shape
+    out = subprocess.run([os.path.join(REF_DIR, "dwt_probe"), filt, "s" if inverse else "a", str(H), str(W), str(levels)],
+                         input=p.tobytes(), stdout=subprocess.PIPE, check=True).stdout
+    return np.frombuffer(out, dtype=np.int16).reshape(H, W).copy()

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own tools (build container only).
+
+The reference (claudio382/QSVC) ships no golden vectors, so the pins are made here by running the
+reference's MCTF stage tools -- compiled from /root/reference by oracle/Makefile into oracle/_ref,
+sources never copied -- on seeded synthetic clips (qsvc_amd/synth.py), exactly as
+analyze_step.py:117-232 chains them, with default glibc malloc.  What is committed is DATA only:
+tiny outputs verbatim (motion fields, frame types, whole small-geometry pictures) and SHA-256
+digests of the frame-sized outputs of larger cases.
+
+    python tests/golden/make_goldens.py        # rewrites tests/golden/mctf_*.npz, dwt_kat.npz
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from qsvc_amd.synth import make_clip  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name, kind, seed, frames, W, H, TRLs, block_size, search_range, full_dump
+CASES = [
+    ("tiny_pan", "pan", 42, 5, 64, 64, 3, 16, 4, True),
+    ("tiny_edge", "edge", 47, 5, 96, 64, 3, 16, 4, True),
+    ("tiny_sat", "saturating", 45, 5, 64, 48, 3, 8, 4, True),
+    ("tiny_binary", "binary", 48, 5, 64, 64, 2, 16, 4, True),
+    ("cif_pan", "pan", 42, 5, 352, 288, 3, 32, 4, False),
+    ("cif_scene_cut", "scene_cut", 44, 9, 352, 288, 3, 32, 4, False),
+    ("cif_saturating", "saturating", 45, 5, 352, 288, 3, 32, 4, False),
+    ("cif_noise", "noise", 46, 5, 352, 288, 2, 32, 4, False),
+    ("cif_binary", "binary", 48, 5, 352, 288, 2, 32, 4, False),
+    ("cif_edge", "edge", 47, 9, 352, 288, 3, 32, 4, False),
+    ("q1_edge_360x200", "edge", 49, 9, 360, 200, 4, 8, 4, False),   # S reaches 16: border quirk Q1
+    ("sat_360x200", "saturating", 45, 9, 360, 200, 4, 8, 4, False),  # has 'I' pictures
+    ("odd_350x286", "pan_noise", 43, 5, 350, 286, 3, 32, 8, False),  # non-PR sizes (Q5), Q7
+    ("q7_200x120", "pan", 42, 5, 200, 120, 2, 32, 4, False),         # rows/cols beyond BY*bs (Q7)
+]
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    assert O.have_ref(), "oracle/_ref missing: run `make -C oracle` in the build container"
+    for name, kind, seed, frames, W, H, TRLs, bs, S, full in CASES:
+        clip = make_clip(kind, frames, W, H, seed)
+        levels = O.ref_analyze(clip, W, H, TRLs, bs, S)
+        out = dict(meta=np.array([frames, W, H, TRLs, bs, S, seed], dtype=np.int64), kind=np.array(kind),
+                   input_sha=np.array(sha(clip)))
+        if full:
+            out["input"] = clip
+        for t, lv in enumerate(levels, 1):
+            out[f"motion_{t}"] = lv["motion"]
+            out[f"motion_filtered_{t}"] = lv["motion_filtered"]
+            out[f"frame_types_{t}"] = np.frombuffer(lv["frame_types"], dtype=np.uint8)
+            for k in ("high", "low", "prediction"):
+                out[f"{k}_{t}_sha"] = np.array(sha(lv[k]))
+                if full:
+                    out[f"{k}_{t}"] = lv[k]
+        np.savez_compressed(os.path.join(HERE, f"mctf_{name}.npz"), **out)
+        print(name, [lv["frame_types"] for lv in levels])
+
+    # known answers of the in-tree transforms (dwt2d.cpp / 5_3.cpp / Haar.cpp) via oracle/_ref/dwt_probe
+    rng = np.random.default_rng(7)
+    kat = {}
+    for (h, w, lv) in [(2, 2, 1), (3, 3, 1), (4, 5, 1), (5, 4, 1), (8, 9, 2), (9, 8, 2), (16, 17, 3), (17, 16, 2),
+                       (32, 48, 3), (30, 50, 2), (36, 44, 2)]:
+        x = rng.integers(0, 256, size=(h, w)).astype(np.int16)
+        kat[f"in_{h}x{w}_{lv}"] = x
+        a = O.ref_dwt(x, lv, inverse=False, filt="53")
+        kat[f"a53_{h}x{w}_{lv}"] = a
+        kat[f"s53_{h}x{w}_{lv}"] = O.ref_dwt(x, lv, inverse=True, filt="53")
+        kat[f"shaar_{h}x{w}_{lv}"] = O.ref_dwt(x, lv, inverse=True, filt="haar")
+    np.savez_compressed(os.path.join(HERE, "dwt_kat.npz"), **kat)
+    print("dwt_kat", len(kat))
+
+
+if __name__ == "__main__":
+    main()

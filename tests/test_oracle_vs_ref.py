@@ -1,0 +1,39 @@
+"""The CPU restatement against the reference's own tools compiled into oracle/_ref, on fresh seeds
+and geometries beyond the committed goldens.  Runs wherever oracle/_ref exists (the build container,
+and the GPU box because the built binaries travel with the snapshot); skipped otherwise."""
+import numpy as np
+import pytest
+
+from qsvc_amd.synth import make_clip
+
+CASES = [
+    ("pan", 11, 5, 352, 288, 32, 4),
+    ("pan_noise", 12, 5, 128, 96, 16, 8),
+    ("edge", 13, 5, 160, 96, 8, 16),
+    ("saturating", 14, 5, 128, 128, 8, 4),
+    ("noise", 15, 3, 96, 64, 16, 4),
+    ("pan", 16, 3, 98, 70, 16, 8),     # odd intermediate sizes: literal analyse/synthesise replay (Q5)
+    ("edge", 17, 5, 360, 200, 8, 16),  # Q1 row aliasing reachable
+]
+
+
+@pytest.mark.parametrize("kind,seed,frames,W,H,bs,S", CASES)
+def test_restatement_equals_compiled_reference(oracle, kind, seed, frames, W, H, bs, S):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    clip = make_clip(kind, frames, W, H, seed)
+    a = oracle.analyze_step(clip, W, H, bs, S, want_prediction=True)
+    b = oracle.ref_analyze_step(clip, W, H, bs, S)
+    for k in ("motion", "motion_filtered", "high", "low", "prediction"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a["frame_types"] == b["frame_types"]
+
+
+def test_dwt_restatement_equals_reference_templates(oracle):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(5)
+    for (h, w, lv) in [(6, 10, 1), (7, 11, 2), (20, 28, 2), (33, 17, 1)]:
+        x = rng.integers(-200, 400, size=(h, w)).astype(np.int16)
+        np.testing.assert_array_equal(oracle.dwt53t(x, lv), oracle.ref_dwt(x, lv))
+        np.testing.assert_array_equal(oracle.dwt53t(x, lv, inverse=True), oracle.ref_dwt(x, lv, inverse=True))
