@@ -1,0 +1,310 @@
+// qsvc_amd/csrc/mctf_core.h -- per-sample arithmetic of the MCTF kernels.
+//
+// Everything here is a pure function of (inputs, output coordinate): the HIP kernels in
+// mctf_kernels.hip map one thread (or one wave) to one output and call these; a host-side
+// loop harness (tests/emul) compiles the very same functions with g++ so the indexing can be
+// checked on a machine without a GPU.  The reference's loop nests are re-expressed as gathers:
+// every output sample pulls what it needs, so a whole temporal level is one launch per stage.
+//
+// Reference semantics restated here (paths relative to /root/reference/trunk/src):
+//   truncating 5/3 lifting ........ 5_3.cpp:39-115, in-place Mallat layout dwt2d.cpp:76-175
+//   replicate border + quirks ..... texture.cpp:34-113 (Q1 alloc aliasing, Q2 corner)
+//   +-1 hierarchical search ....... motion_estimate.cpp:70-184,260-358
+//   bidirectional prediction ...... decorrelate.cpp:69-189,841-861,920-929
+//   ordered saturating update ..... update.cpp:50-148,506-679
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define QHD __host__ __device__ __forceinline__
+#define QHDM __host__ __device__ __forceinline__
+#else
+#define QHD static inline
+#define QHDM inline
+#endif
+
+namespace qsvc {
+
+QHD int tdiv2(int a) { return a / 2; }  // C truncating division, as the reference
+QHD int tdiv4(int a) { return a / 4; }
+QHD int imin(int a, int b) { return a < b ? a : b; }
+QHD int imax(int a, int b) { return a > b ? a : b; }
+QHD int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+QHD int desp(int x, int l) {  // motion_estimate.cpp:232-236
+  for (int i = 0; i < l; i++) x = (x + 1) / 2;
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1-D truncating 5/3, one output coefficient at a time.  `S(i)` returns sample i of the line.
+// n >= 2.  Output index k in [0,n): k < nl -> low k, else high k-nl  (nl = ceil(n/2)).
+template <class Src>
+QHD int a53_high(const Src& S, int i, int n) {  // 5_3.cpp:41-45 / :63-66
+  if (2 * i + 2 < n) return S(2 * i + 1) - tdiv2(S(2 * i) + S(2 * i + 2));
+  return S(n - 1) - S(n - 2);  // even n, last high
+}
+template <class Src>
+QHD int a53_low(const Src& S, int i, int n) {  // 5_3.cpp:47-51 / :68-73
+  int nh = n >> 1;
+  if (i == 0) return S(0) + tdiv2(a53_high(S, 0, n));
+  if (i < nh) return S(2 * i) + tdiv4(a53_high(S, i, n) + a53_high(S, i - 1, n));
+  return S(n - 1) + tdiv2(a53_high(S, nh - 1, n));  // odd n, last low
+}
+template <class Src>
+QHD int a53_coef(const Src& S, int k, int n) {
+  int nl = (n + 1) >> 1;
+  return k < nl ? a53_low(S, k, n) : a53_high(S, k - nl, n);
+}
+// Synthesis: `Lo(i)`, `Hi(i)` return low/high coefficient i.  Output sample k in [0,n).
+template <class LoF, class HiF>
+QHD int s53_even_sample(const LoF& Lo, const HiF& Hi, int i, int n) {  // 5_3.cpp:84-88 / :105-110
+  int nh = n >> 1;
+  if (i == 0) return Lo(0) - tdiv2(Hi(0));
+  if (i < nh) return Lo(i) - tdiv4(Hi(i) + Hi(i - 1));
+  return Lo(nh) - tdiv2(Hi(nh - 1));  // odd n: s[n-1]
+}
+template <class LoF, class HiF>
+QHD int s53_sample(const LoF& Lo, const HiF& Hi, int k, int n) {
+  if ((k & 1) == 0) return s53_even_sample(Lo, Hi, k >> 1, n);
+  int i = k >> 1;
+  if (2 * i + 2 < n) return Hi(i) + tdiv2(s53_even_sample(Lo, Hi, i, n) + s53_even_sample(Lo, Hi, i + 1, n));
+  return Hi(i) + s53_even_sample(Lo, Hi, i, n);  // even n, last odd sample (5_3.cpp:94)
+}
+
+// ---------------------------------------------------------------------------------------------
+// Replicate border of a WxH picture with border b, as texture::fill_border leaves it on a plane
+// from texture::alloc (texture.cpp:34-113).  Returns the interior coordinate whose pixel-domain
+// value the cell (y,x) holds.  Q2: the lower-left corner holds the bottom-RIGHT pixel.  Q1: on row
+// r = H-b the cells x < -safe alias the right border of row r-1 and read back pixel (r-1, W-1).
+struct BorderGeom {
+  int H, W, b, safe;
+};
+QHD BorderGeom make_border(int H, int W, int b) {
+  BorderGeom g;
+  g.H = H; g.W = W; g.b = b;
+  long req = 2L * (W + 2 * b);
+  long pad = (16 - ((req + 8) % 16)) % 16;
+  g.safe = (int)((8 + pad) / 2);
+  return g;
+}
+QHD void border_map(const BorderGeom& g, int y, int x, int& iy, int& ix) {
+  if (y >= g.H) {
+    iy = g.H - 1;
+    ix = x < 0 ? g.W - 1 : (x >= g.W ? g.W - 1 : x);  // Q2 on the left
+    return;
+  }
+  if (y < 0) {
+    iy = 0;
+    ix = x < 0 ? 0 : (x >= g.W ? g.W - 1 : x);
+    return;
+  }
+  iy = y;
+  if (x < 0) {
+    ix = 0;
+    if (y == g.H - g.b && y >= 1 && x < -g.safe) { iy = y - 1; ix = g.W - 1; }  // Q1
+  } else {
+    ix = x >= g.W ? g.W - 1 : x;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chroma x2 interpolation = one level of 5/3 synthesis with zero high bands (decorrelate.cpp:610-648,
+// update.cpp:472-503): closed form for even H, W.  u is the (H/2)x(W/2) u8 plane; (y,x) full-res.
+QHD int chroma_up_col(const uint8_t* u, int cw, int y, int i, int H) {  // column pass (first)
+  if ((y & 1) == 0) return u[(size_t)(y >> 1) * cw + i];
+  int j = y >> 1;
+  if (y + 1 < H) return (u[(size_t)j * cw + i] + u[(size_t)(j + 1) * cw + i]) >> 1;
+  return u[(size_t)j * cw + i];
+}
+QHD int chroma_up(const uint8_t* u, int y, int x, int H, int W) {
+  int cw = W >> 1;
+  if ((x & 1) == 0) return chroma_up_col(u, cw, y, x >> 1, H);
+  int i = x >> 1;
+  if (x + 1 < W) return (chroma_up_col(u, cw, y, i, H) + chroma_up_col(u, cw, y, i + 1, H)) >> 1;
+  return chroma_up_col(u, cw, y, i, H);
+}
+// bordered read of the interpolated chroma plane (border filled AFTER interpolation)
+QHD int chroma_up_b(const uint8_t* u, const BorderGeom& g, int y, int x) {
+  int iy, ix;
+  border_map(g, y, x, iy, ix);
+  return chroma_up(u, iy, ix, g.H, g.W);
+}
+QHD int luma_b(const uint8_t* p, const BorderGeom& g, int y, int x) {
+  int iy, ix;
+  border_map(g, y, x, iy, ix);
+  return p[(size_t)iy * g.W + ix];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Motion field of one B picture: four int16 planes PREV-X, PREV-Y, NEXT-X, NEXT-Y (motion.cpp:9-15).
+struct MvField {
+  const int16_t* p;  // [4][BY][BX]
+  int BY, BX;
+  QHDM int px(int by, int bx) const { return p[(size_t)(0 * BY + by) * BX + bx]; }
+  QHDM int py(int by, int bx) const { return p[(size_t)(1 * BY + by) * BX + bx]; }
+  QHDM int nx(int by, int bx) const { return p[(size_t)(2 * BY + by) * BX + bx]; }
+  QHDM int ny(int by, int bx) const { return p[(size_t)(3 * BY + by) * BX + bx]; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// predict (decorrelate.cpp:93-108): one full-resolution prediction sample.
+//   comp 0: luma planes; comp 1,2: chroma planes interpolated on the fly.
+// (y,x) must lie inside BY*bs x BX*bs.  The clip to 0..255 (decorrelate.cpp:841-848) is a no-op:
+// both operands are in 0..255.
+QHD int predict_luma(const uint8_t* r0, const uint8_t* r1, const BorderGeom& g, const MvField& mv, int bs, int y, int x) {
+  int by = y / bs, bx = x / bs;
+  return (luma_b(r0, g, y + mv.py(by, bx), x + mv.px(by, bx)) + luma_b(r1, g, y + mv.ny(by, bx), x + mv.nx(by, bx))) >> 1;
+}
+QHD int predict_chroma_full(const uint8_t* u0, const uint8_t* u1, const BorderGeom& g, const MvField& mv, int bs, int y, int x) {
+  int by = y / bs, bx = x / bs;
+  return (chroma_up_b(u0, g, y + mv.py(by, bx), x + mv.px(by, bx)) + chroma_up_b(u1, g, y + mv.ny(by, bx), x + mv.nx(by, bx))) >> 1;
+}
+// Chroma /2 (decorrelate.cpp:860-861): LL sample (j,i) of a 1-level analysis (rows, then columns) of
+// the full-resolution plane P(y,x).
+template <class Plane>
+QHD int analyze_ll(const Plane& P, int j, int i, int H, int W) {
+  // low(j) of the column pass needs rows 2j-2 .. 2j+2 of the row-pass output (5_3.cpp:47-51)
+  int j0 = imax(2 * j - 2, 0), j1 = imin(2 * j + 2, H - 1);
+  int lrow[5];
+  for (int yy = j0; yy <= j1; yy++) {
+    auto row = [&](int xx) { return P(yy, xx); };
+    lrow[yy - j0] = (int16_t)a53_low(row, i, W);
+  }
+  auto col = [&](int yy) { return lrow[yy - j0]; };
+  return (int16_t)a53_low(col, j, H);
+}
+
+// One coefficient (y,x) of one 2-D analysis level over the ny x nx top-left region
+// (dwt2d.cpp:84-117: all rows, then all columns; low half first).
+template <class Plane>
+QHD int analyze2d_coef(const Plane& P, int y, int x, int ny, int nx) {
+  auto col = [&](int yy) {
+    auto row = [&](int xx) { return P(yy, xx); };
+    return (int)(int16_t)a53_coef(row, x, nx);
+  };
+  return (int16_t)a53_coef(col, y, ny);
+}
+// One sample (y,x) of one 2-D synthesis level (dwt2d.cpp:139-173: all columns, then all rows).
+template <class Plane>
+QHD int synthesize2d_sample(const Plane& P, int y, int x, int ny, int nx) {
+  int nlx = (nx + 1) >> 1, nly = (ny + 1) >> 1;
+  auto colsyn = [&](int xx) {  // column-synthesised value at (y, xx)
+    auto lo = [&](int i) { return P(i, xx); };
+    auto hi = [&](int i) { return P(nly + i, xx); };
+    return (int)(int16_t)s53_sample(lo, hi, y, ny);
+  };
+  auto lo = [&](int i) { return colsyn(i); };
+  auto hi = [&](int i) { return colsyn(nlx + i); };
+  return (int16_t)s53_sample(lo, hi, x, nx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hierarchical +-1 search (motion_estimate.cpp:70-184).  The reference analyses the three luma
+// planes L levels in place and walks back up by synthesis; with every intermediate size even the
+// state at level l is exactly the l-level in-place (Mallat) analysis of the picture, interior
+// only -- the replicate border keeps pixel-domain values (it is filled before the analysis,
+// motion_estimate.cpp:779,817 then :283-285).  MePlane is that state: `snap` holds the l-level
+// Mallat interior (for l = 0 the u8 luma itself), `luma0` the pixel-domain luma for border cells.
+template <class T>
+struct MePlane {
+  const T* snap;
+  int stride;
+  const uint8_t* luma0;
+  BorderGeom g;
+  QHDM int at(int y, int x) const {
+    if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) return snap[(size_t)y * stride + x];
+    return luma_b(luma0, g, y, x);
+  }
+  QHDM int in(int y, int x) const { return snap[(size_t)y * stride + x]; }  // interior, unchecked
+};
+// candidate order of local_me_for_block (motion_estimate.cpp:124-174): {dy,dx}
+#define QSVC_ME_CANDS {{-1, -1}, {-1, 1}, {1, -1}, {1, 1}, {-1, 0}, {1, 0}, {0, 1}, {0, -1}, {0, 0}}
+// Partial SADs of one block over the pixels idx = lane, lane+nlanes, ...   sad[2*c+d], d: 0 PREV 1 NEXT.
+template <class T>
+QHD void me_block_sads(const MePlane<T>& r0, const MePlane<T>& r1, const MePlane<T>& pr, int bs, int by, int bx, int pvy,
+                       int pvx, int nvy, int nvx, int lane, int nlanes, int* sad) {
+  const int cand[9][2] = QSVC_ME_CANDS;
+  for (int k = 0; k < 18; k++) sad[k] = 0;
+  int y0 = by * bs, x0 = bx * bs;
+  // whole 3x3 neighbourhood of both displaced blocks interior -> unchecked reads
+  bool inner = y0 + pvy - 1 >= 0 && y0 + pvy + bs + 1 <= r0.g.H && x0 + pvx - 1 >= 0 && x0 + pvx + bs + 1 <= r0.g.W &&
+               y0 + nvy - 1 >= 0 && y0 + nvy + bs + 1 <= r0.g.H && x0 + nvx - 1 >= 0 && x0 + nvx + bs + 1 <= r0.g.W;
+  for (int idx = lane; idx < bs * bs; idx += nlanes) {
+    int py = y0 + idx / bs, px = x0 + idx % bs;
+    int pv = pr.in(py, px);
+    if (inner) {
+      for (int c = 0; c < 9; c++) {
+        int a = pv - r0.in(py + pvy + cand[c][0], px + pvx + cand[c][1]);
+        int b = pv - r1.in(py + nvy - cand[c][0], px + nvx - cand[c][1]);
+        sad[2 * c] += a < 0 ? -a : a;
+        sad[2 * c + 1] += b < 0 ? -b : b;
+      }
+    } else {
+      for (int c = 0; c < 9; c++) {
+        int a = pv - r0.at(py + pvy + cand[c][0], px + pvx + cand[c][1]);
+        int b = pv - r1.at(py + nvy - cand[c][0], px + nvx - cand[c][1]);
+        sad[2 * c] += a < 0 ? -a : a;
+        sad[2 * c + 1] += b < 0 ? -b : b;
+      }
+    }
+  }
+}
+// UPDATE_VECTORS (motion_estimate.cpp:112-122): `<=` so the last minimum in candidate order wins.
+QHD void me_pick(const int* sad, int pvy, int pvx, int nvy, int nvx, int16_t* out_px, int16_t* out_py, int16_t* out_nx,
+                 int16_t* out_ny) {
+  const int cand[9][2] = QSVC_ME_CANDS;
+  int bp = 0, bn = 0;
+  for (int c = 1; c < 9; c++) {
+    if (sad[2 * c] <= sad[2 * bp]) bp = c;
+    if (sad[2 * c + 1] <= sad[2 * bn + 1]) bn = c;
+  }
+  *out_py = (int16_t)(pvy + cand[bp][0]); *out_px = (int16_t)(pvx + cand[bp][1]);
+  *out_ny = (int16_t)(nvy - cand[bn][0]); *out_nx = (int16_t)(nvx - cand[bn][1]);
+}
+// MV expansion between levels (motion_estimate.cpp:314-348): Haar synthesis with zero high band
+// (= replicate), x2, clamp to +-S.
+QHD int me_expand(int v, int S) { return iclamp((int16_t)(v * 2), -S, S); }
+
+// ---------------------------------------------------------------------------------------------
+// update (update.cpp:85-146) as an ordered gather for one target sample (ty,tx) of one even
+// picture and one motion direction.  `R(sy,sx)` returns the residue at a source position;
+// (fx,fy) select the PREV or NEXT planes of the B picture's field.  Sources are visited in the
+// reference's (by, bx, y, x) order, so saturation behaves identically.  reach >= max |mv|.
+// Hs, Ws bound the source area that can carry a non-zero residue (Q3: H/2 x W/2 for chroma).
+QHD int upd_one(int v, int r, float uf) {
+  float aux = (float)v;
+#if defined(__HIP_DEVICE_COMPILE__)
+  aux = __fadd_rn(aux, __fmul_rn((float)r, uf));
+#else
+  volatile float prod = (float)r * uf;  // keep the product rounded separately (no contraction)
+  aux = aux + prod;
+#endif
+  if (aux > 255.0f) aux = 255.0f; else if (aux < 0.0f) aux = 0.0f;
+  return (int)aux;
+}
+template <class Res>
+QHD int update_gather(int v, const Res& R, const int16_t* mvx, const int16_t* mvy, int BY, int BX, int bs, int H, int W,
+                      int Hs, int Ws, int reach, int ty, int tx, float uf) {
+  int sy_lo = ty == 0 ? 0 : ty - reach, sy_hi = ty == H - 1 ? H - 1 : ty + reach;
+  int sx_lo = tx == 0 ? 0 : tx - reach, sx_hi = tx == W - 1 ? W - 1 : tx + reach;
+  sy_lo = imax(sy_lo, 0); sx_lo = imax(sx_lo, 0);
+  sy_hi = imin(sy_hi, imin(Hs, BY * bs) - 1); sx_hi = imin(sx_hi, imin(Ws, BX * bs) - 1);
+  if (sy_hi < sy_lo || sx_hi < sx_lo) return v;
+  for (int by = sy_lo / bs; by <= sy_hi / bs; by++)
+    for (int bx = sx_lo / bs; bx <= sx_hi / bs; bx++) {
+      int dy = mvy[(size_t)by * BX + bx], dx = mvx[(size_t)by * BX + bx];
+      int y0 = by * bs, y1 = imin(y0 + bs, Hs) - 1, x0 = bx * bs, x1 = imin(x0 + bs, Ws) - 1;
+      int a, b, c, d;  // source rows [a,b], cols [c,d] of this block that land on the target
+      if (ty == 0) { a = y0; b = imin(y1, -dy); }
+      else if (ty == H - 1) { a = imax(y0, H - 1 - dy); b = y1; }
+      else { a = imax(y0, ty - dy); b = imin(y1, ty - dy); }
+      if (tx == 0) { c = x0; d = imin(x1, -dx); }
+      else if (tx == W - 1) { c = imax(x0, W - 1 - dx); d = x1; }
+      else { c = imax(x0, tx - dx); d = imin(x1, tx - dx); }
+      for (int sy = a; sy <= b; sy++)
+        for (int sx = c; sx <= d; sx++) v = upd_one(v, R(sy, sx), uf);
+    }
+  return v;
+}
+
+}  // namespace qsvc

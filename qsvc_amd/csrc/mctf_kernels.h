@@ -1,0 +1,14 @@
+// qsvc_amd/csrc/mctf_kernels.h -- launch wrappers of mctf_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mctf_threads.h"
+
+namespace qsvc {
+void launch_pyr_level_u8(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int P, int R, int C);
+void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int l, int R, int C);
+void launch_me_search(hipStream_t st, const MeArgs& a);
+void launch_predict(hipStream_t st, const PredArgs& a);
+void launch_update(hipStream_t st, const UpdArgs& a);
+void launch_mv_maxabs(hipStream_t st, const int16_t* mv, size_t n, int* out);
+void launch_dwt53t_level(hipStream_t st, const int16_t* src, int16_t* dst, int stride, int ny, int nx, int inverse);
+}  // namespace qsvc

@@ -1,0 +1,156 @@
+// qsvc_amd/csrc/mctf_kernels.hip -- gfx950 kernels of the MCTF half of `mctf compress`.
+//
+// Each kernel covers a WHOLE temporal level (all B pictures / all even pictures) in one launch;
+// the reference runs one process per stage and a sequential 3-picture window inside it
+// (motion_estimate.cpp:784-907, decorrelate.cpp:690-1075, update.cpp:506-656).  The per-sample
+// arithmetic lives in mctf_core.h / mctf_threads.h (shared with the host loop harness).
+//
+// Wave = 64 lanes everywhere.  No MFMA: this is byte/integer streaming and gather work.
+#include <hip/hip_runtime.h>
+#include "mctf_kernels.h"
+
+namespace qsvc {
+
+// ---------------------------------------------------------------------------------------------
+// ME pyramid level: thread per coefficient, 64x4 tile per workgroup (row-contiguous stores).
+template <class T>
+__global__ void __launch_bounds__(256) k_pyr_level(const T* src, size_t src_pic_stride, int src_row_stride, int16_t* dst,
+                                                    size_t dst_pic_stride, int H, int W, int l, int R, int C) {
+  int x = blockIdx.x * 64 + threadIdx.x;
+  int y = blockIdx.y * 4 + threadIdx.y;
+  pyr_thread<T>(src, src_pic_stride, src_row_stride, dst, dst_pic_stride, H, W, l, R, C, x, y, blockIdx.z);
+}
+void launch_pyr_level_u8(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int P, int R, int C) {
+  dim3 grid((C + 63) / 64, (R + 3) / 4, P), block(64, 4);
+  hipLaunchKernelGGL(k_pyr_level<uint8_t>, grid, block, 0, st, frames, F, W, dst, (size_t)H * W, H, W, 1, R, C);
+}
+void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int l, int R, int C) {
+  dim3 grid((C + 63) / 64, (R + 3) / 4, P), block(64, 4);
+  hipLaunchKernelGGL(k_pyr_level<int16_t>, grid, block, 0, st, src, (size_t)H * W, W, dst, (size_t)H * W, H, W, l, R, C);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ME search: one wave per MC block; lanes split the block's pixels, 18 SADs reduced across the
+// wave with DPP-free xor shuffles (64 lanes).
+template <class T>
+__global__ void __launch_bounds__(64) k_me_search(MeArgs a) {
+  int bx = blockIdx.x, by = blockIdx.y, i = blockIdx.z;
+  int lane = threadIdx.x;
+  MePlane<T> r0, r1, pr;
+  me_block_setup<T>(a, i, r0, r1, pr);
+  int pvx, pvy, nvx, nvy;
+  me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
+  int sad[18];
+  me_block_sads<T>(r0, r1, pr, a.g.bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad);
+#pragma unroll
+  for (int k = 0; k < 18; k++) {
+    int v = sad[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    sad[k] = v;
+  }
+  if (lane == 0) me_block_store(a, i, by, bx, sad, pvx, pvy, nvx, nvy);
+}
+void launch_me_search(hipStream_t st, const MeArgs& a) {
+  dim3 grid(a.nbx, a.nby, a.g.nB), block(64);
+  if (a.l == 0) hipLaunchKernelGGL(k_me_search<uint8_t>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(k_me_search<int16_t>, grid, block, 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// predict + residue, luma: thread per pixel, LDS histograms (odd picture, residue+128).
+__global__ void __launch_bounds__(256) k_pred_luma(PredArgs a) {
+  __shared__ unsigned h[2][256];
+  int tid = threadIdx.y * 64 + threadIdx.x;
+  h[0][tid] = 0; h[1][tid] = 0;
+  __syncthreads();
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+  if (x < a.g.W && y < a.g.H) {
+    int ob, rb;
+    pred_luma_thread(a, x, y, i, ob, rb);
+    atomicAdd(&h[0][ob], 1u);
+    atomicAdd(&h[1][rb], 1u);
+  }
+  __syncthreads();
+  unsigned* gh = a.hist + (size_t)i * 3 * 256;
+  if (h[0][tid]) atomicAdd(&gh[tid], h[0][tid]);
+  if (h[1][tid]) atomicAdd(&gh[256 + tid], h[1][tid]);
+}
+__global__ void __launch_bounds__(256) k_pred_chroma(PredArgs a) {
+  int ci = blockIdx.x * 64 + threadIdx.x, cj = blockIdx.y * 4 + threadIdx.y;
+  int i = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
+  if (ci < a.g.W / 2 && cj < a.g.H / 2) pred_chroma_thread(a, ci, cj, i, c);
+}
+// histogram of the motion components + 128 (decorrelate.cpp:805-812)
+__global__ void __launch_bounds__(256) k_mv_hist(const int16_t* mv, size_t per_pic, unsigned* hist) {
+  __shared__ unsigned h[256];
+  int i = blockIdx.y;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int16_t* m = mv + (size_t)i * per_pic;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < per_pic; k += (size_t)gridDim.x * 256)
+    atomicAdd(&h[(m[k] + 128) & 255], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[((size_t)i * 3 + 2) * 256 + threadIdx.x], h[threadIdx.x]);
+}
+void launch_predict(hipStream_t st, const PredArgs& a) {
+  const LevelGeom& g = a.g;
+  hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);
+  hipLaunchKernelGGL(k_pred_chroma, dim3((g.W / 2 + 63) / 64, (g.H / 2 + 3) / 4, g.nB * 2), block, 0, st, a);
+  size_t per_pic = (size_t)4 * g.BY * g.BX;
+  int nblk = (int)((per_pic + 255) / 256);
+  if (nblk > 64) nblk = 64;
+  hipLaunchKernelGGL(k_mv_hist, dim3(nblk, g.nB), dim3(256), 0, st, a.mv, per_pic, a.hist);
+}
+
+// ---------------------------------------------------------------------------------------------
+// update: thread per target sample (ordered gather), all even pictures of the level at once.
+__global__ void __launch_bounds__(256) k_upd_luma(UpdArgs a) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
+  if (x < a.g.W && y < a.g.H) upd_luma_thread(a, x, y, j);
+}
+__global__ void __launch_bounds__(256) k_upd_chroma(UpdArgs a) {
+  int ci = blockIdx.x * 64 + threadIdx.x, cj = blockIdx.y * 4 + threadIdx.y;
+  int j = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
+  if (ci < a.g.W / 2 && cj < a.g.H / 2) upd_chroma_thread(a, ci, cj, j, c);
+}
+void launch_update(hipStream_t st, const UpdArgs& a) {
+  const LevelGeom& g = a.g;
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_upd_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB + 1), block, 0, st, a);
+  hipLaunchKernelGGL(k_upd_chroma, dim3((g.W / 2 + 63) / 64, (g.H / 2 + 3) / 4, (g.nB + 1) * 2), block, 0, st, a);
+}
+
+// max |component| of a motion buffer -> *out (int, pre-zeroed)
+__global__ void __launch_bounds__(256) k_mv_maxabs(const int16_t* mv, size_t n, int* out) {
+  int m = 0;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+    int v = mv[k];
+    v = v < 0 ? -v : v;
+    m = v > m ? v : m;
+  }
+  for (int off = 32; off >= 1; off >>= 1) { int o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+void launch_mv_maxabs(hipStream_t st, const int16_t* mv, size_t n, int* out) {
+  int nblk = (int)((n + 255) / 256);
+  if (nblk > 256) nblk = 256;
+  if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(k_mv_maxabs, dim3(nblk), dim3(256), 0, st, mv, n, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic truncating 5/3 level (API qsvc_dwt53_trunc): out-of-place, thread per output.
+__global__ void __launch_bounds__(256) k_dwt53t_level(const int16_t* src, int16_t* dst, int stride, int ny, int nx, int inverse) {
+  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= nx || y >= ny) return;
+  auto P = [&](int yy, int xx) { return (int)src[(size_t)yy * stride + xx]; };
+  dst[(size_t)y * stride + x] = (int16_t)(inverse ? synthesize2d_sample(P, y, x, ny, nx) : analyze2d_coef(P, y, x, ny, nx));
+}
+void launch_dwt53t_level(hipStream_t st, const int16_t* src, int16_t* dst, int stride, int ny, int nx, int inverse) {
+  hipLaunchKernelGGL(k_dwt53t_level, dim3((nx + 63) / 64, (ny + 3) / 4), dim3(64, 4), 0, st, src, dst, stride, ny, nx, inverse);
+}
+
+}  // namespace qsvc

@@ -1,0 +1,561 @@
+// qsvc_amd/csrc/qsvc_api.hip -- the C ABI of include/qsvc_hip.h: context, device-resident
+// "files", and the host side of the MCTF stages (stage orchestration, the float entropy I/B rule).
+//
+// Host-side logic restated from the reference (paths relative to /root/reference/trunk/src):
+//   entropy()            entropy.cpp:20-34        (float accumulation, log in double)
+//   I/B decision         decorrelate.cpp:798-819,945-1000
+//   level chain          analyze_step.py:117-232
+#include "qsvc_ctx.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+using namespace qsvc;
+
+// ------------------------------------------------------------------------------------------------
+int qsvc_ctx::fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  err = buf;
+  return code;
+}
+int qsvc_ctx::hipfail(hipError_t e, const char* what) {
+  return fail(QSVC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIPCHK(ctx, call)                                    \
+  do {                                                       \
+    hipError_t e_ = (call);                                  \
+    if (e_ != hipSuccess) return (ctx)->hipfail(e_, #call);  \
+  } while (0)
+
+int DevBuf::ensure(qsvc_ctx* c, size_t n) {
+  if (n <= cap) return QSVC_OK;
+  if (p) (void)hipFree(p);
+  p = nullptr; cap = 0;
+  hipError_t e = hipMalloc(&p, n);
+  if (e != hipSuccess) { p = nullptr; return c->fail(QSVC_ERR_NOMEM, "hipMalloc(%zu): %s", n, hipGetErrorString(e)); }
+  cap = n;
+  return QSVC_OK;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr; cap = 0;
+}
+
+void Prof::begin(qsvc_ctx* c, const char* name) {
+  if (!c->profiling) return;
+  Seg* s = nullptr;
+  for (auto& x : c->segs) if (x.name == name) { s = &x; break; }
+  if (!s) { c->segs.push_back(Seg()); s = &c->segs.back(); s->name = name; }
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  hipEventRecord(a, c->st);
+  s->ev.push_back({a, b});
+  cur = s;
+}
+void Prof::end(qsvc_ctx* c) {
+  if (!c->profiling || !cur) return;
+  hipEventRecord(cur->ev.back().second, c->st);
+  cur = nullptr;
+}
+
+static void free_seq(qsvc_ctx* c) {
+  for (auto& l : c->lv) {
+    l.low.release(); l.high.release(); l.pred.release(); l.mv_raw.release(); l.mv_filt.release(); l.hist.release();
+    l.low_n = l.high_n = l.pred_n = 0; l.mv_raw_n = l.mv_filt_n = 0; l.mv_bs = 0; l.types.clear();
+    l.halo[0] = l.halo[1] = nullptr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int qsvc_init(int device, qsvc_ctx** out) {
+  if (!out) return QSVC_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0 || device < 0 || device >= n) return QSVC_ERR_HIP;  // no CPU fallback
+  if (hipSetDevice(device) != hipSuccess) return QSVC_ERR_HIP;
+  qsvc_ctx* c = new qsvc_ctx();
+  c->dev = device;
+  if (hipStreamCreate(&c->st) != hipSuccess) { delete c; return QSVC_ERR_HIP; }
+  c->lv.resize(QSVC_MAX_T + 1);
+  *out = c;
+  return QSVC_OK;
+}
+
+void qsvc_destroy(qsvc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->dev);
+  (void)hipStreamSynchronize(c->st);
+  free_seq(c);
+  for (auto& b : c->snap) b.release();
+  c->mvtmp[0].release(); c->mvtmp[1].release();
+  for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); }
+  if (c->comm) qsvc_comm_destroy(c);
+  c->scal.release(); c->tmp16[0].release(); c->tmp16[1].release();
+  j2k_release(c);
+  for (auto& s : c->segs) for (auto& p : s.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  (void)hipStreamDestroy(c->st);
+  delete c;
+}
+
+const char* qsvc_last_error(qsvc_ctx* c) { return c ? c->err.c_str() : "null context"; }
+void* qsvc_stream(qsvc_ctx* c) { return c ? (void*)c->st : nullptr; }
+int qsvc_sync(qsvc_ctx* c) {
+  if (!c) return QSVC_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return QSVC_OK;
+}
+
+int qsvc_seq_config(qsvc_ctx* c, int W, int H, int keep_prediction) {
+  if (!c) return QSVC_ERR_INVALID;
+  if (W < 16 || H < 16 || W > 16384 || H > 16384) return c->fail(QSVC_ERR_INVALID, "bad geometry %dx%d", W, H);
+  if ((W & 1) || (H & 1)) return c->fail(QSVC_ERR_UNSUPPORTED, "odd picture size %dx%d (4:2:0 needs even sizes)", W, H);
+  (void)hipSetDevice(c->dev);
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  free_seq(c);
+  c->W = W; c->H = H; c->F = (size_t)W * H + 2 * (size_t)(W / 2) * (H / 2);
+  c->keep_pred = keep_prediction;
+  return QSVC_OK;
+}
+
+static int seq_sel(qsvc_ctx* c, int kind, int t, DevBuf** buf, int** cnt) {
+  if (t < 0 || t > QSVC_MAX_T) return c->fail(QSVC_ERR_INVALID, "temporal subband %d out of range", t);
+  Level& l = c->lv[t];
+  switch (kind) {
+    case QSVC_LOW: *buf = &l.low; *cnt = &l.low_n; return QSVC_OK;
+    case QSVC_HIGH: *buf = &l.high; *cnt = &l.high_n; return QSVC_OK;
+    case QSVC_PRED: *buf = &l.pred; *cnt = &l.pred_n; return QSVC_OK;
+  }
+  return c->fail(QSVC_ERR_INVALID, "unknown sequence kind %d", kind);
+}
+
+int qsvc_put_frames(qsvc_ctx* c, int kind, int t, int first, int count, int total, const uint8_t* src) {
+  if (!c || !src) return QSVC_ERR_INVALID;
+  if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+  DevBuf* b; int* n;
+  int r = seq_sel(c, kind, t, &b, &n);
+  if (r) return r;
+  if (first < 0 || count < 0 || first + count > total) return c->fail(QSVC_ERR_INVALID, "bad frame range");
+  if ((r = b->ensure(c, (size_t)total * c->F))) return r;
+  *n = total;
+  HIPCHK(c, hipMemcpyAsync((uint8_t*)b->p + (size_t)first * c->F, src, (size_t)count * c->F, hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return QSVC_OK;
+}
+int qsvc_get_frames(qsvc_ctx* c, int kind, int t, int first, int count, uint8_t* dst) {
+  if (!c || !dst) return QSVC_ERR_INVALID;
+  DevBuf* b; int* n;
+  int r = seq_sel(c, kind, t, &b, &n);
+  if (r) return r;
+  if (first < 0 || count < 0 || first + count > *n) return c->fail(QSVC_ERR_STATE, "sequence kind %d t=%d holds %d pictures", kind, t, *n);
+  HIPCHK(c, hipMemcpyAsync(dst, (uint8_t*)b->p + (size_t)first * c->F, (size_t)count * c->F, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return QSVC_OK;
+}
+
+int qsvc_put_motion(qsvc_ctx* c, int kind, int t, int nB, int bs, const int16_t* mv) {
+  if (!c || !mv || t < 1 || t > QSVC_MAX_T || bs <= 0 || nB < 0) return QSVC_ERR_INVALID;
+  Level& l = c->lv[t];
+  size_t bytes = (size_t)nB * 4 * (c->H / bs) * (c->W / bs) * sizeof(int16_t);
+  DevBuf& b = kind == QSVC_MOTION_RAW ? l.mv_raw : l.mv_filt;
+  int r = b.ensure(c, bytes ? bytes : 16);
+  if (r) return r;
+  (kind == QSVC_MOTION_RAW ? l.mv_raw_n : l.mv_filt_n) = nB;
+  l.mv_bs = bs;
+  HIPCHK(c, hipMemcpyAsync(b.p, mv, bytes, hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return QSVC_OK;
+}
+int qsvc_get_motion(qsvc_ctx* c, int kind, int t, int16_t* mv) {
+  if (!c || !mv || t < 1 || t > QSVC_MAX_T) return QSVC_ERR_INVALID;
+  Level& l = c->lv[t];
+  int nB = kind == QSVC_MOTION_RAW ? l.mv_raw_n : l.mv_filt_n;
+  if (!l.mv_bs) return c->fail(QSVC_ERR_STATE, "no motion for t=%d", t);
+  DevBuf& b = kind == QSVC_MOTION_RAW ? l.mv_raw : l.mv_filt;
+  size_t bytes = (size_t)nB * 4 * (c->H / l.mv_bs) * (c->W / l.mv_bs) * sizeof(int16_t);
+  HIPCHK(c, hipMemcpyAsync(mv, b.p, bytes, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return QSVC_OK;
+}
+int qsvc_put_frame_types(qsvc_ctx* c, int t, int nB, const char* types) {
+  if (!c || !types || t < 1 || t > QSVC_MAX_T) return QSVC_ERR_INVALID;
+  c->lv[t].types.assign(types, types + nB);
+  return QSVC_OK;
+}
+int qsvc_get_frame_types(qsvc_ctx* c, int t, char* types) {
+  if (!c || !types || t < 1 || t > QSVC_MAX_T) return QSVC_ERR_INVALID;
+  memcpy(types, c->lv[t].types.data(), c->lv[t].types.size());
+  return QSVC_OK;
+}
+int qsvc_get_histograms(qsvc_ctx* c, int t, uint32_t* hist) {
+  if (!c || !hist || t < 1 || t > QSVC_MAX_T) return QSVC_ERR_INVALID;
+  Level& l = c->lv[t];
+  if (!l.hist.p) return c->fail(QSVC_ERR_STATE, "no histograms for t=%d", t);
+  HIPCHK(c, hipMemcpyAsync(hist, l.hist.p, (size_t)l.high_n * 3 * 256 * 4, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return QSVC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int ilog2_exact(int s) {
+  int l = 0;
+  while ((1 << (l + 1)) <= s) l++;
+  return (1 << l) == s ? l : -1;
+}
+static int level_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g) {
+  if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+  if (t < 1 || t > QSVC_MAX_T) return c->fail(QSVC_ERR_INVALID, "temporal subband %d out of range", t);
+  if (bs < 2 || bs > 256) return c->fail(QSVC_ERR_INVALID, "block_size %d", bs);
+  if (P < 1) return c->fail(QSVC_ERR_INVALID, "pictures %d", P);
+  if (c->lv[t - 1].low_n < P) return c->fail(QSVC_ERR_STATE, "low_%d holds %d pictures, %d needed", t - 1, c->lv[t - 1].low_n, P);
+  // rows/cols beyond BY*bs are never predicted by the reference and keep stale heap state there
+  // (decorrelate.cpp:508-509,562-567; trunk/readme.txt:119-125) -- not reproduced on this path.
+  if (c->H % bs || c->W % bs)
+    return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d is not a multiple of block_size %d", c->W, c->H, bs);
+  g->W = c->W; g->H = c->H; g->bs = bs; g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
+  return QSVC_OK;
+}
+
+int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
+  if (!c) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  LevelGeom g;
+  int r = level_geom(c, t, P, bs, S, &g);
+  if (r) return r;
+  int lg = ilog2_exact(S);
+  if (lg < 0 || S > 128) return c->fail(QSVC_ERR_UNSUPPORTED, "search_range %d is not a power of two <= 128", S);
+  int L = lg - 1 < 0 ? 0 : lg - 1;  // motion_estimate.cpp:277
+  // the level-l search state equals the l-level analysis only while every intermediate size is even (Q5)
+  if ((g.H % (1 << L)) || (g.W % (1 << L)))
+    return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d not divisible by 2^%d (search_range %d)", g.W, g.H, L, S);
+  if (desp(g.BY, L) * bs + S > 32767) return c->fail(QSVC_ERR_UNSUPPORTED, "picture too large");
+  Level& lv = c->lv[t];
+  size_t fld = (size_t)g.BY * g.BX, mvbytes = (size_t)g.nB * 4 * fld * sizeof(int16_t);
+  if ((r = lv.mv_raw.ensure(c, mvbytes ? mvbytes : 16))) return r;
+  lv.mv_raw_n = g.nB; lv.mv_bs = bs;
+  if (g.nB == 0) return QSVC_OK;
+  const uint8_t* frames = (const uint8_t*)c->lv[t - 1].low.p;
+  size_t N = (size_t)g.H * g.W;
+  if ((int)c->snap.size() < L + 1) c->snap.resize(L + 1);
+  Prof pf;
+  pf.begin(c, "me_pyramid");
+  for (int l = 1; l <= L; l++) {
+    if ((r = c->snap[l].ensure(c, (size_t)P * N * sizeof(int16_t)))) return r;
+    int R = imin(g.H, imax(desp(g.BY, l) * bs + S, g.H >> l)), C = imin(g.W, imax(desp(g.BX, l) * bs + S, g.W >> l));
+    if (l == 1) launch_pyr_level_u8(c->st, frames, g.F, g.W, g.H, (int16_t*)c->snap[1].p, P, R, C);
+    else launch_pyr_level_s16(c->st, (const int16_t*)c->snap[l - 1].p, (int16_t*)c->snap[l].p, g.W, g.H, P, l, R, C);
+  }
+  pf.end(c);
+  if (L >= 1) {
+    if ((r = c->mvtmp[0].ensure(c, mvbytes))) return r;
+    if ((r = c->mvtmp[1].ensure(c, mvbytes))) return r;
+  }
+  const int16_t* prev = nullptr;
+  for (int l = L; l >= 0; l--) {
+    MeArgs a;
+    a.g = g; a.frames = frames; a.snap = l ? c->snap[l].p : nullptr; a.snap_pic_stride = N;
+    a.mv_prev = prev; a.mv_out = l == 0 ? (int16_t*)lv.mv_raw.p : (int16_t*)c->mvtmp[l & 1].p;
+    a.l = l; a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l);
+    pf.begin(c, l == 0 ? "me_search_l0" : "me_search_coarse");
+    launch_me_search(c->st, a);
+    pf.end(c);
+    prev = a.mv_out;
+  }
+  HIPCHK(c, hipGetLastError());
+  return QSVC_OK;
+}
+
+// entropy() of entropy.cpp:20-34, op for op (float accumulate, double log).
+static float entropy256(const uint32_t* count) {
+  float e = 0.0f;
+  int total = 0;
+  for (int i = 0; i < 256; i++) total += (int)count[i];
+  for (int i = 0; i < 256; i++)
+    if (count[i]) {
+      float prob = (float)(int)count[i] / total;
+      e += prob * (float)(log(prob) / log(2.0));
+    }
+  return -e;
+}
+
+int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
+  if (!c) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  LevelGeom g;
+  int r = level_geom(c, t, P, bs, S, &g);
+  if (r) return r;
+  if (S < 1 || S > 128) return c->fail(QSVC_ERR_INVALID, "search_range %d", S);
+  Level& lv = c->lv[t];
+  if (lv.mv_raw_n < g.nB || lv.mv_bs != bs) return c->fail(QSVC_ERR_STATE, "motion_%d missing (run motion_estimate first)", t);
+  size_t fld = (size_t)g.BY * g.BX, mvbytes = (size_t)g.nB * 4 * fld * sizeof(int16_t);
+  if ((r = lv.high.ensure(c, (size_t)(g.nB ? g.nB : 1) * g.F))) return r;
+  if ((r = lv.mv_filt.ensure(c, mvbytes ? mvbytes : 16))) return r;
+  if ((r = lv.hist.ensure(c, (size_t)(g.nB ? g.nB : 1) * 3 * 256 * 4))) return r;
+  if (c->keep_pred) { if ((r = lv.pred.ensure(c, (size_t)(g.nB ? g.nB : 1) * g.F))) return r; lv.pred_n = g.nB; }
+  lv.high_n = g.nB; lv.mv_filt_n = g.nB;
+  lv.types.assign((size_t)g.nB, 'B');
+  if (g.nB == 0) return QSVC_OK;
+  PredArgs a;
+  a.g = g; a.frames = (const uint8_t*)c->lv[t - 1].low.p; a.mv = (const int16_t*)lv.mv_raw.p;
+  a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = (unsigned*)lv.hist.p;
+  Prof pf;
+  pf.begin(c, "predict");
+  launch_predict(c->st, a);
+  pf.end(c);
+  HIPCHK(c, hipMemcpyAsync(lv.mv_filt.p, lv.mv_raw.p, mvbytes, hipMemcpyDeviceToDevice, c->st));
+  if (!always_B) {
+    // host-side I/B rule (decorrelate.cpp:964-979) on the three device histograms
+    c->hhist.resize((size_t)g.nB * 3 * 256);
+    HIPCHK(c, hipMemcpyAsync(c->hhist.data(), lv.hist.p, c->hhist.size() * 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    for (int i = 0; i < g.nB; i++) {
+      const uint32_t* h = c->hhist.data() + (size_t)i * 3 * 256;
+      float predicted_entropy = entropy256(h), residue_entropy = entropy256(h + 256), motion_entropy = entropy256(h + 512);
+      int predicted_size = (int)(predicted_entropy * (float)g.H * (float)g.W);
+      int residue_size = (int)(residue_entropy * (float)g.H * (float)g.W);
+      int motion_size = (int)(motion_entropy * (float)g.BY * (float)g.BX);
+      if (predicted_size <= residue_size + motion_size) {  // 'I': the odd picture itself, zero motion
+        lv.types[i] = 'I';
+        HIPCHK(c, hipMemcpyAsync((uint8_t*)lv.high.p + (size_t)i * g.F, a.frames + (size_t)(2 * i + 1) * g.F, g.F,
+                                 hipMemcpyDeviceToDevice, c->st));
+        HIPCHK(c, hipMemsetAsync((int16_t*)lv.mv_filt.p + (size_t)i * 4 * fld, 0, 4 * fld * sizeof(int16_t), c->st));
+      }
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return QSVC_OK;
+}
+
+int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
+  if (!c) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  LevelGeom g;
+  int r = level_geom(c, t, P, bs, 0, &g);
+  if (r) return r;
+  Level& lv = c->lv[t];
+  if (lv.high_n < g.nB || lv.mv_filt_n < g.nB || (int)lv.types.size() < g.nB || (g.nB && lv.mv_bs != bs))
+    return c->fail(QSVC_ERR_STATE, "high_%d / motion_filtered_%d / frame_types_%d missing", t, t, t);
+  size_t fld = (size_t)g.BY * g.BX;
+  if ((r = lv.low.ensure(c, (size_t)(g.nB + 1) * g.F))) return r;
+  lv.low_n = g.nB + 1;
+  if ((r = c->scal.ensure(c, 256))) return r;
+  // reach = max |mv| over everything the gather may touch
+  HIPCHK(c, hipMemsetAsync(c->scal.p, 0, 16, c->st));
+  if (g.nB) launch_mv_maxabs(c->st, (const int16_t*)lv.mv_filt.p, (size_t)g.nB * 4 * fld, (int*)c->scal.p);
+  for (int s = 0; s < 2; s++)
+    if (lv.halo[s]) launch_mv_maxabs(c->st, (const int16_t*)((const uint8_t*)lv.halo[s] + g.F), 4 * fld, (int*)c->scal.p);
+  int reach = 0;
+  uint8_t halo_types[2][16] = {{0}, {0}};
+  HIPCHK(c, hipMemcpyAsync(&reach, c->scal.p, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  for (int s = 0; s < 2; s++)
+    if (lv.halo[s])
+      HIPCHK(c, hipMemcpyAsync(halo_types[s], (const uint8_t*)lv.halo[s] + g.F + 4 * fld * sizeof(int16_t), 16, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  // frame types to the device (tiny)
+  if ((r = c->tmp16[0].ensure(c, (size_t)g.nB + 16))) return r;
+  if (g.nB) HIPCHK(c, hipMemcpyAsync(c->tmp16[0].p, lv.types.data(), g.nB, hipMemcpyHostToDevice, c->st));
+  UpdArgs a;
+  a.g = g; a.frames = (const uint8_t*)c->lv[t - 1].low.p; a.high = (const uint8_t*)lv.high.p;
+  a.mv = (const int16_t*)lv.mv_filt.p; a.types = (const uint8_t*)c->tmp16[0].p; a.low = (uint8_t*)lv.low.p;
+  a.uf = uf; a.reach = reach;
+  for (int s = 0; s < 2; s++) {
+    a.halo_high[s] = (const uint8_t*)lv.halo[s];
+    a.halo_mv[s] = lv.halo[s] ? (const int16_t*)((const uint8_t*)lv.halo[s] + g.F) : nullptr;
+    a.halo_type[s] = lv.halo[s] ? halo_types[s][0] : 0;
+  }
+  Prof pf;
+  pf.begin(c, "update");
+  launch_update(c->st, a);
+  pf.end(c);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->st));  // lv.types / halo buffers may be changed by the caller next
+  return QSVC_OK;
+}
+
+int qsvc_analyze_step(qsvc_ctx* c, int t, int P, int bs, int S, int always_B, float uf) {
+  int r = qsvc_motion_estimate(c, t, P, bs, S);
+  if (r) return r;
+  if ((r = qsvc_decorrelate(c, t, P, bs, S, always_B))) return r;
+  return qsvc_update(c, t, P, bs, uf);
+}
+
+// ---- halo ---------------------------------------------------------------------------------------
+size_t qsvc_halo_bytes(qsvc_ctx* c, int bs) {
+  if (!c || !c->F || bs <= 0) return 0;
+  return c->F + (size_t)4 * (c->H / bs) * (c->W / bs) * sizeof(int16_t) + 16;
+}
+// pack our boundary B picture of level t into the context's send buffer `side`
+static int halo_pack(qsvc_ctx* c, int t, int side) {
+  Level& lv = c->lv[t];
+  int nB = lv.high_n;
+  if (nB < 1 || lv.mv_filt_n < nB || (int)lv.types.size() < nB) return c->fail(QSVC_ERR_STATE, "nothing to export for t=%d", t);
+  int i = side == 0 ? 0 : nB - 1;
+  size_t fld = (size_t)(c->H / lv.mv_bs) * (c->W / lv.mv_bs), mvb = 4 * fld * sizeof(int16_t);
+  int r = c->halo_tx[side].ensure(c, c->F + mvb + 16);
+  if (r) return r;
+  uint8_t* d = (uint8_t*)c->halo_tx[side].p;
+  HIPCHK(c, hipMemcpyAsync(d, (uint8_t*)lv.high.p + (size_t)i * c->F, c->F, hipMemcpyDeviceToDevice, c->st));
+  HIPCHK(c, hipMemcpyAsync(d + c->F, (uint8_t*)lv.mv_filt.p + (size_t)i * mvb, mvb, hipMemcpyDeviceToDevice, c->st));
+  memset(c->halo_tb[side], 0, 16);
+  c->halo_tb[side][0] = (uint8_t)lv.types[i];
+  HIPCHK(c, hipMemcpyAsync(d + c->F + mvb, c->halo_tb[side], 16, hipMemcpyHostToDevice, c->st));
+  return QSVC_OK;
+}
+int qsvc_halo_export_host(qsvc_ctx* c, int t, int side, void* dst) {
+  if (!c || !dst || t < 1 || t > QSVC_MAX_T || (side != 0 && side != 1)) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  int r = halo_pack(c, t, side);
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(dst, c->halo_tx[side].p, qsvc_halo_bytes(c, c->lv[t].mv_bs), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return QSVC_OK;
+}
+int qsvc_halo_import_host(qsvc_ctx* c, int t, int side, const void* src) {
+  if (!c || t < 1 || t > QSVC_MAX_T || (side != 0 && side != 1)) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  Level& lv = c->lv[t];
+  if (!src) { lv.halo[side] = nullptr; return QSVC_OK; }
+  if (!lv.mv_bs) return c->fail(QSVC_ERR_STATE, "halo import before decorrelate of t=%d", t);
+  size_t n = qsvc_halo_bytes(c, lv.mv_bs);
+  int r = c->halo_rx[side].ensure(c, n);
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(c->halo_rx[side].p, src, n, hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  lv.halo[side] = c->halo_rx[side].p;
+  return QSVC_OK;
+}
+
+// RCCL is dlopen'ed on first use so that single-GPU runs never load it.
+#include <dlfcn.h>
+struct Id128 { char b[128]; };  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
+namespace {
+struct Rccl {
+  void* h = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+static Rccl g_rccl;
+static const char* rccl_load() {
+  if (g_rccl.h) return nullptr;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) return dlerror();
+#define SYM(field, name) *(void**)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) return "missing symbol " name;
+  SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+  SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
+  SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  g_rccl.h = h;
+  return nullptr;
+}
+int qsvc_comm_unique_id(void* out, size_t cap) {
+  if (!out || cap < 128) return QSVC_ERR_INVALID;
+  if (rccl_load()) return QSVC_ERR_UNSUPPORTED;
+  Id128 id;
+  if (g_rccl.GetUniqueId(&id) != 0) return QSVC_ERR_HIP;
+  memcpy(out, &id, 128);
+  return QSVC_OK;
+}
+int qsvc_comm_init(qsvc_ctx* c, int rank, int nranks, const void* id, size_t id_len) {
+  if (!c || !id || id_len < 128 || rank < 0 || rank >= nranks) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  const char* e = rccl_load();
+  if (e) return c->fail(QSVC_ERR_UNSUPPORTED, "cannot load RCCL: %s", e);
+  Id128 uid;
+  memcpy(&uid, id, 128);
+  int r = g_rccl.CommInitRank(&c->comm, nranks, uid, rank);
+  if (r != 0) { c->comm = nullptr; return c->fail(QSVC_ERR_HIP, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+  c->rank = rank; c->nranks = nranks;
+  return QSVC_OK;
+}
+int qsvc_comm_destroy(qsvc_ctx* c) {
+  if (!c) return QSVC_ERR_INVALID;
+  if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+  return QSVC_OK;
+}
+int qsvc_halo_exchange(qsvc_ctx* c, int t) {
+  if (!c || t < 1 || t > QSVC_MAX_T) return QSVC_ERR_INVALID;
+  if (!c->comm) return c->fail(QSVC_ERR_STATE, "qsvc_comm_init not called");
+  (void)hipSetDevice(c->dev);
+  Level& lv = c->lv[t];
+  if (!lv.mv_bs) return c->fail(QSVC_ERR_STATE, "halo exchange before decorrelate of t=%d", t);
+  size_t n = qsvc_halo_bytes(c, lv.mv_bs);
+  bool left = c->rank > 0, right = c->rank + 1 < c->nranks;
+  int r;
+  if (left) { if ((r = halo_pack(c, t, 0))) return r; if ((r = c->halo_rx[0].ensure(c, n))) return r; }
+  if (right) { if ((r = halo_pack(c, t, 1))) return r; if ((r = c->halo_rx[1].ensure(c, n))) return r; }
+  const int ncclUint8 = 1;  // ncclUint8 / ncclChar enum value in nccl.h
+  int e = g_rccl.GroupStart();
+  if (!e && left) e = g_rccl.Send(c->halo_tx[0].p, n, ncclUint8, c->rank - 1, c->comm, c->st);
+  if (!e && left) e = g_rccl.Recv(c->halo_rx[0].p, n, ncclUint8, c->rank - 1, c->comm, c->st);
+  if (!e && right) e = g_rccl.Send(c->halo_tx[1].p, n, ncclUint8, c->rank + 1, c->comm, c->st);
+  if (!e && right) e = g_rccl.Recv(c->halo_rx[1].p, n, ncclUint8, c->rank + 1, c->comm, c->st);
+  int e2 = g_rccl.GroupEnd();
+  if (e || e2) return c->fail(QSVC_ERR_HIP, "RCCL halo exchange: %s", g_rccl.GetErrorString(e ? e : e2));
+  lv.halo[0] = left ? c->halo_rx[0].p : nullptr;
+  lv.halo[1] = right ? c->halo_rx[1].p : nullptr;
+  return QSVC_OK;
+}
+
+// ---- truncating 5/3 on a host plane ---------------------------------------------------------------
+int qsvc_dwt53_trunc(qsvc_ctx* c, int16_t* plane, int H, int W, int stride, int levels, int inverse) {
+  if (!c || !plane || H < 2 || W < 2 || stride < W || levels < 0) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  if ((H >> (levels ? levels - 1 : 0)) < 2 || (W >> (levels ? levels - 1 : 0)) < 2)
+    return c->fail(QSVC_ERR_INVALID, "too many levels for %dx%d", W, H);
+  size_t bytes = (size_t)H * stride * sizeof(int16_t);
+  int r;
+  if ((r = c->tmp16[0].ensure(c, bytes))) return r;
+  if ((r = c->tmp16[1].ensure(c, bytes))) return r;
+  int16_t* A = (int16_t*)c->tmp16[0].p; int16_t* B = (int16_t*)c->tmp16[1].p;
+  HIPCHK(c, hipMemcpyAsync(A, plane, bytes, hipMemcpyHostToDevice, c->st));
+  for (int k = 0; k < levels; k++) {
+    int lv = inverse ? levels - 1 - k : k;
+    int ny = H >> lv, nx = W >> lv;
+    launch_dwt53t_level(c->st, A, B, stride, ny, nx, inverse);
+    HIPCHK(c, hipMemcpy2DAsync(A, (size_t)stride * 2, B, (size_t)stride * 2, (size_t)nx * 2, ny, hipMemcpyDeviceToDevice, c->st));
+  }
+  HIPCHK(c, hipMemcpyAsync(plane, A, bytes, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, hipGetLastError());
+  return QSVC_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------
+int qsvc_set_profiling(qsvc_ctx* c, int on) {
+  if (!c) return QSVC_ERR_INVALID;
+  (void)hipStreamSynchronize(c->st);
+  for (auto& s : c->segs) for (auto& p : s.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  c->segs.clear();
+  c->profiling = on;
+  return QSVC_OK;
+}
+int qsvc_get_timings(qsvc_ctx* c, const char** names, float* ms, int* launches, int cap) {
+  if (!c) return QSVC_ERR_INVALID;
+  (void)hipStreamSynchronize(c->st);
+  int n = 0;
+  for (auto& s : c->segs) {
+    if (n >= cap) break;
+    float tot = 0;
+    for (auto& p : s.ev) { float m = 0; if (hipEventElapsedTime(&m, p.first, p.second) == hipSuccess) tot += m; }
+    names[n] = s.name.c_str(); ms[n] = tot; if (launches) launches[n] = (int)s.ev.size();
+    n++;
+  }
+  return n;
+}
+
+}  // extern "C"

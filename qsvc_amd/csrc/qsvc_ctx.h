@@ -1,0 +1,69 @@
+// qsvc_amd/csrc/qsvc_ctx.h -- the context behind the C ABI (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/qsvc_hip.h"
+#include "mctf_kernels.h"
+
+#define QSVC_MAX_T 15
+
+struct qsvc_ctx;
+
+struct DevBuf {  // grow-only device allocation: steady-state stage calls never hipMalloc
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(qsvc_ctx* c, size_t n);
+  void release();
+};
+
+struct Level {  // the device-resident "files" of temporal subband t
+  DevBuf low, high, pred;        // low_t, high_t, prediction_even_t
+  int low_n = 0, high_n = 0, pred_n = 0;
+  DevBuf mv_raw, mv_filt;        // motion_t, motion_filtered_t
+  int mv_raw_n = 0, mv_filt_n = 0, mv_bs = 0;
+  DevBuf hist;                   // [nB][3][256] u32
+  std::string types;             // frame_types_t
+  const void* halo[2] = {nullptr, nullptr};
+};
+
+struct Seg {
+  std::string name;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+struct Prof {
+  Seg* cur = nullptr;
+  void begin(qsvc_ctx* c, const char* name);
+  void end(qsvc_ctx* c);
+};
+
+struct J2kState;
+
+struct qsvc_ctx {
+  int dev = 0;
+  hipStream_t st = nullptr;
+  int W = 0, H = 0;
+  size_t F = 0;
+  int keep_pred = 0;
+  std::vector<Level> lv;
+  std::vector<DevBuf> snap;  // ME pyramid snapshots per DWT level
+  DevBuf mvtmp[2], scal, tmp16[2];
+  DevBuf halo_tx[2], halo_rx[2];  // boundary records: [0] left neighbour, [1] right neighbour
+  uint8_t halo_tb[2][16];
+  void* comm = nullptr;            // ncclComm_t (RCCL), line topology
+  int rank = 0, nranks = 1;
+  std::vector<uint32_t> hhist;
+  std::string err;
+  int profiling = 0;
+  std::vector<Seg> segs;
+  J2kState* j2k = nullptr;
+  int fail(int code, const char* fmt, ...);
+  int hipfail(hipError_t e, const char* what);
+};
+
+void j2k_release(qsvc_ctx* c);

@@ -1,0 +1,249 @@
+"""ctypes binding of libqsvc_hip.so (include/qsvc_hip.h) -- the only compute backend of this package.
+
+There is no CPU fallback: if the shared library is missing or no GPU is usable, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqsvc_hip.so")
+
+LOW, HIGH, PRED = 0, 1, 2
+MOTION_RAW, MOTION_FILTERED = 0, 1
+
+# every symbol include/qsvc_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "qsvc_init", "qsvc_destroy", "qsvc_last_error", "qsvc_stream", "qsvc_sync", "qsvc_seq_config",
+    "qsvc_put_frames", "qsvc_get_frames", "qsvc_put_motion", "qsvc_get_motion", "qsvc_put_frame_types",
+    "qsvc_get_frame_types", "qsvc_get_histograms", "qsvc_motion_estimate", "qsvc_decorrelate", "qsvc_update",
+    "qsvc_analyze_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
+    "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_dwt53_trunc",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_plane", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
+]
+
+
+class J2kParams(C.Structure):
+    _fields_ = [("reversible", C.c_int), ("levels", C.c_int), ("layers", C.c_int), ("cblk_w", C.c_int),
+                ("cblk_h", C.c_int), ("use_sop", C.c_int), ("base_step", C.c_float), ("slopes", C.c_int * 16)]
+
+
+class QsvcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"qsvc error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libqsvc_hip.so; raises if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built: run `make -C qsvc_amd/csrc` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    vp, i, u8p, i16p = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p
+    L.qsvc_init.argtypes = [i, C.POINTER(vp)]
+    L.qsvc_destroy.argtypes = [vp]; L.qsvc_destroy.restype = None
+    L.qsvc_last_error.argtypes = [vp]; L.qsvc_last_error.restype = C.c_char_p
+    L.qsvc_stream.argtypes = [vp]; L.qsvc_stream.restype = vp
+    L.qsvc_sync.argtypes = [vp]
+    L.qsvc_seq_config.argtypes = [vp, i, i, i]
+    L.qsvc_put_frames.argtypes = [vp, i, i, i, i, i, u8p]
+    L.qsvc_get_frames.argtypes = [vp, i, i, i, i, u8p]
+    L.qsvc_put_motion.argtypes = [vp, i, i, i, i, i16p]
+    L.qsvc_get_motion.argtypes = [vp, i, i, i16p]
+    L.qsvc_put_frame_types.argtypes = [vp, i, i, C.c_char_p]
+    L.qsvc_get_frame_types.argtypes = [vp, i, C.c_char_p]
+    L.qsvc_get_histograms.argtypes = [vp, i, vp]
+    L.qsvc_motion_estimate.argtypes = [vp, i, i, i, i]
+    L.qsvc_decorrelate.argtypes = [vp, i, i, i, i, i]
+    L.qsvc_update.argtypes = [vp, i, i, i, C.c_float]
+    L.qsvc_analyze_step.argtypes = [vp, i, i, i, i, i, C.c_float]
+    L.qsvc_halo_bytes.argtypes = [vp, i]; L.qsvc_halo_bytes.restype = C.c_size_t
+    L.qsvc_halo_export_host.argtypes = [vp, i, i, vp]
+    L.qsvc_halo_import_host.argtypes = [vp, i, i, vp]
+    L.qsvc_comm_unique_id.argtypes = [vp, C.c_size_t]
+    L.qsvc_comm_init.argtypes = [vp, i, i, vp, C.c_size_t]
+    L.qsvc_comm_destroy.argtypes = [vp]
+    L.qsvc_halo_exchange.argtypes = [vp, i]
+    L.qsvc_dwt53_trunc.argtypes = [vp, i16p, i, i, i, i, i]
+    L.qsvc_j2k_encode_frames.argtypes = [vp, i, i, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.qsvc_j2k_encode_plane.argtypes = [vp, u8p, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.qsvc_j2k_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.qsvc_set_profiling.argtypes = [vp, i]
+    L.qsvc_get_timings.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), i]
+    _lib = L
+    return L
+
+
+def frame_bytes(W: int, H: int) -> int:
+    return W * H + 2 * (W // 2) * (H // 2)
+
+
+def j2k_params(reversible=False, levels=4, layers=1, cblk=64, use_sop=True, base_step=1.0 / 256, slopes=()):
+    p = J2kParams()
+    p.reversible, p.levels, p.layers, p.cblk_w, p.cblk_h, p.use_sop = int(reversible), levels, layers, cblk, cblk, int(use_sop)
+    p.base_step = base_step
+    for k in range(16):
+        p.slopes[k] = int(slopes[k]) if k < len(slopes) else 0
+    return p
+
+
+class Engine:
+    """One GPU context (one per process / per GPU)."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        h = C.c_void_p()
+        r = self.L.qsvc_init(device, C.byref(h))
+        if r != 0 or not h:
+            raise QsvcError(r, "qsvc_init failed: no usable HIP device (this package has no CPU fallback)")
+        self.h = h
+        self.W = self.H = self.F = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.qsvc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r != 0:
+            raise QsvcError(r, self.L.qsvc_last_error(self.h).decode())
+
+    # ---- sequence / files
+    def seq_config(self, W, H, keep_prediction=False):
+        self._chk(self.L.qsvc_seq_config(self.h, W, H, int(keep_prediction)))
+        self.W, self.H, self.F = W, H, frame_bytes(W, H)
+
+    def put_frames(self, kind, t, frames: np.ndarray, first=0, total=None):
+        a = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, self.F)
+        total = a.shape[0] if total is None else total
+        self._chk(self.L.qsvc_put_frames(self.h, kind, t, first, a.shape[0], total, a.ctypes.data))
+
+    def get_frames(self, kind, t, first, count) -> np.ndarray:
+        out = np.empty((count, self.F), dtype=np.uint8)
+        self._chk(self.L.qsvc_get_frames(self.h, kind, t, first, count, out.ctypes.data))
+        return out
+
+    def put_motion(self, kind, t, mv: np.ndarray, block_size):
+        a = np.ascontiguousarray(mv, dtype=np.int16)
+        self._chk(self.L.qsvc_put_motion(self.h, kind, t, a.shape[0], block_size, a.ctypes.data))
+
+    def get_motion(self, kind, t, nB, block_size) -> np.ndarray:
+        out = np.empty((nB, 4, self.H // block_size, self.W // block_size), dtype=np.int16)
+        self._chk(self.L.qsvc_get_motion(self.h, kind, t, out.ctypes.data))
+        return out
+
+    def put_frame_types(self, t, types: bytes):
+        self._chk(self.L.qsvc_put_frame_types(self.h, t, len(types), types))
+
+    def get_frame_types(self, t, nB) -> bytes:
+        buf = C.create_string_buffer(nB + 1)
+        self._chk(self.L.qsvc_get_frame_types(self.h, t, buf))
+        return buf.raw[:nB]
+
+    def get_histograms(self, t, nB) -> np.ndarray:
+        out = np.empty((nB, 3, 256), dtype=np.uint32)
+        self._chk(self.L.qsvc_get_histograms(self.h, t, out.ctypes.data))
+        return out
+
+    # ---- stages
+    def motion_estimate(self, t, pictures, block_size, search_range):
+        self._chk(self.L.qsvc_motion_estimate(self.h, t, pictures, block_size, search_range))
+
+    def decorrelate(self, t, pictures, block_size, search_range, always_B=0):
+        self._chk(self.L.qsvc_decorrelate(self.h, t, pictures, block_size, search_range, always_B))
+
+    def update(self, t, pictures, block_size, update_factor=0.25):
+        self._chk(self.L.qsvc_update(self.h, t, pictures, block_size, update_factor))
+
+    def analyze_step(self, t, pictures, block_size, search_range, always_B=0, update_factor=0.25):
+        self._chk(self.L.qsvc_analyze_step(self.h, t, pictures, block_size, search_range, always_B, update_factor))
+
+    def sync(self):
+        self._chk(self.L.qsvc_sync(self.h))
+
+    # ---- open-GOP boundary records
+    def halo_bytes(self, block_size) -> int:
+        return int(self.L.qsvc_halo_bytes(self.h, block_size))
+
+    def halo_export(self, t, side, block_size) -> np.ndarray:
+        out = np.empty(self.halo_bytes(block_size), dtype=np.uint8)
+        self._chk(self.L.qsvc_halo_export_host(self.h, t, side, out.ctypes.data))
+        return out
+
+    def halo_import(self, t, side, record):
+        if record is None:
+            self._chk(self.L.qsvc_halo_import_host(self.h, t, side, None))
+        else:
+            a = np.ascontiguousarray(record, dtype=np.uint8)
+            self._chk(self.L.qsvc_halo_import_host(self.h, t, side, a.ctypes.data))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        r = load_library().qsvc_comm_unique_id(buf, 128)
+        if r != 0:
+            raise QsvcError(r, "cannot create an RCCL unique id")
+        return buf.raw
+
+    def comm_init(self, rank, nranks, uid: bytes):
+        self._chk(self.L.qsvc_comm_init(self.h, rank, nranks, uid, len(uid)))
+
+    def halo_exchange(self, t):
+        self._chk(self.L.qsvc_halo_exchange(self.h, t))
+
+    # ---- transforms
+    def dwt53_trunc(self, plane: np.ndarray, levels: int, inverse=False) -> np.ndarray:
+        p = np.ascontiguousarray(plane, dtype=np.int16).copy()
+        H, W = p.shape
+        self._chk(self.L.qsvc_dwt53_trunc(self.h, p.ctypes.data, H, W, W, levels, int(inverse)))
+        return p
+
+    # ---- JPEG 2000
+    def j2k_encode_frames(self, kind, t, first, count, params: J2kParams, cap=None):
+        cap = cap or (count * self.F * 2 + (1 << 20))
+        out = np.empty(cap, dtype=np.uint8)
+        offs = (C.c_size_t * (3 * count + 1))()
+        self._chk(self.L.qsvc_j2k_encode_frames(self.h, kind, t, first, count, C.byref(params), out.ctypes.data, cap, offs))
+        o = list(offs)
+        return [out[o[k]:o[k + 1]].tobytes() for k in range(3 * count)]
+
+    def j2k_encode_plane(self, plane: np.ndarray, params: J2kParams) -> bytes:
+        p = np.ascontiguousarray(plane, dtype=np.uint8)
+        H, W = p.shape
+        cap = H * W * 2 + (1 << 16)
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t()
+        self._chk(self.L.qsvc_j2k_encode_plane(self.h, p.ctypes.data, H, W, C.byref(params), out.ctypes.data, cap, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def j2k_stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.qsvc_j2k_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(codeblocks=a.value, passes=b.value, symbols=c.value)
+
+    # ---- profiling
+    def set_profiling(self, on=True):
+        self._chk(self.L.qsvc_set_profiling(self.h, int(on)))
+
+    def timings(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n_l = (C.c_int * cap)()
+        n = self.L.qsvc_get_timings(self.h, names, ms, n_l, cap)
+        return {names[k].decode(): (ms[k], n_l[k]) for k in range(max(n, 0))}

@@ -1,0 +1,132 @@
+// tests/emul/emul.cpp -- TEST INFRASTRUCTURE: host loop harness over the kernel thread bodies.
+//
+// Compiles qsvc_amd/csrc/mctf_threads.h (the exact per-thread code the HIP kernels run) with g++
+// and drives it with plain nested loops in place of the HIP grid, so kernel indexing and arithmetic
+// can be checked against the oracle in a container that has no GPU.  It is NOT a product fallback:
+// nothing in qsvc_amd/ loads this library, and the GPU parity tests do not use it.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../qsvc_amd/csrc/mctf_threads.h"
+
+using namespace qsvc;
+
+static LevelGeom make_geom(int P, int W, int H, int bs, int S) {
+  LevelGeom g;
+  g.W = W; g.H = H; g.bs = bs; g.BY = H / bs; g.BX = W / bs; g.S = S; g.P = P; g.nB = P / 2;
+  g.F = (size_t)W * H + 2 * (size_t)(W / 2) * (H / 2);
+  return g;
+}
+static int ilog2i(int s) { int l = 0; while ((1 << (l + 1)) <= s) l++; return l; }
+
+extern "C" {
+
+int emul_dwt53t(int16_t* plane, int stride, int H, int W, int levels, int inverse) {
+  std::vector<int16_t> tmp((size_t)H * W);
+  if (!inverse) {
+    for (int lv = 0; lv < levels; lv++) {
+      int ny = H >> lv, nx = W >> lv;
+      auto P = [&](int y, int x) { return (int)plane[(size_t)y * stride + x]; };
+      for (int y = 0; y < ny; y++) for (int x = 0; x < nx; x++) tmp[(size_t)y * W + x] = (int16_t)analyze2d_coef(P, y, x, ny, nx);
+      for (int y = 0; y < ny; y++) for (int x = 0; x < nx; x++) plane[(size_t)y * stride + x] = tmp[(size_t)y * W + x];
+    }
+  } else {
+    for (int lv = levels - 1; lv >= 0; lv--) {
+      int ny = H >> lv, nx = W >> lv;
+      auto P = [&](int y, int x) { return (int)plane[(size_t)y * stride + x]; };
+      for (int y = 0; y < ny; y++) for (int x = 0; x < nx; x++) tmp[(size_t)y * W + x] = (int16_t)synthesize2d_sample(P, y, x, ny, nx);
+      for (int y = 0; y < ny; y++) for (int x = 0; x < nx; x++) plane[(size_t)y * stride + x] = tmp[(size_t)y * W + x];
+    }
+  }
+  return 0;
+}
+
+int emul_motion_estimate(const uint8_t* low, int P, int W, int H, int bs, int S, int16_t* mv_out) {
+  LevelGeom g = make_geom(P, W, H, bs, S);
+  int L = ilog2i(S) - 1;
+  if (L < 0) L = 0;
+  if ((1 << ilog2i(S)) != S || (H % (1 << L)) || (W % (1 << L))) return -2;
+  size_t N = (size_t)H * W, fld = (size_t)g.BY * g.BX;
+  std::vector<std::vector<int16_t>> snap(L + 1);
+  for (int l = 1; l <= L; l++) {
+    snap[l].assign((size_t)P * N, 0);
+    int R = imin(H, imax(desp(g.BY, l) * bs + S, H >> l)), C = imin(W, imax(desp(g.BX, l) * bs + S, W >> l));
+    for (int pic = 0; pic < P; pic++)
+      for (int y = 0; y < R; y++)
+        for (int x = 0; x < C; x++) {
+          if (l == 1) pyr_thread<uint8_t>(low, g.F, W, snap[l].data(), N, H, W, l, R, C, x, y, pic);
+          else pyr_thread<int16_t>(snap[l - 1].data(), N, W, snap[l].data(), N, H, W, l, R, C, x, y, pic);
+        }
+  }
+  std::vector<int16_t> mvb[2];
+  mvb[0].assign((size_t)g.nB * 4 * fld, 0); mvb[1].assign((size_t)g.nB * 4 * fld, 0);
+  const int16_t* prev = nullptr;
+  for (int l = L; l >= 0; l--) {
+    MeArgs a;
+    a.g = g; a.frames = low; a.snap = l ? snap[l].data() : nullptr; a.snap_pic_stride = N;
+    a.mv_prev = prev; a.mv_out = l == 0 ? mv_out : mvb[l & 1].data(); a.l = l;
+    a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l);
+    if (l == 0) memset(mv_out, 0, sizeof(int16_t) * g.nB * 4 * fld);
+    for (int i = 0; i < g.nB; i++)
+      for (int by = 0; by < a.nby; by++)
+        for (int bx = 0; bx < a.nbx; bx++) {
+          int pvx, pvy, nvx, nvy, sad[18], tot[18] = {0};
+          me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
+          for (int lane = 0; lane < 64; lane++) {  // 64 lanes, summed like the wave reduction
+            if (l == 0) { MePlane<uint8_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
+            else { MePlane<int16_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
+            for (int k = 0; k < 18; k++) tot[k] += sad[k];
+          }
+          me_block_store(a, i, by, bx, tot, pvx, pvy, nvx, nvy);
+        }
+    prev = a.mv_out;
+  }
+  return 0;
+}
+
+int emul_predict(const uint8_t* low, int P, int W, int H, int bs, int S, const int16_t* mv, uint8_t* high, uint8_t* pred,
+                 unsigned* hist /*[nB][3][256]*/) {
+  LevelGeom g = make_geom(P, W, H, bs, S);
+  if (H % bs || W % bs || (W & 1) || (H & 1)) return -2;
+  PredArgs a = {g, low, mv, high, pred, hist};
+  memset(hist, 0, sizeof(unsigned) * g.nB * 3 * 256);
+  size_t fld = (size_t)g.BY * g.BX;
+  for (int i = 0; i < g.nB; i++) {
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        int ob, rb;
+        pred_luma_thread(a, x, y, i, ob, rb);
+        hist[((size_t)i * 3 + 0) * 256 + ob]++; hist[((size_t)i * 3 + 1) * 256 + rb]++;
+      }
+    for (int c = 1; c < 3; c++)
+      for (int y = 0; y < H / 2; y++)
+        for (int x = 0; x < W / 2; x++) pred_chroma_thread(a, x, y, i, c);
+    for (size_t k = 0; k < 4 * fld; k++) hist[((size_t)i * 3 + 2) * 256 + ((mv[(size_t)i * 4 * fld + k] + 128) & 255)]++;
+  }
+  return 0;
+}
+
+int emul_update(const uint8_t* low, int P, int W, int H, int bs, const uint8_t* high, const int16_t* mv, const char* types,
+                float uf, int reach, const uint8_t* halo_l, int halo_l_type, const uint8_t* halo_r, int halo_r_type,
+                uint8_t* low_out) {
+  LevelGeom g = make_geom(P, W, H, bs, 0);
+  if (H % bs || W % bs || (W & 1) || (H & 1)) return -2;
+  UpdArgs a;
+  a.g = g; a.frames = low; a.high = high; a.mv = mv; a.types = (const uint8_t*)types; a.low = low_out; a.uf = uf; a.reach = reach;
+  a.halo_high[0] = halo_l; a.halo_mv[0] = halo_l ? (const int16_t*)(halo_l + g.F) : nullptr; a.halo_type[0] = halo_l ? halo_l_type : 0;
+  a.halo_high[1] = halo_r; a.halo_mv[1] = halo_r ? (const int16_t*)(halo_r + g.F) : nullptr; a.halo_type[1] = halo_r ? halo_r_type : 0;
+  for (int j = 0; j <= g.nB; j++) {
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) upd_luma_thread(a, x, y, j);
+    for (int c = 1; c < 3; c++)
+      for (int y = 0; y < H / 2; y++) for (int x = 0; x < W / 2; x++) upd_chroma_thread(a, x, y, j, c);
+  }
+  return 0;
+}
+
+int emul_border_luma(const uint8_t* luma, int H, int W, int b, int16_t* out /*(H+2b)x(W+2b)*/) {
+  BorderGeom g = make_border(H, W, b);
+  for (int y = -b; y < H + b; y++)
+    for (int x = -b; x < W + b; x++) out[(size_t)(y + b) * (W + 2 * b) + (x + b)] = (int16_t)luma_b(luma, g, y, x);
+  return 0;
+}
+}

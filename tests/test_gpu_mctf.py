@@ -1,0 +1,150 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the committed reference goldens."""
+import numpy as np
+import pytest
+
+from helpers import check_levels_against_golden, golden_cases, golden_input, load_golden
+from qsvc_amd.synth import make_clip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from qsvc_amd import hip
+    e = hip.Engine(0)
+    yield e
+    e.close()
+
+
+def run_levels(eng, clip, W, H, TRLs, bs, S, always_B=0, uf=0.25, keep_prediction=True):
+    from qsvc_amd import hip
+    eng.seq_config(W, H, keep_prediction)
+    eng.put_frames(hip.LOW, 0, clip)
+    P = clip.shape[0]
+    out = []
+    for t in range(1, TRLs):
+        nB = P // 2
+        eng.motion_estimate(t, P, bs, S)
+        eng.decorrelate(t, P, bs, S, always_B)
+        eng.update(t, P, bs, uf)
+        out.append(dict(motion=eng.get_motion(hip.MOTION_RAW, t, nB, bs), motion_filtered=eng.get_motion(hip.MOTION_FILTERED, t, nB, bs),
+                        frame_types=eng.get_frame_types(t, nB), high=eng.get_frames(hip.HIGH, t, 0, nB),
+                        low=eng.get_frames(hip.LOW, t, 0, nB + 1),
+                        prediction=eng.get_frames(hip.PRED, t, 0, nB) if keep_prediction else None,
+                        hists=eng.get_histograms(t, nB)))
+        P = (P + 1) // 2
+        S = min(2 * S, 128)
+    return out
+
+
+SUPPORTED = [n for n in golden_cases() if n not in ("odd_350x286", "q7_200x120")]
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_hip_matches_reference_goldens(eng, name):
+    z, m = load_golden(name)
+    clip = golden_input(z, m)
+    levels = run_levels(eng, clip, m["W"], m["H"], m["TRLs"], m["bs"], m["S"])
+    check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "frame_types", "high", "low", "prediction"))
+
+
+@pytest.mark.parametrize("name", ["odd_350x286", "q7_200x120"])
+def test_unsupported_geometries_fail_loudly(eng, name):
+    from qsvc_amd import hip
+    z, m = load_golden(name)
+    clip = golden_input(z, m)
+    with pytest.raises(hip.QsvcError):
+        run_levels(eng, clip, m["W"], m["H"], m["TRLs"], m["bs"], m["S"])
+
+
+CASES = [
+    ("pan_noise", 21, 9, 256, 160, 3, 16, 4),
+    ("edge", 22, 9, 320, 192, 4, 8, 4),
+    ("saturating", 23, 5, 192, 128, 3, 8, 8),
+    ("noise", 24, 5, 128, 128, 2, 32, 16),
+    ("scene_cut", 25, 9, 352, 288, 4, 32, 4),
+    ("binary", 26, 5, 128, 96, 2, 16, 4),
+]
+
+
+@pytest.mark.parametrize("kind,seed,frames,W,H,TRLs,bs,S", CASES)
+def test_hip_matches_oracle_fresh_clips(eng, oracle, kind, seed, frames, W, H, TRLs, bs, S):
+    clip = make_clip(kind, frames, W, H, seed)
+    got = run_levels(eng, clip, W, H, TRLs, bs, S)
+    want = oracle.analyze(clip, W, H, TRLs, bs, S)
+    for t, (g, w) in enumerate(zip(got, want), 1):
+        np.testing.assert_array_equal(g["motion"], w["motion"], err_msg=f"motion_{t}")
+        assert g["frame_types"] == w["frame_types"], f"frame_types_{t}"
+        np.testing.assert_array_equal(g["motion_filtered"], w["motion_filtered"], err_msg=f"motion_filtered_{t}")
+        np.testing.assert_array_equal(g["hists"].astype(np.int32), w["hists"], err_msg=f"hist_{t}")
+        np.testing.assert_array_equal(g["high"], w["high"], err_msg=f"high_{t}")
+        np.testing.assert_array_equal(g["low"], w["low"], err_msg=f"low_{t}")
+
+
+def test_always_B_and_update_factor(eng, oracle):
+    W, H, bs, S = 128, 96, 16, 4
+    clip = make_clip("binary", 5, W, H, 31)
+    got = run_levels(eng, clip, W, H, 2, bs, S, always_B=1, uf=0.5)[0]
+    want = oracle.analyze_step(clip, W, H, bs, S, always_B=1, update_factor=0.5)
+    assert got["frame_types"] == b"BB" == want["frame_types"]
+    np.testing.assert_array_equal(got["high"], want["high"])
+    np.testing.assert_array_equal(got["low"], want["low"])
+    # a non-dyadic factor exercises the separately-rounded float multiply/add of update.cpp:99-106
+    got = run_levels(eng, clip, W, H, 2, bs, S, always_B=1, uf=0.3)[0]
+    want = oracle.analyze_step(clip, W, H, bs, S, always_B=1, update_factor=0.3)
+    np.testing.assert_array_equal(got["low"], want["low"])
+
+
+def test_dwt53_trunc_kernel(eng, oracle):
+    rng = np.random.default_rng(9)
+    for (h, w, lv) in [(16, 16, 2), (24, 40, 3), (9, 8, 1), (17, 33, 1), (270, 480, 2)]:
+        x = rng.integers(-300, 300, size=(h, w)).astype(np.int16)
+        if (h >> (lv - 1)) % 2 or (w >> (lv - 1)) % 2:
+            lv = 1
+        a = eng.dwt53_trunc(x, lv)
+        np.testing.assert_array_equal(a, oracle.dwt53t(x, lv))
+        np.testing.assert_array_equal(eng.dwt53_trunc(a, lv, inverse=True), oracle.dwt53t(a, lv, inverse=True))
+
+
+def test_1080p_level_against_oracle(eng, oracle):
+    """BASELINE config 3 geometry (1920x1080, bs 8), one level of 5 pictures: full-size bit-exactness."""
+    W, H, bs, S = 1920, 1080, 8, 4
+    clip = make_clip("pan_noise", 5, W, H, 43)
+    got = run_levels(eng, clip, W, H, 2, bs, S, keep_prediction=False)[0]
+    want = oracle.analyze_step(clip, W, H, bs, S)
+    np.testing.assert_array_equal(got["motion"], want["motion"])
+    assert got["frame_types"] == want["frame_types"]
+    np.testing.assert_array_equal(got["high"], want["high"])
+    np.testing.assert_array_equal(got["low"], want["low"])
+
+
+def test_halo_split_equals_whole_sequence(eng):
+    """Open-GOP sharding: two halves with exchanged halos == the whole sequence in one piece."""
+    import ctypes as C
+    from qsvc_amd import hip
+    W, H, bs, S = 192, 128, 16, 4
+    clip = make_clip("pan_noise", 9, W, H, 77)
+    whole = run_levels(eng, clip, W, H, 2, bs, S, keep_prediction=False)[0]
+    L = hip.load_library()
+    # left half: pictures 0..4, right half: 4..8, on two contexts of the same GPU
+    e2 = hip.Engine(0)
+    try:
+        halves = []
+        for e, part in ((eng, clip[0:5]), (e2, clip[4:9])):
+            e.seq_config(W, H)
+            e.put_frames(hip.LOW, 0, part)
+            e.motion_estimate(1, 5, bs, S)
+            e.decorrelate(1, 5, bs, S)
+        to_right = eng.halo_export(1, 1, bs)   # left shard's last B picture
+        to_left = e2.halo_export(1, 0, bs)     # right shard's first B picture
+        eng.halo_import(1, 1, to_left)
+        e2.halo_import(1, 0, to_right)
+        eng.update(1, 5, bs, 0.25)
+        e2.update(1, 5, bs, 0.25)
+        left = eng.get_frames(hip.LOW, 1, 0, 3)
+        right = e2.get_frames(hip.LOW, 1, 0, 3)
+        eng.halo_import(1, 1, None)
+        np.testing.assert_array_equal(left[2], right[0], err_msg="boundary picture differs between the two shards")
+        np.testing.assert_array_equal(np.concatenate([left, right[1:]]), whole["low"])
+    finally:
+        e2.close()
