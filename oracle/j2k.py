@@ -1,0 +1,108 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes bindings of the T.800 restatement (oracle/j2k_oracle.c) and an
+independent decoder (OpenJPEG through Pillow) used to pin it.  Parity with the reference's Kakadu is
+UNPINNED (no Kakadu artefact exists under /root/reference); see the header of j2k_oracle.c."""
+from __future__ import annotations
+
+import ctypes as C
+import io
+
+import numpy as np
+
+from . import oracle as _O
+
+
+class Params(C.Structure):
+    _fields_ = [("reversible", C.c_int), ("levels", C.c_int), ("layers", C.c_int), ("cblk_w", C.c_int),
+                ("cblk_h", C.c_int), ("use_sop", C.c_int), ("base_step", C.c_float), ("slopes", C.c_int * 16)]
+
+
+_ready = False
+
+
+def _lib():
+    global _ready
+    L = _O.lib()
+    if not _ready:
+        L.qo_j2k_encode_plane.restype = C.c_long
+        L.qo_j2k_encode_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.qo_j2k_t1_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+        L.qo_j2k_coefficients.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.qo_j2k_dwt97_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.qo_j2k_norm.restype = C.c_double
+        L.qo_j2k_norm.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.qo_j2k_slope_to_lambda.restype = C.c_double
+        L.qo_j2k_slope_to_lambda.argtypes = [C.c_int]
+        _ready = True
+    return L
+
+
+def params(reversible=False, levels=4, layers=1, cblk=64, use_sop=True, base_step=1.0 / 256, slopes=()):
+    p = Params()
+    p.reversible, p.levels, p.layers, p.cblk_w, p.cblk_h, p.use_sop = int(reversible), levels, layers, cblk, cblk, int(use_sop)
+    p.base_step = base_step
+    for k in range(16):
+        p.slopes[k] = int(slopes[k]) if k < len(slopes) else 0
+    return p
+
+
+def encode_plane(plane: np.ndarray, reversible=False, levels=4, layers=1, cblk=64, use_sop=True, base_step=1.0 / 256,
+                 slopes=(), want_stats=False):
+    p = np.ascontiguousarray(plane, dtype=np.uint8)
+    H, W = p.shape
+    cap = H * W * 3 + (1 << 16)
+    out = np.empty(cap, dtype=np.uint8)
+    st = np.zeros(3, dtype=np.uint64)
+    prm = params(reversible, levels, layers, cblk, use_sop, base_step, slopes)
+    n = _lib().qo_j2k_encode_plane(p.ctypes.data, H, W, C.byref(prm), out.ctypes.data, cap, st.ctypes.data)
+    if n < 0:
+        raise RuntimeError(f"qo_j2k_encode_plane failed: {n}")
+    cs = out[:n].tobytes()
+    return (cs, dict(codeblocks=int(st[0]), passes=int(st[1]), symbols=int(st[2]))) if want_stats else cs
+
+
+def coefficients(plane, reversible, levels, base_step=1.0 / 256) -> np.ndarray:
+    p = np.ascontiguousarray(plane, dtype=np.uint8)
+    H, W = p.shape
+    out = np.empty((H, W), dtype=np.int32)
+    _lib().qo_j2k_coefficients(p.ctypes.data, H, W, int(reversible), levels, base_step, out.ctypes.data)
+    return out
+
+
+def dwt97(plane, levels) -> np.ndarray:
+    p = np.ascontiguousarray(plane, dtype=np.uint8)
+    H, W = p.shape
+    out = np.empty((H, W), dtype=np.float32)
+    _lib().qo_j2k_dwt97_plane(p.ctypes.data, H, W, levels, out.ctypes.data)
+    return out
+
+
+def t1_block(vals: np.ndarray, orient: int):
+    v = np.ascontiguousarray(vals, dtype=np.int32)
+    h, w = v.shape
+    out = np.empty(w * h * 4 + 64, dtype=np.uint8)
+    npasses, nbps = C.c_int(), C.c_int()
+    pl = np.zeros(128, dtype=np.int32)
+    n = _lib().qo_j2k_t1_block(v.ctypes.data, w, h, orient, out.ctypes.data, C.byref(npasses), C.byref(nbps), pl.ctypes.data)
+    return out[:n].tobytes(), npasses.value, nbps.value, pl[:npasses.value].copy()
+
+
+def decode(codestream: bytes, layers=None, reduce=0) -> np.ndarray:
+    """Independent decoder: OpenJPEG via Pillow."""
+    from PIL import Image
+    im = Image.open(io.BytesIO(codestream))
+    if reduce:
+        im.reduce = reduce
+    if layers is not None:
+        # Pillow only forwards .layers to the decoder when .reduce is set; patch the tile descriptor directly.
+        im.layers = layers
+        t = im.tile[0]
+        args = (t[3][0], t[3][1], layers) + tuple(t[3][3:])
+        im.tile = [type(t)(t[0], t[1], t[2], args)] if hasattr(t, "_fields") else [(t[0], t[1], t[2], args)]
+    im.load()
+    return np.asarray(im)
+
+
+def psnr(a, b) -> float:
+    d = a.astype(np.float64) - b.astype(np.float64)
+    m = float((d * d).mean())
+    return 99.0 if m == 0 else 10 * np.log10(255.0 ** 2 / m)
