@@ -143,6 +143,9 @@ int qsvc_j2k_encode_frames(qsvc_ctx* ctx, int kind, int t, int first, int count,
 /* Same on a host plane (copied to the device first); one code-stream. */
 int qsvc_j2k_encode_plane(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, const qsvc_j2k_params* p, uint8_t* out,
                           size_t cap, size_t* len);
+/* Unit-testable transform: level shift + `levels` of forward DWT of a host 8-bit plane, Mallat layout.
+ * out receives H*W int32 (reversible 5/3) or H*W float32 (irreversible 9/7, before quantisation). */
+int qsvc_j2k_dwt(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, int reversible, int levels, void* out);
 /* Statistics of the last qsvc_j2k_encode_* call: code-blocks coded, coding passes, MQ symbols. */
 int qsvc_j2k_stats(qsvc_ctx* ctx, uint64_t* codeblocks, uint64_t* passes, uint64_t* symbols);
 

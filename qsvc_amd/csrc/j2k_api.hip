@@ -1,0 +1,548 @@
+// qsvc_amd/csrc/j2k_api.hip -- host side of the JPEG 2000 texture stage: plan (subbands, code-blocks),
+// kernel orchestration, rate allocation, Tier-2 (packet headers, tag trees) and code-stream markers.
+//
+// Replaces the reference's per-picture, per-component `kdu_compress` process
+// (trunk/src/texture_compress_fb_j2k.py:155-195).  Parameters the reference pins there: 8-bit unsigned
+// single component, Clevels = SRLs-1, Clayers = nLayers, Cuse_sop = yes, Creversible = no; Kakadu
+// defaults kept: one tile, 64x64 code-blocks, LRCP, no precinct partition.  Algorithm: ITU-T T.800.
+#include <math.h>
+#include <stdio.h>
+
+#include <algorithm>
+
+#include "j2k_kernels.h"
+#include "qsvc_ctx.h"
+#include "j2k_norms.inc"
+
+using namespace qsvc;
+
+#define J2K_GUARD 2
+#define J2K_MAXLEV 10
+#define J2K_OUTCAP (64 * 64 * 3 + 64)  // bytes per code-block lane buffer (incl. scratch byte)
+
+#define HIPCHK(ctx, call)                                    \
+  do {                                                       \
+    hipError_t e_ = (call);                                  \
+    if (e_ != hipSuccess) return (ctx)->hipfail(e_, #call);  \
+  } while (0)
+
+namespace {
+
+struct Subband {
+  int x0, y0, w, h, orient, dlev, eps, mant, Mb;
+  float delta;
+  int gx, gy, first_cb;  // code-block grid and index of its first block within the plane
+};
+
+struct PlanePlan {  // everything about one plane geometry
+  int W, H, L;
+  std::vector<Subband> sb;
+  int ncb;
+};
+
+double norm_of(bool rev, int orient, int dlev) {
+  if (dlev < 1) dlev = 1;
+  if (dlev > J2K_MAXLEV) dlev = J2K_MAXLEV;
+  return (rev ? kNorm53 : kNorm97)[orient][dlev - 1];
+}
+
+// subbands in code-stream order: LL_L, then HL, LH, HH for d = L..1 (T.800 B.5, tile at the origin)
+void build_plan(PlanePlan& pp, int W, int H, int levels, bool rev, float base_step, int cbw, int cbh) {
+  int L = levels;
+  while (L > 0 && ((W >> (L - 1)) < 1 || (H >> (L - 1)) < 1)) L--;
+  pp.W = W; pp.H = H; pp.L = L;
+  int ws[J2K_MAXLEV + 1], hs[J2K_MAXLEV + 1];
+  ws[0] = W; hs[0] = H;
+  for (int d = 1; d <= L; d++) { ws[d] = (ws[d - 1] + 1) >> 1; hs[d] = (hs[d - 1] + 1) >> 1; }
+  pp.sb.clear();
+  auto add = [&](int x0, int y0, int w, int h, int orient, int dlev) {
+    Subband s;
+    s.x0 = x0; s.y0 = y0; s.w = w; s.h = h; s.orient = orient; s.dlev = dlev;
+    int gain = orient == 0 ? 0 : (orient == 3 ? 2 : 1);
+    int Rb = 8 + gain;
+    if (rev) { s.eps = Rb; s.mant = 0; s.delta = 1.0f; }
+    else {  // T.800 E.1.1: delta = 2^(Rb-eps) (1 + mant/2^11), target base_step*2^8/norm
+      double target = (double)base_step * 256.0 / norm_of(false, orient, dlev ? dlev : 1);
+      int e = (int)floor(log2(target));
+      double m = target / ldexp(1.0, e) - 1.0;
+      int mant = (int)floor(m * 2048.0);
+      mant = mant < 0 ? 0 : (mant > 2047 ? 2047 : mant);
+      int eps = Rb - e;
+      if (eps < 0) { eps = 0; mant = 0; }
+      if (eps > 31) { eps = 31; mant = 0; }
+      s.eps = eps; s.mant = mant;
+      s.delta = (float)(ldexp(1.0, Rb - eps) * (1.0 + mant / 2048.0));
+    }
+    s.Mb = J2K_GUARD + s.eps - 1;
+    s.gx = (w + cbw - 1) / cbw; s.gy = (h + cbh - 1) / cbh;
+    pp.sb.push_back(s);
+  };
+  add(0, 0, ws[L], hs[L], 0, L);
+  for (int d = L; d >= 1; d--) {
+    int lw = ws[d], lh = hs[d], hw = ws[d - 1] - lw, hh = hs[d - 1] - lh;
+    add(lw, 0, hw, lh, 1, d);
+    add(0, lh, lw, hh, 2, d);
+    add(lw, lh, hw, hh, 3, d);
+  }
+  int k = 0;
+  for (auto& s : pp.sb) { s.first_cb = k; k += s.gx * s.gy; }
+  pp.ncb = k;
+}
+
+// ---- Tier-2 helpers ---------------------------------------------------------------------------
+struct OBuf {
+  uint8_t* p; size_t n, cap; bool ovf;
+  void put(int v) { if (n < cap) p[n] = (uint8_t)v; else ovf = true; n++; }
+  void u16(int v) { put(v >> 8); put(v & 255); }
+  void u32(uint32_t v) { u16(v >> 16); u16(v & 0xFFFF); }
+  void bytes(const uint8_t* s, size_t k) { if (n + k <= cap) memcpy(p + n, s, k); else ovf = true; n += k; }
+};
+struct BitW {  // packet-header bit writer with the 0xFF stuffing rule (T.800 B.10.1)
+  OBuf* o; int acc = 0, nbits = 0; bool last_ff = false;
+  void bit(int v) {
+    int cap = last_ff ? 7 : 8;
+    acc = (acc << 1) | (v & 1); nbits++;
+    if (nbits == cap) { o->put(acc); last_ff = acc == 0xFF; acc = 0; nbits = 0; }
+  }
+  void bits(unsigned v, int n) { for (int i = n - 1; i >= 0; i--) bit((v >> i) & 1); }
+  void flush() {
+    if (nbits) { int cap = last_ff ? 7 : 8; int v = acc << (cap - nbits); o->put(v); last_ff = v == 0xFF; acc = 0; nbits = 0; }
+    if (last_ff) { o->put(0); last_ff = false; }
+  }
+};
+struct TagTree {  // T.800 B.10.2
+  int w = 0, h = 0, nlev = 0;
+  int lw[16], lh[16], off[16];
+  std::vector<int> val, low;
+  std::vector<uint8_t> known;
+  void init(int w_, int h_, const int* leaf) {
+    w = w_; h = h_; nlev = 0;
+    int n = 0, cw = w, ch = h;
+    for (;;) { lw[nlev] = cw; lh[nlev] = ch; off[nlev] = n; n += cw * ch; nlev++; if (cw == 1 && ch == 1) break; cw = (cw + 1) >> 1; ch = (ch + 1) >> 1; }
+    val.assign(n, 0); low.assign(n, 0); known.assign(n, 0);
+    for (int i = 0; i < w * h; i++) val[i] = leaf[i];
+    for (int l = 1; l < nlev; l++)
+      for (int y = 0; y < lh[l]; y++)
+        for (int x = 0; x < lw[l]; x++) {
+          int mn = 0x7FFFFFFF;
+          for (int dy = 0; dy < 2; dy++)
+            for (int dx = 0; dx < 2; dx++) {
+              int cy = 2 * y + dy, cx = 2 * x + dx;
+              if (cy < lh[l - 1] && cx < lw[l - 1]) mn = std::min(mn, val[off[l - 1] + cy * lw[l - 1] + cx]);
+            }
+          val[off[l] + y * lw[l] + x] = mn;
+        }
+  }
+  void encode(BitW& b, int lx, int ly, int threshold) {
+    int path[16], n = 0;
+    for (int l = 0; l < nlev; l++) path[n++] = off[l] + (ly >> l) * lw[l] + (lx >> l);
+    int lo = 0;
+    for (int k = n - 1; k >= 0; k--) {
+      int nd = path[k];
+      if (lo > low[nd]) low[nd] = lo; else lo = low[nd];
+      while (lo < threshold) {
+        if (lo >= val[nd]) { if (!known[nd]) { b.bit(1); known[nd] = 1; } break; }
+        b.bit(0); lo++;
+      }
+      low[nd] = lo;
+    }
+  }
+};
+int ilog2i(int v) { int l = 0; while (v > 1) { v >>= 1; l++; } return l; }
+void put_npasses(BitW& b, int n) {  // T.800 Table B.4
+  if (n == 1) b.bit(0);
+  else if (n == 2) b.bits(2, 2);
+  else if (n <= 5) b.bits(0xC | (n - 3), 4);
+  else if (n <= 36) b.bits(0x1E0 | (n - 6), 9);
+  else b.bits(0xFF80 | (n - 37), 16);
+}
+// Kakadu-style logarithmic slope -> Lagrangian threshold in 8-bit-sample^2 per byte.  APPROXIMATE: the
+// `-slope` semantics are Kakadu-private; s = 256*(192 + log2(dD/dL)), D in full-scale^2.
+double slope_to_lambda(int slope) { return pow(2.0, slope / 256.0 - 176.0); }
+// passes on the convex hull of (length, distortion) with slope >= lambda (PCRD-opt, T.800 J.14)
+int passes_for_lambda(int npasses, const int* plen, const long long* pdist, double weight, double lambda) {
+  if (lambda <= 0) return npasses;
+  int best = 0, best_l = 0, cur = 0;
+  while (cur < npasses) {
+    double bs = -1; int bi = -1;
+    double cd = 0;
+    for (int i = cur; i < npasses; i++) {
+      cd += (double)pdist[i] * weight;
+      int dl = plen[i] - best_l;
+      if (dl <= 0) { if (cd > 0) { bs = 1e300; bi = i; } continue; }
+      double s = cd / dl;
+      if (s >= bs) { bs = s; bi = i; }
+    }
+    if (bi < 0 || bs < lambda) break;
+    best_l = plen[bi]; best = bi + 1; cur = bi + 1;
+  }
+  return best;
+}
+
+struct HostCb {  // host view of one coded block
+  int len, npasses, nbps, zbp;
+  size_t data_off;              // into the gathered byte buffer
+  int layer_passes[16];
+  int first_layer, lblock;
+  bool included;
+};
+
+}  // namespace
+
+struct J2kState {
+  DevBuf coefA, coefB, planes_d, cbs_d, nbps_d, mags, flags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
+  uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
+  std::vector<PlaneDesc> planes;
+  std::vector<CbDesc> cbs;
+  std::vector<CbOut> res;
+  std::vector<int> plen;
+  std::vector<long long> pdist;
+  std::vector<HostCb> hcb;
+  uint64_t st_cb = 0, st_pass = 0, st_sym = 0;
+};
+
+void j2k_release(qsvc_ctx* c) {
+  J2kState* s = c->j2k;
+  if (!s) return;
+  DevBuf* all[] = {&s->coefA, &s->coefB, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->flags, &s->outbuf, &s->res_d, &s->plen_d,
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d};
+  for (auto* b : all) b->release();
+  if (s->gath_h) (void)hipHostFree(s->gath_h);
+  delete s;
+  c->j2k = nullptr;
+}
+
+// Write one plane's code-stream (T.800 Annex A markers + LRCP packets) from its coded blocks.
+static long write_codestream(const PlanePlan& pp, const qsvc_j2k_params& prm, int layers, int cbw, int cbh, HostCb* cb,
+                             const int* plen_all /*[ncb][T1_MAXPASS]*/, const uint8_t* data, uint8_t* out, size_t cap) {
+  const int L = pp.L, nsb = (int)pp.sb.size();
+  OBuf o{out, 0, cap, false};
+  o.u16(0xFF4F);                                      // SOC
+  o.u16(0xFF51); o.u16(41); o.u16(0);                 // SIZ
+  o.u32(pp.W); o.u32(pp.H); o.u32(0); o.u32(0); o.u32(pp.W); o.u32(pp.H); o.u32(0); o.u32(0);
+  o.u16(1); o.put(7); o.put(1); o.put(1);
+  o.u16(0xFF52); o.u16(12);                           // COD
+  o.put(prm.use_sop ? 0x02 : 0x00);
+  o.put(0); o.u16(layers); o.put(0);
+  o.put(L); o.put(ilog2i(cbw) - 2); o.put(ilog2i(cbh) - 2); o.put(0); o.put(prm.reversible ? 1 : 0);
+  o.u16(0xFF5C);                                      // QCD
+  if (prm.reversible) { o.u16(3 + nsb); o.put((J2K_GUARD << 5) | 0); for (auto& s : pp.sb) o.put(s.eps << 3); }
+  else { o.u16(3 + 2 * nsb); o.put((J2K_GUARD << 5) | 2); for (auto& s : pp.sb) o.u16((s.eps << 11) | s.mant); }
+  size_t sot = o.n;
+  o.u16(0xFF90); o.u16(10); o.u16(0); o.u32(0); o.put(0); o.put(1);  // SOT (Psot patched below)
+  o.u16(0xFF93);                                      // SOD
+  std::vector<TagTree> incl(nsb), zbpt(nsb);
+  std::vector<int> v1, v2;
+  for (int s = 0; s < nsb; s++) {
+    int n = pp.sb[s].gx * pp.sb[s].gy;
+    if (!n) continue;
+    v1.resize(n); v2.resize(n);
+    for (int i = 0; i < n; i++) { v1[i] = cb[pp.sb[s].first_cb + i].first_layer; v2[i] = cb[pp.sb[s].first_cb + i].zbp; }
+    incl[s].init(pp.sb[s].gx, pp.sb[s].gy, v1.data()); zbpt[s].init(pp.sb[s].gx, pp.sb[s].gy, v2.data());
+  }
+  int nsop = 0;
+  for (int l = 0; l < layers; l++)
+    for (int r = 0; r <= L; r++) {
+      int s0 = r == 0 ? 0 : 1 + 3 * (r - 1), s1 = r == 0 ? 1 : s0 + 3;
+      if (prm.use_sop) { o.u16(0xFF91); o.u16(4); o.u16(nsop & 0xFFFF); }
+      nsop++;
+      BitW bw; bw.o = &o;
+      bool any = false;
+      for (int s = s0; s < s1 && !any; s++)
+        for (int i = 0; i < pp.sb[s].gx * pp.sb[s].gy; i++) {
+          HostCb& c = cb[pp.sb[s].first_cb + i];
+          if (c.layer_passes[l] > (l ? c.layer_passes[l - 1] : 0)) { any = true; break; }
+        }
+      bw.bit(any);
+      if (any)
+        for (int s = s0; s < s1; s++)
+          for (int i = 0; i < pp.sb[s].gx * pp.sb[s].gy; i++) {
+            int ci = pp.sb[s].first_cb + i;
+            HostCb& c = cb[ci];
+            const int* pl = plen_all + (size_t)ci * T1_MAXPASS;
+            int bx = i % pp.sb[s].gx, by = i / pp.sb[s].gx;
+            int prev = l ? c.layer_passes[l - 1] : 0, now = c.layer_passes[l], add = now - prev;
+            if (!c.included) {
+              incl[s].encode(bw, bx, by, l + 1);
+              if (add <= 0) continue;
+              zbpt[s].encode(bw, bx, by, 0x7FFFFFF);
+              c.included = true;
+            } else {
+              bw.bit(add > 0);
+              if (add <= 0) continue;
+            }
+            put_npasses(bw, add);
+            int len = pl[now - 1] - (prev ? pl[prev - 1] : 0);
+            int need = 1; while ((len >> need) && need < 32) need++;
+            int have = c.lblock + ilog2i(add);
+            int inc = need > have ? need - have : 0;
+            for (int q = 0; q < inc; q++) bw.bit(1);
+            bw.bit(0);
+            c.lblock += inc;
+            bw.bits((unsigned)len, c.lblock + ilog2i(add));
+          }
+      bw.flush();
+      if (any)
+        for (int s = s0; s < s1; s++)
+          for (int i = 0; i < pp.sb[s].gx * pp.sb[s].gy; i++) {
+            int ci = pp.sb[s].first_cb + i;
+            HostCb& c = cb[ci];
+            const int* pl = plen_all + (size_t)ci * T1_MAXPASS;
+            int prev = l ? c.layer_passes[l - 1] : 0, now = c.layer_passes[l];
+            if (now <= prev) continue;
+            int a = prev ? pl[prev - 1] : 0, e = pl[now - 1];
+            o.bytes(data + c.data_off + a, (size_t)(e - a));
+          }
+    }
+  size_t psot = o.n - sot;
+  if (sot + 10 <= cap) { out[sot + 6] = (uint8_t)(psot >> 24); out[sot + 7] = (uint8_t)(psot >> 16); out[sot + 8] = (uint8_t)(psot >> 8); out[sot + 9] = (uint8_t)psot; }
+  o.u16(0xFFD9);                                      // EOC
+  return o.ovf ? -1 : (long)o.n;
+}
+
+struct PlaneSrc { size_t u8off; int stride, W, H; };
+
+// Encode a batch of planes whose samples live in the device buffer `u8base`.
+static int j2k_encode_planes(qsvc_ctx* c, const uint8_t* u8base, const std::vector<PlaneSrc>& src, const qsvc_j2k_params* prm,
+                             uint8_t* out, size_t cap, size_t* offs) {
+  if (!c->j2k) c->j2k = new J2kState();
+  J2kState& S = *c->j2k;
+  const bool rev = prm->reversible != 0;
+  int layers = prm->layers < 1 ? 1 : prm->layers;
+  int cbw = prm->cblk_w ? prm->cblk_w : 64, cbh = prm->cblk_h ? prm->cblk_h : 64;
+  if (layers > 16) return c->fail(QSVC_ERR_INVALID, "at most 16 quality layers");
+  if (prm->levels < 0 || prm->levels > J2K_MAXLEV) return c->fail(QSVC_ERR_INVALID, "Clevels %d", prm->levels);
+  if (cbw > 64 || cbh > 64 || cbw < 4 || cbh < 4 || (cbw & (cbw - 1)) || (cbh & (cbh - 1)))
+    return c->fail(QSVC_ERR_UNSUPPORTED, "code-block %dx%d (powers of two in 4..64)", cbw, cbh);
+  float base_step = prm->base_step > 0 ? prm->base_step : 1.0f / 256;
+  const int np = (int)src.size();
+  // distinct plane geometries of the batch
+  std::vector<PlanePlan> plans;
+  std::vector<int> plan_of(np);
+  for (int p = 0; p < np; p++) {
+    int k = -1;
+    for (size_t q = 0; q < plans.size(); q++) if (plans[q].W == src[p].W && plans[q].H == src[p].H) { k = (int)q; break; }
+    if (k < 0) { plans.emplace_back(); build_plan(plans.back(), src[p].W, src[p].H, prm->levels, rev, base_step, cbw, cbh); k = (int)plans.size() - 1; }
+    plan_of[p] = k;
+  }
+  for (auto& pl : plans)
+    for (auto& s : pl.sb) if (s.Mb > 15) return c->fail(QSVC_ERR_UNSUPPORTED, "subband needs %d magnitude bit-planes (> 15): raise base_step", s.Mb);
+  int maxL = 0, maxW = 0, maxH = 0;
+  S.planes.resize(np);
+  size_t total = 0;
+  std::vector<int> first_cb(np + 1);
+  int ncb = 0;
+  for (int p = 0; p < np; p++) {
+    S.planes[p].off = total; S.planes[p].u8off = src[p].u8off; S.planes[p].u8stride = src[p].stride; S.planes[p].W = src[p].W; S.planes[p].H = src[p].H;
+    total += (size_t)src[p].W * src[p].H;
+    maxW = std::max(maxW, src[p].W); maxH = std::max(maxH, src[p].H); maxL = std::max(maxL, plans[plan_of[p]].L);
+    first_cb[p] = ncb; ncb += plans[plan_of[p]].ncb;
+  }
+  first_cb[np] = ncb;
+  // all planes must share L for the batched DWT launches (same Clevels, sizes large enough)
+  for (int p = 0; p < np; p++)
+    if (plans[plan_of[p]].L != maxL) return c->fail(QSVC_ERR_UNSUPPORTED, "planes of one batch must allow the same number of DWT levels");
+  S.cbs.resize(ncb);
+  for (int p = 0; p < np; p++) {
+    const PlanePlan& pl = plans[plan_of[p]];
+    int k = first_cb[p];
+    for (auto& s : pl.sb)
+      for (int by = 0; by < s.gy; by++)
+        for (int bx = 0; bx < s.gx; bx++, k++) {
+          CbDesc& d = S.cbs[k];
+          d.plane = p; d.x0 = s.x0 + bx * cbw; d.y0 = s.y0 + by * cbh;
+          d.w = (short)((bx + 1) * cbw <= s.w ? cbw : s.w - bx * cbw);
+          d.h = (short)((by + 1) * cbh <= s.h ? cbh : s.h - by * cbh);
+          d.orient = (short)s.orient; d.Mb = (short)s.Mb; d.delta = s.delta;
+        }
+  }
+  const int ngroups = (ncb + 63) / 64;
+  const bool want_dist = layers > 1 || prm->slopes[0] > 0;
+  int r;
+  if ((r = S.coefA.ensure(c, total * 4))) return r;
+  if ((r = S.coefB.ensure(c, total * 4))) return r;
+  if ((r = S.planes_d.ensure(c, np * sizeof(PlaneDesc)))) return r;
+  if ((r = S.cbs_d.ensure(c, (size_t)ncb * sizeof(CbDesc)))) return r;
+  if ((r = S.nbps_d.ensure(c, (size_t)ncb * 4))) return r;
+  if ((r = S.mags.ensure(c, (size_t)ngroups * T1_MAGS_PER_GROUP * 8))) return r;
+  if ((r = S.flags.ensure(c, (size_t)ngroups * T1_FLAGS_PER_GROUP * 4))) return r;
+  if ((r = S.outbuf.ensure(c, (size_t)ncb * J2K_OUTCAP))) return r;
+  if ((r = S.res_d.ensure(c, (size_t)ncb * sizeof(CbOut)))) return r;
+  if ((r = S.plen_d.ensure(c, (size_t)ncb * T1_MAXPASS * 4))) return r;
+  if (want_dist) if ((r = S.pdist_d.ensure(c, (size_t)ncb * T1_MAXPASS * 8))) return r;
+  if ((r = S.offs_d.ensure(c, (size_t)ncb * 8))) return r;
+  if ((r = S.lens_d.ensure(c, (size_t)ncb * 4))) return r;
+  if ((r = S.err_d.ensure(c, 16))) return r;
+  HIPCHK(c, hipMemcpyAsync(S.planes_d.p, S.planes.data(), np * sizeof(PlaneDesc), hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipMemcpyAsync(S.cbs_d.p, S.cbs.data(), (size_t)ncb * sizeof(CbDesc), hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
+  Prof pf;
+  pf.begin(c, rev ? "j2k_dwt53" : "j2k_dwt97");
+  launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, u8base, S.coefA.p, S.coefB.p, maxL, rev);
+  pf.end(c);
+  pf.begin(c, "j2k_t1_pack");
+  HIPCHK(c, hipMemsetAsync(S.flags.p, 0, (size_t)ngroups * T1_FLAGS_PER_GROUP * 4, c->st));
+  launch_t1_pack(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (uint64_t*)S.mags.p, (int*)S.nbps_d.p,
+                 (int*)S.err_d.p, rev);
+  pf.end(c);
+  pf.begin(c, "j2k_t1_encode");
+  launch_t1_encode(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const uint64_t*)S.mags.p, (uint32_t*)S.flags.p,
+                   (uint8_t*)S.outbuf.p, J2K_OUTCAP, (CbOut*)S.res_d.p, (int*)S.plen_d.p, want_dist ? (long long*)S.pdist_d.p : nullptr,
+                   want_dist ? 1 : 0);
+  pf.end(c);
+  S.res.resize(ncb);
+  int err = 0;
+  HIPCHK(c, hipMemcpyAsync(S.res.data(), S.res_d.p, (size_t)ncb * sizeof(CbOut), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipMemcpyAsync(&err, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
+  S.plen.resize((size_t)ncb * T1_MAXPASS);
+  HIPCHK(c, hipMemcpyAsync(S.plen.data(), S.plen_d.p, (size_t)ncb * T1_MAXPASS * 4, hipMemcpyDeviceToHost, c->st));
+  if (want_dist) {
+    S.pdist.resize((size_t)ncb * T1_MAXPASS);
+    HIPCHK(c, hipMemcpyAsync(S.pdist.data(), S.pdist_d.p, (size_t)ncb * T1_MAXPASS * 8, hipMemcpyDeviceToHost, c->st));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, hipGetLastError());
+  if (err) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
+  // host: rate allocation, gather offsets
+  S.hcb.assign(ncb, HostCb());
+  std::vector<unsigned long long> goffs(ncb);
+  std::vector<int> glens(ncb);
+  size_t gtotal = 0;
+  S.st_cb = ncb; S.st_pass = 0; S.st_sym = 0;
+  for (int p = 0; p < np; p++) {
+    const PlanePlan& pl = plans[plan_of[p]];
+    for (auto& s : pl.sb) {
+      double wgt = (double)s.delta * norm_of(rev, s.orient, s.dlev);
+      wgt *= wgt;
+      for (int i = 0; i < s.gx * s.gy; i++) {
+        int k = first_cb[p] + s.first_cb + i;
+        const CbOut& ro = S.res[k];
+        if (ro.overflow) return c->fail(QSVC_ERR_NOMEM, "code-block segment exceeds %d bytes", J2K_OUTCAP);
+        HostCb& h = S.hcb[k];
+        h.len = ro.len; h.npasses = ro.npasses; h.nbps = ro.nbps; h.zbp = s.Mb - ro.nbps; h.lblock = 3; h.included = false;
+        S.st_pass += ro.npasses; S.st_sym += ro.nsym;
+        const int* plen = S.plen.data() + (size_t)k * T1_MAXPASS;
+        for (int l = 0; l < layers; l++) {
+          int n;
+          if (l == layers - 1 && prm->slopes[l] <= 0) n = ro.npasses;
+          else if (prm->slopes[l] <= 0) n = 0;
+          else n = passes_for_lambda(ro.npasses, plen, S.pdist.data() + (size_t)k * T1_MAXPASS, wgt, slope_to_lambda(prm->slopes[l]));
+          if (l > 0 && n < h.layer_passes[l - 1]) n = h.layer_passes[l - 1];
+          h.layer_passes[l] = n;
+        }
+        h.first_layer = layers;
+        for (int l = layers - 1; l >= 0; l--) if (h.layer_passes[l] > 0) h.first_layer = l;
+        int used = h.layer_passes[layers - 1] ? plen[h.layer_passes[layers - 1] - 1] : 0;
+        h.data_off = gtotal; goffs[k] = gtotal; glens[k] = used; gtotal += used;
+      }
+    }
+  }
+  if ((r = S.gath_d.ensure(c, gtotal ? gtotal : 16))) return r;
+  if (S.gath_h_cap < gtotal) {
+    if (S.gath_h) (void)hipHostFree(S.gath_h);
+    S.gath_h = nullptr; S.gath_h_cap = 0;
+    size_t want = gtotal + gtotal / 4 + (1 << 20);
+    if (hipHostMalloc((void**)&S.gath_h, want, hipHostMallocDefault) != hipSuccess) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%zu)", want);
+    S.gath_h_cap = want;
+  }
+  pf.begin(c, "j2k_gather");
+  HIPCHK(c, hipMemcpyAsync(S.offs_d.p, goffs.data(), (size_t)ncb * 8, hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipMemcpyAsync(S.lens_d.p, glens.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
+  launch_gather(c->st, (const uint8_t*)S.outbuf.p, J2K_OUTCAP, (const unsigned long long*)S.offs_d.p, (const int*)S.lens_d.p, ncb,
+                (uint8_t*)S.gath_d.p);
+  pf.end(c);
+  if (gtotal) HIPCHK(c, hipMemcpyAsync(S.gath_h, S.gath_d.p, gtotal, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, hipGetLastError());
+  // host: Tier-2, one code-stream per plane
+  size_t pos = 0;
+  for (int p = 0; p < np; p++) {
+    offs[p] = pos;
+    long n = write_codestream(plans[plan_of[p]], *prm, layers, cbw, cbh, S.hcb.data() + first_cb[p],
+                              S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS, S.gath_h, out + pos, cap - pos);
+    if (n < 0) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes)", cap);
+    pos += (size_t)n;
+  }
+  offs[np] = pos;
+  return QSVC_OK;
+}
+
+extern "C" {
+
+int qsvc_j2k_encode_frames(qsvc_ctx* c, int kind, int t, int first, int count, const qsvc_j2k_params* prm, uint8_t* out,
+                           size_t cap, size_t* offs) {
+  if (!c || !prm || !out || !offs) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+  if (t < 0 || t > QSVC_MAX_T) return c->fail(QSVC_ERR_INVALID, "temporal subband %d out of range", t);
+  Level& lv = c->lv[t];
+  DevBuf* b; int n;
+  switch (kind) {
+    case QSVC_LOW: b = &lv.low; n = lv.low_n; break;
+    case QSVC_HIGH: b = &lv.high; n = lv.high_n; break;
+    case QSVC_PRED: b = &lv.pred; n = lv.pred_n; break;
+    default: return c->fail(QSVC_ERR_INVALID, "unknown sequence kind %d", kind);
+  }
+  if (first < 0 || count < 0 || first + count > n) return c->fail(QSVC_ERR_STATE, "sequence kind %d t=%d holds %d pictures", kind, t, n);
+  if (count == 0) { offs[0] = 0; return QSVC_OK; }
+  std::vector<PlaneSrc> src;
+  int cw = c->W / 2, ch = c->H / 2;
+  for (int i = 0; i < count; i++) {  // order (picture, component), texture_compress_fb_j2k.py:255-257
+    size_t f = (size_t)(first + i) * c->F;
+    src.push_back({f, c->W, c->W, c->H});
+    src.push_back({f + (size_t)c->W * c->H, cw, cw, ch});
+    src.push_back({f + (size_t)c->W * c->H + (size_t)cw * ch, cw, cw, ch});
+  }
+  // the batched DWT needs one level count: luma and chroma planes go in separate batches if they differ
+  return j2k_encode_planes(c, (const uint8_t*)b->p, src, prm, out, cap, offs);
+}
+
+int qsvc_j2k_encode_plane(qsvc_ctx* c, const uint8_t* plane, int H, int W, const qsvc_j2k_params* prm, uint8_t* out, size_t cap,
+                          size_t* len) {
+  if (!c || !plane || !prm || !out || !len || W < 1 || H < 1 || W > 16384 || H > 16384) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  if (!c->j2k) c->j2k = new J2kState();
+  int r = c->j2k->up_d.ensure(c, (size_t)W * H);
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(c->j2k->up_d.p, plane, (size_t)W * H, hipMemcpyHostToDevice, c->st));
+  std::vector<PlaneSrc> src{{0, W, W, H}};
+  size_t offs[2];
+  r = j2k_encode_planes(c, (const uint8_t*)c->j2k->up_d.p, src, prm, out, cap, offs);
+  if (r) return r;
+  *len = offs[1];
+  return QSVC_OK;
+}
+
+int qsvc_j2k_dwt(qsvc_ctx* c, const uint8_t* plane, int H, int W, int reversible, int levels, void* out) {
+  if (!c || !plane || !out || W < 1 || H < 1 || W > 16384 || H > 16384 || levels < 0 || levels > J2K_MAXLEV) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  if (!c->j2k) c->j2k = new J2kState();
+  J2kState& S = *c->j2k;
+  size_t N = (size_t)W * H;
+  int r;
+  if ((r = S.up_d.ensure(c, N))) return r;
+  if ((r = S.coefA.ensure(c, N * 4))) return r;
+  if ((r = S.coefB.ensure(c, N * 4))) return r;
+  if ((r = S.planes_d.ensure(c, sizeof(PlaneDesc)))) return r;
+  int L = levels;
+  while (L > 0 && ((W >> (L - 1)) < 1 || (H >> (L - 1)) < 1)) L--;
+  PlaneDesc pd{0, 0, W, W, H};
+  HIPCHK(c, hipMemcpyAsync(S.up_d.p, plane, N, hipMemcpyHostToDevice, c->st));
+  HIPCHK(c, hipMemcpyAsync(S.planes_d.p, &pd, sizeof pd, hipMemcpyHostToDevice, c->st));
+  launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, (const uint8_t*)S.up_d.p, S.coefA.p, S.coefB.p, L, reversible != 0);
+  HIPCHK(c, hipMemcpyAsync(out, S.coefA.p, N * 4, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, hipGetLastError());
+  return QSVC_OK;
+}
+
+int qsvc_j2k_stats(qsvc_ctx* c, uint64_t* codeblocks, uint64_t* passes, uint64_t* symbols) {
+  if (!c) return QSVC_ERR_INVALID;
+  if (!c->j2k) return c->fail(QSVC_ERR_STATE, "no JPEG 2000 call yet");
+  if (codeblocks) *codeblocks = c->j2k->st_cb;
+  if (passes) *passes = c->j2k->st_pass;
+  if (symbols) *symbols = c->j2k->st_sym;
+  return QSVC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// qsvc_amd/csrc/j2k_kernels.h -- device-side structures and launch wrappers of j2k_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "t1_core.h"
+
+namespace qsvc {
+
+struct PlaneDesc {   // one image component plane of the batch
+  size_t off;        // element offset of the plane in the coefficient buffers (stride = W)
+  size_t u8off;      // byte offset of the source samples in the u8 frame store
+  int u8stride;      // source row stride in bytes
+  int W, H;
+};
+struct CbDesc {      // one code-block
+  int plane;
+  int x0, y0;        // position in the plane's Mallat layout
+  short w, h;
+  short orient;      // 0 LL, 1 HL, 2 LH, 3 HH
+  short Mb;          // magnitude bit-planes of its subband
+  float delta;       // quantiser step (irreversible path)
+};
+struct CbOut {
+  int len, npasses, nbps, overflow;
+  unsigned long long nsym;
+};
+
+// Tier-1 working set per group of 64 code-blocks (lane-interleaved)
+#define T1_MAGS_PER_GROUP (16 * 64 * 64)          // u64 words
+#define T1_FLAGS_PER_GROUP (18 * T1_FW * 64)      // u32 words
+
+void launch_dwt(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, const uint8_t* u8base, void* A,
+                void* B, int levels, bool reversible);
+void launch_t1_pack(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef, uint64_t* mags,
+                    int* nbps, int* err, bool reversible);
+void launch_t1_encode(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint64_t* mags, uint32_t* flags,
+                      uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist);
+void launch_gather(hipStream_t st, const uint8_t* outbuf, int outcap, const unsigned long long* offs, const int* lens, int ncb,
+                   uint8_t* dst);
+}  // namespace qsvc

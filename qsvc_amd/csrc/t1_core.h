@@ -1,0 +1,319 @@
+// qsvc_amd/csrc/t1_core.h -- EBCOT Tier-1 (ITU-T T.800 Annex C + D) for one code-block per LANE.
+//
+// Mapping: 64 code-blocks are coded by the 64 lanes of one wavefront in lock-step over the common
+// scan (bit-plane -> pass -> stripe -> column); each lane carries its own MQ coder and block state.
+// Block state lives in HBM in a lane-interleaved layout so that the wave's accesses coalesce:
+//   mags : [stripe-column][lane] u64 = 4 x (sign<<15 | 15-bit magnitude), rows 4s..4s+3 of column x
+//   flags: [(stripe+1)*66 + (x+1)][lane] u32, one word per stripe-column with a one-cell apron:
+//            bits 0-17  significance of the 6x3 neighbourhood (rows 4s-1..4s+4, cols x-1..x+1), bit 3r+c
+//            bits 18-23 sign of the centre column's rows 4s-1..4s+4 (set when they become significant)
+//            bits 24-27 "visited in this bit-plane's significance pass" for rows 4s..4s+3
+//            bits 28-31 "refined before" for rows 4s..4s+3
+//   (the reference has no source for this stage -- it calls Kakadu, texture_compress_fb_j2k.py:183-195;
+//    the algorithm is the published one, restated independently in oracle/j2k_oracle.c)
+// The same functions compile for the host (tests/emul) with lane stride 1.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define T1HD __host__ __device__ __forceinline__
+#else
+#define T1HD static inline
+#endif
+
+namespace qsvc {
+
+#define T1_FW 66            // flag words per stripe row (64 + apron)
+#define T1_MAXPASS 48       // 3*16-2 coding passes at most
+#define T1_SIG_ALL 0x3FFFFu
+#define T1_CHI_SHIFT 18
+#define T1_PI_SHIFT 24
+#define T1_MU_SHIFT 28
+#define T1_CTX_RUN 17
+#define T1_CTX_UNI 18
+
+// MQ probability state table (T.800 Table C.2), packed: qe | nmps<<16 | nlps<<22 | switch<<28
+#define T1_MQ_TABLE_INIT                                                                                                  \
+  {0x5601 | 1 << 16 | 1 << 22 | 1 << 28,   0x3401 | 2 << 16 | 6 << 22,    0x1801 | 3 << 16 | 9 << 22,    0x0AC1 | 4 << 16 | 12 << 22,  \
+   0x0521 | 5 << 16 | 29 << 22,            0x0221 | 38 << 16 | 33 << 22,  0x5601 | 7 << 16 | 6 << 22 | 1 << 28, 0x5401 | 8 << 16 | 14 << 22, \
+   0x4801 | 9 << 16 | 14 << 22,            0x3801 | 10 << 16 | 14 << 22,  0x3001 | 11 << 16 | 17 << 22,  0x2401 | 12 << 16 | 18 << 22, \
+   0x1C01 | 13 << 16 | 20 << 22,           0x1601 | 29 << 16 | 21 << 22,  0x5601 | 15 << 16 | 14 << 22 | 1 << 28, 0x5401 | 16 << 16 | 14 << 22, \
+   0x5101 | 17 << 16 | 15 << 22,           0x4801 | 18 << 16 | 16 << 22,  0x3801 | 19 << 16 | 17 << 22,  0x3401 | 20 << 16 | 18 << 22, \
+   0x3001 | 21 << 16 | 19 << 22,           0x2801 | 22 << 16 | 19 << 22,  0x2401 | 23 << 16 | 20 << 22,  0x2201 | 24 << 16 | 21 << 22, \
+   0x1C01 | 25 << 16 | 22 << 22,           0x1801 | 26 << 16 | 23 << 22,  0x1601 | 27 << 16 | 24 << 22,  0x1401 | 28 << 16 | 25 << 22, \
+   0x1201 | 29 << 16 | 26 << 22,           0x1101 | 30 << 16 | 27 << 22,  0x0AC1 | 31 << 16 | 28 << 22,  0x09C1 | 32 << 16 | 29 << 22, \
+   0x08A1 | 33 << 16 | 30 << 22,           0x0521 | 34 << 16 | 31 << 22,  0x0441 | 35 << 16 | 32 << 22,  0x02A1 | 36 << 16 | 33 << 22, \
+   0x0221 | 37 << 16 | 34 << 22,           0x0141 | 38 << 16 | 35 << 22,  0x0111 | 39 << 16 | 36 << 22,  0x0085 | 40 << 16 | 37 << 22, \
+   0x0049 | 41 << 16 | 38 << 22,           0x0025 | 42 << 16 | 39 << 22,  0x0015 | 43 << 16 | 40 << 22,  0x0009 | 44 << 16 | 41 << 22, \
+   0x0005 | 45 << 16 | 42 << 22,           0x0001 | 45 << 16 | 43 << 22,  0x5601 | 46 << 16 | 46 << 22}
+
+// zero-coding context (T.800 Table D.1) from the 9-bit neighbourhood (bit 3*dr+dc, centre = bit 4)
+T1HD int t1_zc_from_nb(int nb, int orient) {
+  int h = ((nb >> 3) & 1) + ((nb >> 5) & 1);
+  int v = ((nb >> 1) & 1) + ((nb >> 7) & 1);
+  int d = (nb & 1) + ((nb >> 2) & 1) + ((nb >> 6) & 1) + ((nb >> 8) & 1);
+  if (orient == 1) { int t = h; h = v; v = t; }
+  if (orient == 3) {
+    int hv = h + v;
+    if (d >= 3) return 8;
+    if (d == 2) return hv >= 1 ? 7 : 6;
+    if (d == 1) return hv >= 2 ? 5 : (hv == 1 ? 4 : 3);
+    return hv >= 2 ? 2 : (hv == 1 ? 1 : 0);
+  }
+  if (h == 2) return 8;
+  if (h == 1) return v >= 1 ? 7 : (d >= 1 ? 6 : 5);
+  if (v == 2) return 4;
+  if (v == 1) return 3;
+  return d >= 2 ? 2 : (d == 1 ? 1 : 0);
+}
+
+struct T1Result {  // per code-block outputs besides the bytes
+  int len;
+  int npasses;
+  int nbps;
+  int overflow;         // the segment did not fit the lane's output capacity
+  int* pass_len;        // [T1_MAXPASS] cumulative truncation length after each pass
+  long long* pass_dist; // [T1_MAXPASS] integer distortion decrease per pass, quantiser-step^2 units (or nullptr)
+  unsigned long long nsym;
+};
+
+// One lane's view of its block.  `ls` = lane stride (64 on the GPU, 1 on the host harness).
+struct T1Lane {
+  uint32_t* flags;        // this lane's first flag word; word i at flags[i*ls]
+  const uint64_t* mags;   // this lane's first mags word; word i at mags[i*ls]
+  uint8_t* cx;            // this lane's context-state bytes (index<<1 | mps); context c at cx[c*cs]
+  const uint32_t* mqtab;  // [47]
+  const uint8_t* zclut;   // [3][512] zero-coding LUT (class 0: LL/LH, 1: HL, 2: HH)
+  uint8_t* out;           // out[0] is a scratch byte; the segment is out[1..]
+  int ls, cs;
+  int cap;                // bytes available at out (incl. the scratch byte)
+  int w, h, orient, nbps;
+  // MQ registers
+  uint32_t A, C;
+  int CT, B, n;           // B: byte register (not yet in memory), n: bytes emitted incl. the scratch byte
+  unsigned long long nsym;
+};
+
+T1HD void mq_emit(T1Lane& t) {
+  if (t.n < t.cap) t.out[t.n] = (uint8_t)t.B;
+  t.n++;
+}
+T1HD void mq_byteout(T1Lane& t) {  // BYTEOUT, T.800 C.2.7, with the byte register held in t.B
+  if (t.B == 0xFF) {
+    mq_emit(t); t.B = t.C >> 20; t.C &= 0xFFFFF; t.CT = 7;
+  } else if (t.C < 0x8000000u) {
+    mq_emit(t); t.B = t.C >> 19; t.C &= 0x7FFFF; t.CT = 8;
+  } else {
+    t.B++;
+    if (t.B == 0xFF) {
+      t.C &= 0x7FFFFFF;
+      mq_emit(t); t.B = t.C >> 20; t.C &= 0xFFFFF; t.CT = 7;
+    } else {
+      mq_emit(t); t.B = t.C >> 19; t.C &= 0x7FFFF; t.CT = 8;
+    }
+  }
+}
+T1HD void mq_encode(T1Lane& t, int cx, int d) {  // ENCODE/CODEMPS/CODELPS/RENORME, T.800 C.2.2-C.2.6
+  uint8_t st = t.cx[cx * t.cs];
+  uint32_t e = t.mqtab[st >> 1];
+  uint32_t qe = e & 0xFFFF;
+  int mps = st & 1;
+  t.nsym++;
+  t.A -= qe;
+  if (d == mps) {
+    if (t.A & 0x8000) { t.C += qe; return; }
+    if (t.A < qe) t.A = qe; else t.C += qe;
+    t.cx[cx * t.cs] = (uint8_t)((((e >> 16) & 63) << 1) | mps);
+  } else {
+    if (t.A < qe) t.C += qe; else t.A = qe;
+    if ((e >> 28) & 1) mps ^= 1;
+    t.cx[cx * t.cs] = (uint8_t)((((e >> 22) & 63) << 1) | mps);
+  }
+  do {
+    t.A <<= 1; t.C <<= 1; t.CT--;
+    if (t.CT == 0) mq_byteout(t);
+  } while ((t.A & 0x8000) == 0);
+}
+T1HD int mq_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment length
+  uint32_t tempc = t.C + t.A;
+  t.C |= 0xFFFF;
+  if (t.C >= tempc) t.C -= 0x8000;
+  t.C <<= t.CT; mq_byteout(t);
+  t.C <<= t.CT; mq_byteout(t);
+  if (t.B != 0xFF) mq_emit(t);
+  return t.n - 1;
+}
+
+T1HD int t1_mag(uint64_t m, int k) { return (int)((m >> (16 * k)) & 0x7FFF); }
+T1HD int t1_neg(uint64_t m, int k) { return (int)((m >> (16 * k + 15)) & 1); }
+
+// sample (stripe s, column x, row-in-stripe k) has just become significant with sign `neg`:
+// publish it to every flag word whose neighbourhood contains it.  fw = index of word (s, x).
+T1HD void t1_set_sig(T1Lane& t, int fw, uint32_t& own, int k, int neg) {
+  int ls = t.ls;
+  own |= (1u << (3 * (k + 1) + 1)) | ((uint32_t)neg << (T1_CHI_SHIFT + k + 1));
+  t.flags[(fw - 1) * ls] |= 1u << (3 * (k + 1) + 2);
+  t.flags[(fw + 1) * ls] |= 1u << (3 * (k + 1) + 0);
+  if (k == 0) {  // also row 4 (r = 5) of the stripe above
+    t.flags[(fw - T1_FW) * ls] |= (1u << 16) | ((uint32_t)neg << (T1_CHI_SHIFT + 5));
+    t.flags[(fw - T1_FW - 1) * ls] |= 1u << 17;
+    t.flags[(fw - T1_FW + 1) * ls] |= 1u << 15;
+  } else if (k == 3) {  // also row -1 (r = 0) of the stripe below
+    t.flags[(fw + T1_FW) * ls] |= (1u << 1) | ((uint32_t)neg << (T1_CHI_SHIFT + 0));
+    t.flags[(fw + T1_FW - 1) * ls] |= 1u << 2;
+    t.flags[(fw + T1_FW + 1) * ls] |= 1u << 0;
+  }
+}
+// sign coding (T.800 D.3.2, Tables D.2/D.3)
+T1HD void t1_code_sign(T1Lane& t, int fw, uint32_t own, int k, int neg) {
+  uint32_t l = t.flags[(fw - 1) * t.ls], r = t.flags[(fw + 1) * t.ls];
+  int nb = (own >> (3 * k)) & 0x1FF;
+  int hc = 0, vc = 0;
+  if (nb & (1 << 3)) hc += ((l >> (T1_CHI_SHIFT + k + 1)) & 1) ? -1 : 1;
+  if (nb & (1 << 5)) hc += ((r >> (T1_CHI_SHIFT + k + 1)) & 1) ? -1 : 1;
+  if (nb & (1 << 1)) vc += ((own >> (T1_CHI_SHIFT + k)) & 1) ? -1 : 1;
+  if (nb & (1 << 7)) vc += ((own >> (T1_CHI_SHIFT + k + 2)) & 1) ? -1 : 1;
+  hc = hc > 1 ? 1 : (hc < -1 ? -1 : hc);
+  vc = vc > 1 ? 1 : (vc < -1 ? -1 : vc);
+  int xr = hc < 0 || (hc == 0 && vc < 0);
+  if (xr) { hc = -hc; vc = -vc; }  // after the flip: hc in {0,1}; hc == 0 -> vc in {0,1}
+  int cx = hc == 1 ? 12 + vc : (vc == 1 ? 10 : 9);
+  mq_encode(t, cx, neg ^ xr);
+}
+T1HD long long t1_dist_sig(int m, int p) {  // distortion decrease, midpoint reconstruction
+  long long r = (long long)((m >> p) << p) + (p ? (1 << (p - 1)) : 0);
+  return r * (2LL * m - r);
+}
+T1HD long long t1_dist_ref(int m, int p) {
+  long long r0 = (long long)((m >> (p + 1)) << (p + 1)) + (1 << p);
+  long long r1 = (long long)((m >> p) << p) + (p ? (1 << (p - 1)) : 0);
+  long long d0 = m - r0, d1 = m - r1;
+  return d0 * d0 - d1 * d1;
+}
+
+// The whole block.  `top` = highest bit-plane index any lane of the wave codes (uniform loop bound);
+// wmax/hmax = uniform scan bounds (max over the wave).  A lane with nbps == 0 emits nothing.
+T1HD void t1_encode_lane(T1Lane& t, int top, int wmax, int hmax, bool want_dist, T1Result& res) {
+  const int ls = t.ls;
+  const uint8_t* zc = t.zclut + 512 * (t.orient == 1 ? 1 : (t.orient == 3 ? 2 : 0));
+  for (int c = 0; c < 19; c++) t.cx[c * t.cs] = 0;
+  t.cx[0 * t.cs] = 4 << 1; t.cx[T1_CTX_RUN * t.cs] = 3 << 1; t.cx[T1_CTX_UNI * t.cs] = 46 << 1;
+  t.A = 0x8000; t.C = 0; t.CT = 12; t.B = 0; t.n = 0; t.nsym = 0;
+  int np = 0;
+  const int nstripes = (hmax + 3) >> 2;
+  for (int p = top; p >= 0; p--) {
+    const bool active = p < t.nbps;
+    const bool first = p == t.nbps - 1;
+    // ---- significance propagation pass (D.3.1) ----
+    if (active && !first) {
+      long long dist = 0;
+      for (int s = 0; s < nstripes; s++)
+        for (int x = 0; x < wmax; x++) {
+          if (x >= t.w || 4 * s >= t.h) continue;
+          int fw = (s + 1) * T1_FW + x + 1;
+          uint32_t f = t.flags[fw * ls];
+          if ((f & T1_SIG_ALL) == 0) continue;
+          uint64_t m = t.mags[(s * 64 + x) * ls];
+          uint32_t f0 = f;
+          for (int k = 0; k < 4 && 4 * s + k < t.h; k++) {
+            int nb = (f >> (3 * k)) & 0x1FF;
+            if ((nb & 0x10) || (nb & 0x1EF) == 0) continue;
+            int mag = t1_mag(m, k), bit = (mag >> p) & 1;
+            mq_encode(t, zc[nb & 0x1EF], bit);
+            if (bit) {
+              int neg = t1_neg(m, k);
+              t1_code_sign(t, fw, f, k, neg);
+              t1_set_sig(t, fw, f, k, neg);
+              if (want_dist) dist += t1_dist_sig(mag, p);
+            }
+            f |= 1u << (T1_PI_SHIFT + k);
+          }
+          if (f != f0) t.flags[fw * ls] = f;
+        }
+      res.pass_len[np] = t.n + 4; if (res.pass_dist) res.pass_dist[np] = dist; np++;
+    }
+    // ---- magnitude refinement pass (D.3.3) ----
+    if (active && !first) {
+      long long dist = 0;
+      for (int s = 0; s < nstripes; s++)
+        for (int x = 0; x < wmax; x++) {
+          if (x >= t.w || 4 * s >= t.h) continue;
+          int fw = (s + 1) * T1_FW + x + 1;
+          uint32_t f = t.flags[fw * ls];
+          uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);  // sigma of rows 0..3
+          uint32_t todo = own & ~(f >> T1_PI_SHIFT) & 0xF;
+          if (!todo) continue;
+          uint64_t m = t.mags[(s * 64 + x) * ls];
+          uint32_t f0 = f;
+          for (int k = 0; k < 4; k++) {
+            if (!((todo >> k) & 1)) continue;
+            int nb = (f >> (3 * k)) & 0x1FF;
+            int cx = ((f >> (T1_MU_SHIFT + k)) & 1) ? 16 : ((nb & 0x1EF) ? 15 : 14);
+            int mag = t1_mag(m, k);
+            mq_encode(t, cx, (mag >> p) & 1);
+            f |= 1u << (T1_MU_SHIFT + k);
+            if (want_dist) dist += t1_dist_ref(mag, p);
+          }
+          if (f != f0) t.flags[fw * ls] = f;
+        }
+      res.pass_len[np] = t.n + 4; if (res.pass_dist) res.pass_dist[np] = dist; np++;
+    }
+    // ---- clean-up pass (D.3.4) ----
+    if (active) {
+      long long dist = 0;
+      for (int s = 0; s < nstripes; s++)
+        for (int x = 0; x < wmax; x++) {
+          if (x >= t.w || 4 * s >= t.h) continue;
+          int fw = (s + 1) * T1_FW + x + 1;
+          uint32_t f = t.flags[fw * ls];
+          uint32_t f0 = f;
+          uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);
+          uint32_t done = (own | (f >> T1_PI_SHIFT)) & 0xF;
+          int rows = t.h - 4 * s; if (rows > 4) rows = 4;
+          if (done != 0xF || rows < 4) {
+            uint64_t m = t.mags[(s * 64 + x) * ls];
+            int k = 0;
+            if (rows == 4 && (f & (T1_SIG_ALL | (0xFu << T1_PI_SHIFT))) == 0) {  // run-length mode
+              int b0 = (t1_mag(m, 0) >> p) & 1, b1 = (t1_mag(m, 1) >> p) & 1, b2 = (t1_mag(m, 2) >> p) & 1, b3 = (t1_mag(m, 3) >> p) & 1;
+              if (!(b0 | b1 | b2 | b3)) { mq_encode(t, T1_CTX_RUN, 0); k = 4; }
+              else {
+                int fk = b0 ? 0 : (b1 ? 1 : (b2 ? 2 : 3));
+                mq_encode(t, T1_CTX_RUN, 1);
+                mq_encode(t, T1_CTX_UNI, fk >> 1);
+                mq_encode(t, T1_CTX_UNI, fk & 1);
+                int neg = t1_neg(m, fk);
+                t1_code_sign(t, fw, f, fk, neg);
+                t1_set_sig(t, fw, f, fk, neg);
+                if (want_dist) dist += t1_dist_sig(t1_mag(m, fk), p);
+                k = fk + 1;
+              }
+            }
+            for (; k < rows; k++) {
+              int nb = (f >> (3 * k)) & 0x1FF;
+              if ((nb & 0x10) || ((f >> (T1_PI_SHIFT + k)) & 1)) continue;
+              int mag = t1_mag(m, k), bit = (mag >> p) & 1;
+              mq_encode(t, zc[nb & 0x1EF], bit);
+              if (bit) {
+                int neg = t1_neg(m, k);
+                t1_code_sign(t, fw, f, k, neg);
+                t1_set_sig(t, fw, f, k, neg);
+                if (want_dist) dist += t1_dist_sig(mag, p);
+              }
+            }
+          }
+          f &= ~(0xFu << T1_PI_SHIFT);  // the "visited" marks last one bit-plane
+          if (f != f0) t.flags[fw * ls] = f;
+        }
+      res.pass_len[np] = t.n + 4; if (res.pass_dist) res.pass_dist[np] = dist; np++;
+    }
+  }
+  res.npasses = np;
+  res.nbps = t.nbps;
+  res.len = t.nbps ? mq_flush(t) : 0;
+  res.overflow = t.n > t.cap;
+  res.nsym = t.nsym;
+  for (int i = 0; i < np; i++) if (res.pass_len[i] > res.len) res.pass_len[i] = res.len;
+  if (np) res.pass_len[np - 1] = res.len;
+}
+
+}  // namespace qsvc

@@ -22,7 +22,7 @@ SYMBOLS = [
     "qsvc_get_frame_types", "qsvc_get_histograms", "qsvc_motion_estimate", "qsvc_decorrelate", "qsvc_update",
     "qsvc_analyze_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_dwt53_trunc",
-    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_plane", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_plane", "qsvc_j2k_dwt", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
 ]
 
 
@@ -76,6 +76,7 @@ def load_library() -> C.CDLL:
     L.qsvc_dwt53_trunc.argtypes = [vp, i16p, i, i, i, i, i]
     L.qsvc_j2k_encode_frames.argtypes = [vp, i, i, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_encode_plane.argtypes = [vp, u8p, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.qsvc_j2k_dwt.argtypes = [vp, u8p, i, i, i, i, vp]
     L.qsvc_j2k_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qsvc_set_profiling.argtypes = [vp, i]
     L.qsvc_get_timings.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), i]
@@ -230,6 +231,13 @@ class Engine:
         n = C.c_size_t()
         self._chk(self.L.qsvc_j2k_encode_plane(self.h, p.ctypes.data, H, W, C.byref(params), out.ctypes.data, cap, C.byref(n)))
         return out[:n.value].tobytes()
+
+    def j2k_dwt(self, plane: np.ndarray, reversible: bool, levels: int) -> np.ndarray:
+        p = np.ascontiguousarray(plane, dtype=np.uint8)
+        H, W = p.shape
+        out = np.empty((H, W), dtype=np.int32 if reversible else np.float32)
+        self._chk(self.L.qsvc_j2k_dwt(self.h, p.ctypes.data, H, W, int(reversible), levels, out.ctypes.data))
+        return out
 
     def j2k_stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -130,3 +130,45 @@ int emul_border_luma(const uint8_t* luma, int H, int W, int b, int16_t* out /*(H
   return 0;
 }
 }
+
+// ---- EBCOT Tier-1: one block through the lane code with lane stride 1 -------------------------
+#include "../../qsvc_amd/csrc/t1_core.h"
+extern "C" int emul_t1_block(const int32_t* vals, int w, int h, int orient, uint8_t* out, int* npasses, int* nbps,
+                             int* pass_len, long long* pass_dist) {
+  static const uint32_t mqtab[47] = T1_MQ_TABLE_INIT;
+  static uint8_t zclut[3 * 512];
+  static bool init = false;
+  if (!init) {
+    for (int c = 0; c < 3; c++)
+      for (int nb = 0; nb < 512; nb++) zclut[c * 512 + nb] = (uint8_t)t1_zc_from_nb(nb, c == 0 ? 0 : (c == 1 ? 1 : 3));
+    init = true;
+  }
+  std::vector<uint32_t> flags(18 * T1_FW, 0);
+  std::vector<uint64_t> mags(16 * 64, 0);
+  int maxm = 0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int v = vals[y * w + x];
+      int m = v < 0 ? -v : v;
+      if (m > 0x7FFF) return -1;
+      if (m > maxm) maxm = m;
+      uint64_t sm = (uint64_t)(m | (v < 0 ? 0x8000 : 0));
+      mags[(y >> 2) * 64 + x] |= sm << (16 * (y & 3));
+    }
+  int nb = 0;
+  while (maxm >> nb) nb++;
+  uint8_t cx[19];
+  std::vector<uint8_t> buf((size_t)w * h * 4 + 64);
+  T1Lane t;
+  t.flags = flags.data(); t.mags = mags.data(); t.cx = cx; t.mqtab = mqtab; t.zclut = zclut; t.out = buf.data();
+  t.ls = 1; t.cs = 1; t.cap = (int)buf.size(); t.w = w; t.h = h; t.orient = orient; t.nbps = nb;
+  T1Result r;
+  int pl[T1_MAXPASS]; long long pd[T1_MAXPASS];
+  r.pass_len = pl; r.pass_dist = pd;
+  t1_encode_lane(t, nb - 1, w, h, true, r);
+  if (r.overflow) return -2;
+  memcpy(out, buf.data() + 1, r.len);
+  *npasses = r.npasses; *nbps = r.nbps;
+  for (int i = 0; i < r.npasses; i++) { pass_len[i] = pl[i]; if (pass_dist) pass_dist[i] = pd[i]; }
+  return r.len;
+}

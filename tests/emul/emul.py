@@ -17,7 +17,7 @@ def lib():
     if _LIB is None:
         so = os.path.join(_HERE, "libqsvc_emul.so")
         srcs = [os.path.join(_HERE, "emul.cpp")] + [os.path.join(_HERE, "..", "..", "qsvc_amd", "csrc", f)
-                                                    for f in ("mctf_core.h", "mctf_threads.h")]
+                                                    for f in ("mctf_core.h", "mctf_threads.h", "t1_core.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so,
                                    os.path.join(_HERE, "emul.cpp")])
@@ -27,6 +27,7 @@ def lib():
         L.emul_predict.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p, _u8p, _u8p, _u32p]
         L.emul_update.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _i16p, C.c_char_p, C.c_float, C.c_int,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, _u8p]
+        L.emul_t1_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.emul_border_luma.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _i16p]
         _LIB = L
     return _LIB
@@ -66,3 +67,14 @@ def update(low, W, H, bs, high, mv, types, uf=0.25, halo_l=None, halo_r=None):
     r = lib().emul_update(low, low.shape[0], W, H, bs, np.ascontiguousarray(high), np.ascontiguousarray(mv), types, uf, reach,
                           hl.ctypes.data if hl is not None else None, tl, hr.ctypes.data if hr is not None else None, tr, out)
     return r, out
+
+
+def t1_block(vals, orient):
+    v = np.ascontiguousarray(vals, dtype=np.int32)
+    h, w = v.shape
+    out = np.empty(w * h * 4 + 64, dtype=np.uint8)
+    npasses, nbps = C.c_int(), C.c_int()
+    pl = np.zeros(64, dtype=np.int32)
+    pd = np.zeros(64, dtype=np.int64)
+    n = lib().emul_t1_block(v.ctypes.data, w, h, orient, out.ctypes.data, C.byref(npasses), C.byref(nbps), pl.ctypes.data, pd.ctypes.data)
+    return out[:max(n, 0)].tobytes(), npasses.value, nbps.value, pl[:npasses.value].copy(), pd[:npasses.value].copy()

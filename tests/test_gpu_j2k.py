@@ -1,0 +1,97 @@
+"""GPU parity of the JPEG 2000 stage: HIP path (through the C ABI) == the T.800 restatement byte for byte,
+and every code-stream decodes in an independent decoder (OpenJPEG via Pillow).  Parity with the
+reference's Kakadu is UNPINNED (see oracle/j2k_oracle.c)."""
+import numpy as np
+import pytest
+
+from qsvc_amd.synth import make_clip
+
+pytestmark = pytest.mark.gpu
+J = pytest.importorskip("oracle.j2k")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from qsvc_amd import hip
+    e = hip.Engine(0)
+    yield e
+    e.close()
+
+
+def _luma(kind, W, H, seed):
+    return make_clip(kind, 1, W, H, seed)[0][:W * H].reshape(H, W)
+
+
+DWT_CASES = [("pan", 64, 64, 3), ("noise", 100, 75, 3), ("pan_noise", 352, 288, 5), ("edge", 37, 130, 2), ("noise", 65, 129, 1),
+             ("pan", 1920, 1080, 5)]
+
+
+@pytest.mark.parametrize("kind,W,H,levels", DWT_CASES)
+def test_dwt53_bit_exact(eng, kind, W, H, levels):
+    y = _luma(kind, W, H, 5)
+    np.testing.assert_array_equal(eng.j2k_dwt(y, True, levels), J.coefficients(y, True, levels))
+
+
+@pytest.mark.parametrize("kind,W,H,levels", DWT_CASES)
+def test_dwt97_within_one_ulp(eng, kind, W, H, levels):
+    """north_star tolerance: within 1 ULP per coefficient (float32); the kernel keeps the restatement's
+    operation order without FMA contraction, so in practice it is bit-identical."""
+    y = _luma(kind, W, H, 6)
+    got, want = eng.j2k_dwt(y, False, levels), J.dwt97(y, levels)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1
+    np.testing.assert_array_equal(got, want)
+
+
+CS_CASES = [("pan", 64, 64, 0), ("pan", 64, 64, 3), ("noise", 100, 75, 3), ("binary", 128, 96, 5), ("pan_noise", 352, 288, 4),
+            ("edge", 37, 130, 2), ("saturating", 200, 120, 5), ("noise", 65, 129, 1), ("noise", 256, 256, 5)]
+
+
+@pytest.mark.parametrize("kind,W,H,levels", CS_CASES)
+@pytest.mark.parametrize("reversible", [True, False])
+def test_codestream_equals_restatement_and_decodes(eng, kind, W, H, levels, reversible):
+    from qsvc_amd import hip
+    y = _luma(kind, W, H, 7)
+    cs = eng.j2k_encode_plane(y, hip.j2k_params(reversible=reversible, levels=levels))
+    want = J.encode_plane(y, reversible=reversible, levels=levels)
+    assert cs == want
+    d = J.decode(cs)
+    if reversible:
+        np.testing.assert_array_equal(d, y)
+    else:
+        assert J.psnr(d, y) > 50
+
+
+def test_layers_slopes_and_options(eng):
+    from qsvc_amd import hip
+    y = _luma("pan", 352, 288, 42)
+    for kw in (dict(reversible=False, levels=4, layers=5, slopes=(49000, 48000, 47000, 46000, 45000)),
+               dict(reversible=False, levels=4, layers=5, slopes=(45000, 46000, 47000, 48000, 49000)),
+               dict(reversible=True, levels=4, layers=3, slopes=(47000, 45000, 0)),
+               dict(reversible=True, levels=3, use_sop=False),
+               dict(reversible=False, levels=5, base_step=1.0 / 16),
+               dict(reversible=True, levels=2, cblk=32)):
+        cs = eng.j2k_encode_plane(y, hip.j2k_params(**kw))
+        assert cs == J.encode_plane(y, **kw), kw
+    st = eng.j2k_stats()
+    assert st["codeblocks"] > 0 and st["passes"] > 0 and st["symbols"] > 0
+
+
+def test_frames_1080p_lossless(eng):
+    """BASELINE config 2: 1080p intra frame, 5/3 + EBCOT: per-component streams == restatement, lossless."""
+    from qsvc_amd import hip
+    W, H = 1920, 1080
+    clip = make_clip("pan_noise", 2, W, H, 43)
+    eng.seq_config(W, H)
+    eng.put_frames(hip.LOW, 0, clip)
+    streams = eng.j2k_encode_frames(hip.LOW, 0, 0, 2, hip.j2k_params(reversible=True, levels=4))
+    assert len(streams) == 6
+    assert eng.j2k_stats()["codeblocks"] == 2 * 921
+    for i in range(2):
+        Y = clip[i][:W * H].reshape(H, W)
+        U = clip[i][W * H:W * H + (W // 2) * (H // 2)].reshape(H // 2, W // 2)
+        V = clip[i][W * H + (W // 2) * (H // 2):].reshape(H // 2, W // 2)
+        for k, pl in enumerate((Y, U, V)):
+            np.testing.assert_array_equal(J.decode(streams[3 * i + k]), pl)
+    assert streams[0] == J.encode_plane(clip[0][:W * H].reshape(H, W), reversible=True, levels=4)
+    assert streams[4] == J.encode_plane(clip[1][W * H:W * H + (W // 2) * (H // 2)].reshape(H // 2, W // 2), reversible=True, levels=4)
