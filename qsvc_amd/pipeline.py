@@ -1,0 +1,95 @@
+"""Device-resident `mctf compress` pipeline: the orchestration of compress.py / analyze.py /
+analyze_step.py / texture_compress.py / texture_compress_fb_j2k.py with every stage running on the GPU
+through the C ABI and nothing but code-streams crossing PCIe.
+
+The compute backend is an `Engine` (qsvc_amd/hip.py).  `exchange` (optional) implements the open-GOP
+boundary exchange between neighbouring shards (qsvc_amd/sharding.py).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+from . import schedule
+from .hip import HIGH, LOW, j2k_params
+
+
+@dataclass
+class CompressParams:  # defaults of compress.py:57-106
+    pixels_in_x: int = 352
+    pixels_in_y: int = 288
+    always_B: int = 0
+    block_size: int | None = None
+    block_size_min: int | None = None
+    GOPs: int = 1
+    quantization_texture: int = 45000
+    quantization_step: int = 0
+    search_range: int = 4
+    TRLs: int = 4
+    SRLs: int = 5
+    nLayers: int = 5
+    update_factor: float = 0.25
+    reversible: bool = False       # build extension: the reference hard-codes Creversible=no
+    lossless: bool = False         # build extension: one layer, every coding pass (ignores the slopes)
+    base_step: float = 1.0 / 256
+
+    def resolve(self):
+        d = schedule.default_block_size(self.pixels_in_x, self.pixels_in_y)
+        if self.block_size is None:
+            self.block_size = d
+        if self.block_size_min is None:
+            self.block_size_min = d
+        return self
+
+
+class Compressor:
+    def __init__(self, engine, params: CompressParams, exchange=None):
+        self.e = engine
+        self.p = params.resolve()
+        self.exchange = exchange
+        self.levels = schedule.level_schedule(self.p.GOPs, self.p.TRLs, self.p.block_size, self.p.block_size_min, self.p.search_range)
+        self.pictures = schedule.pictures(self.p.GOPs, self.p.TRLs)
+        self.slopes = schedule.slope_table(self.p.TRLs, self.p.quantization_texture, self.p.nLayers, self.p.quantization_step)
+
+    def configure(self, keep_prediction=False):
+        self.e.seq_config(self.p.pixels_in_x, self.p.pixels_in_y, keep_prediction)
+
+    def load(self, low0):
+        self.e.put_frames(LOW, 0, low0)
+
+    # analyze.py:121-153 -> analyze_step.py:117-232
+    def analyze(self):
+        for (t, P, S, bs) in self.levels:
+            self.e.motion_estimate(t, P, bs, S)
+            self.e.decorrelate(t, P, bs, S, self.p.always_B)
+            if self.exchange is not None:
+                self.exchange.exchange(self.e, t, bs)
+            self.e.update(t, P, bs, self.p.update_factor)
+
+    def j2k_params_for(self, subband_index):
+        """subband_index into the slope table: 0 = L, k = H_{TRLs-k} (texture_compress.py:183-217)."""
+        if self.p.lossless:
+            return j2k_params(reversible=True, levels=max(self.p.SRLs - 1, 0), layers=1)
+        return j2k_params(reversible=self.p.reversible, levels=max(self.p.SRLs - 1, 0), layers=self.p.nLayers,
+                          slopes=self.slopes[subband_index], base_step=self.p.base_step)
+
+    # texture_compress.py:183-217: high_t (pictures-1 each) then low_{TRLs-1}
+    def texture_items(self, low_first=0):
+        items = []
+        for (t, P, S, bs) in self.levels:
+            items.append((HIGH, t, 0, P // 2, self.j2k_params_for(self.p.TRLs - t)))
+        T = self.p.TRLs - 1
+        nlow = self.levels[-1][1] // 2 + 1 if self.levels else self.pictures
+        items.append((LOW, T, low_first, nlow - low_first, self.j2k_params_for(0)))
+        return items
+
+    def texture(self, low_first=0):
+        """-> {(kind, t): [code-stream bytes per (picture, component)]}"""
+        out = {}
+        for (kind, t, first, count, prm) in self.texture_items(low_first):
+            out[(kind, t)] = self.e.j2k_encode_frames(kind, t, first, count, prm) if count > 0 else []
+        return out
+
+    def compress(self):
+        if self.p.TRLs > 1:
+            self.analyze()
+        return self.texture()
