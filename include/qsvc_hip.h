@@ -140,6 +140,12 @@ typedef struct {
  * (picture, component); offs[3*count+1] receives their byte offsets. */
 int qsvc_j2k_encode_frames(qsvc_ctx* ctx, int kind, int t, int first, int count, const qsvc_j2k_params* p,
                            uint8_t* out, size_t cap, size_t* offs);
+/* Several sequences in ONE batch (one DWT / Tier-1 launch set for all of them): sequence i is
+ * (kinds[i], ts[i], firsts[i], counts[i]) coded with prms[i].  The transform, step and code-block
+ * parameters must agree across the batch; layers and slopes may differ (texture_compress.py:183-217 codes
+ * high_1..high_{T-1} and low_{T-1} with different slope lists).  offs[3*sum(counts)+1]. */
+int qsvc_j2k_encode_multi(qsvc_ctx* ctx, int nseq, const int* kinds, const int* ts, const int* firsts, const int* counts,
+                          const qsvc_j2k_params* prms, uint8_t* out, size_t cap, size_t* offs);
 /* Same on a host plane (copied to the device first); one code-stream. */
 int qsvc_j2k_encode_plane(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, const qsvc_j2k_params* p, uint8_t* out,
                           size_t cap, size_t* len);

@@ -7,6 +7,7 @@
 // defaults kept: one tile, 64x64 code-blocks, LRCP, no precinct partition.  Algorithm: ITU-T T.800.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -300,17 +301,24 @@ static long write_codestream(const PlanePlan& pp, const qsvc_j2k_params& prm, in
   return o.ovf ? -1 : (long)o.n;
 }
 
-struct PlaneSrc { size_t u8off; int stride, W, H; };
+struct PlaneSrc { const uint8_t* src; int stride, W, H; const qsvc_j2k_params* prm; };
 
-// Encode a batch of planes whose samples live in the device buffer `u8base`.
-static int j2k_encode_planes(qsvc_ctx* c, const uint8_t* u8base, const std::vector<PlaneSrc>& src, const qsvc_j2k_params* prm,
-                             uint8_t* out, size_t cap, size_t* offs) {
+// Encode a batch of device-resident planes.  All planes share the transform/quantiser/code-block parameters
+// of src[0].prm; the number of layers and the slopes may differ per plane (they only steer the host's PCRD).
+static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8_t* out, size_t cap, size_t* offs) {
   if (!c->j2k) c->j2k = new J2kState();
   J2kState& S = *c->j2k;
+  const qsvc_j2k_params* prm = src[0].prm;
+  bool any_dist = false;
+  for (auto& p : src) {
+    if (p.prm->reversible != prm->reversible || p.prm->levels != prm->levels || p.prm->cblk_w != prm->cblk_w ||
+        p.prm->cblk_h != prm->cblk_h || p.prm->base_step != prm->base_step)
+      return c->fail(QSVC_ERR_INVALID, "planes of one batch must share transform, step and code-block parameters");
+    if (p.prm->layers > 16) return c->fail(QSVC_ERR_INVALID, "at most 16 quality layers");
+    if (p.prm->layers > 1 || p.prm->slopes[0] > 0) any_dist = true;
+  }
   const bool rev = prm->reversible != 0;
-  int layers = prm->layers < 1 ? 1 : prm->layers;
   int cbw = prm->cblk_w ? prm->cblk_w : 64, cbh = prm->cblk_h ? prm->cblk_h : 64;
-  if (layers > 16) return c->fail(QSVC_ERR_INVALID, "at most 16 quality layers");
   if (prm->levels < 0 || prm->levels > J2K_MAXLEV) return c->fail(QSVC_ERR_INVALID, "Clevels %d", prm->levels);
   if (cbw > 64 || cbh > 64 || cbw < 4 || cbh < 4 || (cbw & (cbw - 1)) || (cbh & (cbh - 1)))
     return c->fail(QSVC_ERR_UNSUPPORTED, "code-block %dx%d (powers of two in 4..64)", cbw, cbh);
@@ -333,7 +341,7 @@ static int j2k_encode_planes(qsvc_ctx* c, const uint8_t* u8base, const std::vect
   std::vector<int> first_cb(np + 1);
   int ncb = 0;
   for (int p = 0; p < np; p++) {
-    S.planes[p].off = total; S.planes[p].u8off = src[p].u8off; S.planes[p].u8stride = src[p].stride; S.planes[p].W = src[p].W; S.planes[p].H = src[p].H;
+    S.planes[p].off = total; S.planes[p].src = src[p].src; S.planes[p].u8stride = src[p].stride; S.planes[p].W = src[p].W; S.planes[p].H = src[p].H;
     total += (size_t)src[p].W * src[p].H;
     maxW = std::max(maxW, src[p].W); maxH = std::max(maxH, src[p].H); maxL = std::max(maxL, plans[plan_of[p]].L);
     first_cb[p] = ncb; ncb += plans[plan_of[p]].ncb;
@@ -356,16 +364,17 @@ static int j2k_encode_planes(qsvc_ctx* c, const uint8_t* u8base, const std::vect
           d.orient = (short)s.orient; d.Mb = (short)s.Mb; d.delta = s.delta;
         }
   }
-  const int ngroups = (ncb + 63) / 64;
-  const bool want_dist = layers > 1 || prm->slopes[0] > 0;
+  static const int lanes = [] { const char* e = getenv("QSVC_T1_LANES"); int v = e ? atoi(e) : 8; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 8; }();
+  const int ngroups = (ncb + lanes - 1) / lanes;
+  const bool want_dist = any_dist;
   int r;
   if ((r = S.coefA.ensure(c, total * 4))) return r;
   if ((r = S.coefB.ensure(c, total * 4))) return r;
   if ((r = S.planes_d.ensure(c, np * sizeof(PlaneDesc)))) return r;
   if ((r = S.cbs_d.ensure(c, (size_t)ncb * sizeof(CbDesc)))) return r;
   if ((r = S.nbps_d.ensure(c, (size_t)ncb * 4))) return r;
-  if ((r = S.mags.ensure(c, (size_t)ngroups * T1_MAGS_PER_GROUP * 8))) return r;
-  if ((r = S.flags.ensure(c, (size_t)ngroups * T1_FLAGS_PER_GROUP * 4))) return r;
+  if ((r = S.mags.ensure(c, (size_t)ngroups * lanes * T1_MAGS_WORDS * 4))) return r;
+  if ((r = S.flags.ensure(c, (size_t)ngroups * lanes * T1_FLAGS_WORDS * 4))) return r;
   if ((r = S.outbuf.ensure(c, (size_t)ncb * J2K_OUTCAP))) return r;
   if ((r = S.res_d.ensure(c, (size_t)ncb * sizeof(CbOut)))) return r;
   if ((r = S.plen_d.ensure(c, (size_t)ncb * T1_MAXPASS * 4))) return r;
@@ -378,17 +387,17 @@ static int j2k_encode_planes(qsvc_ctx* c, const uint8_t* u8base, const std::vect
   HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
   Prof pf;
   pf.begin(c, rev ? "j2k_dwt53" : "j2k_dwt97");
-  launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, u8base, S.coefA.p, S.coefB.p, maxL, rev);
+  launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, S.coefA.p, S.coefB.p, maxL, rev);
   pf.end(c);
   pf.begin(c, "j2k_t1_pack");
-  HIPCHK(c, hipMemsetAsync(S.flags.p, 0, (size_t)ngroups * T1_FLAGS_PER_GROUP * 4, c->st));
-  launch_t1_pack(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (uint64_t*)S.mags.p, (int*)S.nbps_d.p,
-                 (int*)S.err_d.p, rev);
+  HIPCHK(c, hipMemsetAsync(S.flags.p, 0, (size_t)ngroups * lanes * T1_FLAGS_WORDS * 4, c->st));
+  launch_t1_pack(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (uint32_t*)S.mags.p, (int*)S.nbps_d.p,
+                 (int*)S.err_d.p, rev, lanes);
   pf.end(c);
   pf.begin(c, "j2k_t1_encode");
-  launch_t1_encode(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const uint64_t*)S.mags.p, (uint32_t*)S.flags.p,
+  launch_t1_encode(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const uint32_t*)S.mags.p, (uint32_t*)S.flags.p,
                    (uint8_t*)S.outbuf.p, J2K_OUTCAP, (CbOut*)S.res_d.p, (int*)S.plen_d.p, want_dist ? (long long*)S.pdist_d.p : nullptr,
-                   want_dist ? 1 : 0);
+                   want_dist ? 1 : 0, lanes);
   pf.end(c);
   S.res.resize(ncb);
   int err = 0;
@@ -411,6 +420,8 @@ static int j2k_encode_planes(qsvc_ctx* c, const uint8_t* u8base, const std::vect
   S.st_cb = ncb; S.st_pass = 0; S.st_sym = 0;
   for (int p = 0; p < np; p++) {
     const PlanePlan& pl = plans[plan_of[p]];
+    const qsvc_j2k_params* pprm = src[p].prm;
+    const int layers = pprm->layers < 1 ? 1 : pprm->layers;
     for (auto& s : pl.sb) {
       double wgt = (double)s.delta * norm_of(rev, s.orient, s.dlev);
       wgt *= wgt;
@@ -424,9 +435,9 @@ static int j2k_encode_planes(qsvc_ctx* c, const uint8_t* u8base, const std::vect
         const int* plen = S.plen.data() + (size_t)k * T1_MAXPASS;
         for (int l = 0; l < layers; l++) {
           int n;
-          if (l == layers - 1 && prm->slopes[l] <= 0) n = ro.npasses;
-          else if (prm->slopes[l] <= 0) n = 0;
-          else n = passes_for_lambda(ro.npasses, plen, S.pdist.data() + (size_t)k * T1_MAXPASS, wgt, slope_to_lambda(prm->slopes[l]));
+          if (l == layers - 1 && pprm->slopes[l] <= 0) n = ro.npasses;
+          else if (pprm->slopes[l] <= 0) n = 0;
+          else n = passes_for_lambda(ro.npasses, plen, S.pdist.data() + (size_t)k * T1_MAXPASS, wgt, slope_to_lambda(pprm->slopes[l]));
           if (l > 0 && n < h.layer_passes[l - 1]) n = h.layer_passes[l - 1];
           h.layer_passes[l] = n;
         }
@@ -458,7 +469,7 @@ static int j2k_encode_planes(qsvc_ctx* c, const uint8_t* u8base, const std::vect
   size_t pos = 0;
   for (int p = 0; p < np; p++) {
     offs[p] = pos;
-    long n = write_codestream(plans[plan_of[p]], *prm, layers, cbw, cbh, S.hcb.data() + first_cb[p],
+    long n = write_codestream(plans[plan_of[p]], *src[p].prm, src[p].prm->layers < 1 ? 1 : src[p].prm->layers, cbw, cbh, S.hcb.data() + first_cb[p],
                               S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS, S.gath_h, out + pos, cap - pos);
     if (n < 0) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes)", cap);
     pos += (size_t)n;
@@ -469,11 +480,7 @@ static int j2k_encode_planes(qsvc_ctx* c, const uint8_t* u8base, const std::vect
 
 extern "C" {
 
-int qsvc_j2k_encode_frames(qsvc_ctx* c, int kind, int t, int first, int count, const qsvc_j2k_params* prm, uint8_t* out,
-                           size_t cap, size_t* offs) {
-  if (!c || !prm || !out || !offs) return QSVC_ERR_INVALID;
-  (void)hipSetDevice(c->dev);
-  if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+static int add_sequence(qsvc_ctx* c, int kind, int t, int first, int count, const qsvc_j2k_params* prm, std::vector<PlaneSrc>& src) {
   if (t < 0 || t > QSVC_MAX_T) return c->fail(QSVC_ERR_INVALID, "temporal subband %d out of range", t);
   Level& lv = c->lv[t];
   DevBuf* b; int n;
@@ -484,17 +491,33 @@ int qsvc_j2k_encode_frames(qsvc_ctx* c, int kind, int t, int first, int count, c
     default: return c->fail(QSVC_ERR_INVALID, "unknown sequence kind %d", kind);
   }
   if (first < 0 || count < 0 || first + count > n) return c->fail(QSVC_ERR_STATE, "sequence kind %d t=%d holds %d pictures", kind, t, n);
-  if (count == 0) { offs[0] = 0; return QSVC_OK; }
-  std::vector<PlaneSrc> src;
   int cw = c->W / 2, ch = c->H / 2;
   for (int i = 0; i < count; i++) {  // order (picture, component), texture_compress_fb_j2k.py:255-257
-    size_t f = (size_t)(first + i) * c->F;
-    src.push_back({f, c->W, c->W, c->H});
-    src.push_back({f + (size_t)c->W * c->H, cw, cw, ch});
-    src.push_back({f + (size_t)c->W * c->H + (size_t)cw * ch, cw, cw, ch});
+    const uint8_t* f = (const uint8_t*)b->p + (size_t)(first + i) * c->F;
+    src.push_back({f, c->W, c->W, c->H, prm});
+    src.push_back({f + (size_t)c->W * c->H, cw, cw, ch, prm});
+    src.push_back({f + (size_t)c->W * c->H + (size_t)cw * ch, cw, cw, ch, prm});
   }
-  // the batched DWT needs one level count: luma and chroma planes go in separate batches if they differ
-  return j2k_encode_planes(c, (const uint8_t*)b->p, src, prm, out, cap, offs);
+  return QSVC_OK;
+}
+
+int qsvc_j2k_encode_frames(qsvc_ctx* c, int kind, int t, int first, int count, const qsvc_j2k_params* prm, uint8_t* out,
+                           size_t cap, size_t* offs) {
+  return qsvc_j2k_encode_multi(c, 1, &kind, &t, &first, &count, prm, out, cap, offs);
+}
+
+int qsvc_j2k_encode_multi(qsvc_ctx* c, int nseq, const int* kinds, const int* ts, const int* firsts, const int* counts,
+                          const qsvc_j2k_params* prms, uint8_t* out, size_t cap, size_t* offs) {
+  if (!c || !kinds || !ts || !firsts || !counts || !prms || !out || !offs || nseq < 1) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+  std::vector<PlaneSrc> src;
+  for (int i = 0; i < nseq; i++) {
+    int r = add_sequence(c, kinds[i], ts[i], firsts[i], counts[i], &prms[i], src);
+    if (r) return r;
+  }
+  if (src.empty()) { offs[0] = 0; return QSVC_OK; }
+  return j2k_encode_planes(c, src, out, cap, offs);
 }
 
 int qsvc_j2k_encode_plane(qsvc_ctx* c, const uint8_t* plane, int H, int W, const qsvc_j2k_params* prm, uint8_t* out, size_t cap,
@@ -505,9 +528,9 @@ int qsvc_j2k_encode_plane(qsvc_ctx* c, const uint8_t* plane, int H, int W, const
   int r = c->j2k->up_d.ensure(c, (size_t)W * H);
   if (r) return r;
   HIPCHK(c, hipMemcpyAsync(c->j2k->up_d.p, plane, (size_t)W * H, hipMemcpyHostToDevice, c->st));
-  std::vector<PlaneSrc> src{{0, W, W, H}};
+  std::vector<PlaneSrc> src{{(const uint8_t*)c->j2k->up_d.p, W, W, H, prm}};
   size_t offs[2];
-  r = j2k_encode_planes(c, (const uint8_t*)c->j2k->up_d.p, src, prm, out, cap, offs);
+  r = j2k_encode_planes(c, src, out, cap, offs);
   if (r) return r;
   *len = offs[1];
   return QSVC_OK;
@@ -526,10 +549,10 @@ int qsvc_j2k_dwt(qsvc_ctx* c, const uint8_t* plane, int H, int W, int reversible
   if ((r = S.planes_d.ensure(c, sizeof(PlaneDesc)))) return r;
   int L = levels;
   while (L > 0 && ((W >> (L - 1)) < 1 || (H >> (L - 1)) < 1)) L--;
-  PlaneDesc pd{0, 0, W, W, H};
+  PlaneDesc pd{0, (const uint8_t*)S.up_d.p, W, W, H};
   HIPCHK(c, hipMemcpyAsync(S.up_d.p, plane, N, hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipMemcpyAsync(S.planes_d.p, &pd, sizeof pd, hipMemcpyHostToDevice, c->st));
-  launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, (const uint8_t*)S.up_d.p, S.coefA.p, S.coefB.p, L, reversible != 0);
+  launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, S.coefA.p, S.coefB.p, L, reversible != 0);
   HIPCHK(c, hipMemcpyAsync(out, S.coefA.p, N * 4, hipMemcpyDeviceToHost, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   HIPCHK(c, hipGetLastError());

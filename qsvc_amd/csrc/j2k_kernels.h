@@ -8,7 +8,7 @@ namespace qsvc {
 
 struct PlaneDesc {   // one image component plane of the batch
   size_t off;        // element offset of the plane in the coefficient buffers (stride = W)
-  size_t u8off;      // byte offset of the source samples in the u8 frame store
+  const uint8_t* src; // source 8-bit samples (device)
   int u8stride;      // source row stride in bytes
   int W, H;
 };
@@ -25,16 +25,16 @@ struct CbOut {
   unsigned long long nsym;
 };
 
-// Tier-1 working set per group of 64 code-blocks (lane-interleaved)
-#define T1_MAGS_PER_GROUP (16 * 64 * 64)          // u64 words
-#define T1_FLAGS_PER_GROUP (18 * T1_FW * 64)      // u32 words
+// Tier-1 working set per code-block, lane-interleaved within a group of `lanes` blocks
+#define T1_MAGS_WORDS (16 * 64 * 2)               // u32 words per block: [stripe][x][half] (x lanes)
+#define T1_FLAGS_WORDS (18 * T1_FW)               // u32 words per block (x lanes)
 
-void launch_dwt(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, const uint8_t* u8base, void* A,
+void launch_dwt(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, void* A,
                 void* B, int levels, bool reversible);
-void launch_t1_pack(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef, uint64_t* mags,
-                    int* nbps, int* err, bool reversible);
-void launch_t1_encode(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint64_t* mags, uint32_t* flags,
-                      uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist);
+void launch_t1_pack(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef, uint32_t* mags,
+                    int* nbps, int* err, bool reversible, int lanes);
+void launch_t1_encode(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint32_t* mags, uint32_t* flags,
+                      uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist, int lanes);
 void launch_gather(hipStream_t st, const uint8_t* outbuf, int outcap, const unsigned long long* offs, const int* lens, int ncb,
                    uint8_t* dst);
 }  // namespace qsvc

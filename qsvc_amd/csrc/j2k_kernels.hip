@@ -56,7 +56,7 @@ __device__ __forceinline__ float dwt97_coef(const Ld& X, int k, int n) {  // T.8
 
 // vertical pass of level `lev` (region hr x wr of each plane): src -> dst (same layout)
 template <bool REV, bool FROM_U8>
-__global__ void __launch_bounds__(256) k_dwt_v(const PlaneDesc* planes, const uint8_t* u8base, const void* srcv, void* dstv, int lev) {
+__global__ void __launch_bounds__(256) k_dwt_v(const PlaneDesc* planes, const void* srcv, void* dstv, int lev) {
   PlaneDesc pd = planes[blockIdx.z];
   int wr = pd.W, hr = pd.H;
   for (int l = 0; l < lev; l++) { wr = (wr + 1) >> 1; hr = (hr + 1) >> 1; }
@@ -65,12 +65,12 @@ __global__ void __launch_bounds__(256) k_dwt_v(const PlaneDesc* planes, const ui
   size_t o = pd.off + (size_t)y * pd.W + x;
   if (REV) {
     const int32_t* s = (const int32_t*)srcv + pd.off;
-    const uint8_t* u = u8base + pd.u8off;
+    const uint8_t* u = pd.src;
     auto X = [&](int yy) { return FROM_U8 ? (int)u[(size_t)yy * pd.u8stride + x] - 128 : s[(size_t)yy * pd.W + x]; };
     ((int32_t*)dstv)[o] = hr >= 2 ? dwt53_coef(X, y, hr) : X(y);
   } else {
     const float* s = (const float*)srcv + pd.off;
-    const uint8_t* u = u8base + pd.u8off;
+    const uint8_t* u = pd.src;
     auto X = [&](int yy) { return FROM_U8 ? (float)((int)u[(size_t)yy * pd.u8stride + x] - 128) : s[(size_t)yy * pd.W + x]; };
     ((float*)dstv)[o] = hr >= 2 ? dwt97_coef(X, y, hr) : X(y);
   }
@@ -95,22 +95,22 @@ __global__ void __launch_bounds__(256) k_dwt_h(const PlaneDesc* planes, const vo
 }
 // level 0 with no decomposition at all: just the level shift
 template <bool REV>
-__global__ void __launch_bounds__(256) k_level_shift(const PlaneDesc* planes, const uint8_t* u8base, void* dstv) {
+__global__ void __launch_bounds__(256) k_level_shift(const PlaneDesc* planes, void* dstv) {
   PlaneDesc pd = planes[blockIdx.z];
   int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= pd.W || y >= pd.H) return;
-  int v = (int)u8base[pd.u8off + (size_t)y * pd.u8stride + x] - 128;
+  int v = (int)pd.src[(size_t)y * pd.u8stride + x] - 128;
   if (REV) ((int32_t*)dstv)[pd.off + (size_t)y * pd.W + x] = v;
   else ((float*)dstv)[pd.off + (size_t)y * pd.W + x] = (float)v;
 }
 
-void launch_dwt(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, const uint8_t* u8base, void* A,
+void launch_dwt(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, void* A,
                 void* B, int levels, bool reversible) {
   dim3 block(64, 4);
   if (levels == 0) {
     dim3 grid((maxW + 63) / 64, (maxH + 3) / 4, nplanes);
-    if (reversible) hipLaunchKernelGGL(k_level_shift<true>, grid, block, 0, st, d_planes, u8base, A);
-    else hipLaunchKernelGGL(k_level_shift<false>, grid, block, 0, st, d_planes, u8base, A);
+    if (reversible) hipLaunchKernelGGL(k_level_shift<true>, grid, block, 0, st, d_planes, A);
+    else hipLaunchKernelGGL(k_level_shift<false>, grid, block, 0, st, d_planes, A);
     return;
   }
   int w = maxW, h = maxH;
@@ -118,12 +118,12 @@ void launch_dwt(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW
     dim3 grid((w + 63) / 64, (h + 3) / 4, nplanes);
     // vertical: A (or the u8 source at level 0) -> B ; horizontal: B -> A
     if (reversible) {
-      if (l == 0) hipLaunchKernelGGL((k_dwt_v<true, true>), grid, block, 0, st, d_planes, u8base, A, B, l);
-      else hipLaunchKernelGGL((k_dwt_v<true, false>), grid, block, 0, st, d_planes, u8base, A, B, l);
+      if (l == 0) hipLaunchKernelGGL((k_dwt_v<true, true>), grid, block, 0, st, d_planes, A, B, l);
+      else hipLaunchKernelGGL((k_dwt_v<true, false>), grid, block, 0, st, d_planes, A, B, l);
       hipLaunchKernelGGL(k_dwt_h<true>, grid, block, 0, st, d_planes, B, A, l);
     } else {
-      if (l == 0) hipLaunchKernelGGL((k_dwt_v<false, true>), grid, block, 0, st, d_planes, u8base, A, B, l);
-      else hipLaunchKernelGGL((k_dwt_v<false, false>), grid, block, 0, st, d_planes, u8base, A, B, l);
+      if (l == 0) hipLaunchKernelGGL((k_dwt_v<false, true>), grid, block, 0, st, d_planes, A, B, l);
+      else hipLaunchKernelGGL((k_dwt_v<false, false>), grid, block, 0, st, d_planes, A, B, l);
       hipLaunchKernelGGL(k_dwt_h<false>, grid, block, 0, st, d_planes, B, A, l);
     }
     w = (w + 1) >> 1; h = (h + 1) >> 1;
@@ -134,13 +134,13 @@ void launch_dwt(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW
 // Quantise + pack one code-block per workgroup into the lane-interleaved Tier-1 layout.
 template <bool REV>
 __global__ void __launch_bounds__(256) k_t1_pack(const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coefv,
-                                                  uint64_t* mags, int* nbps_out, int* err) {
+                                                  uint32_t* mags, int* nbps_out, int* err, int lanes) {
   int b = blockIdx.x;
   if (b >= ncb) return;
   CbDesc cb = cbs[b];
   PlaneDesc pd = planes[cb.plane];
-  int g = b >> 6, lane = b & 63;
-  uint64_t* mg = mags + (size_t)g * T1_MAGS_PER_GROUP + lane;
+  int g = b / lanes, lane = b % lanes;
+  uint32_t* mg = mags + (size_t)g * T1_MAGS_WORDS * lanes + lane;
   __shared__ int smax[256];
   int x = threadIdx.x & 63, sq = threadIdx.x >> 6;
   int mymax = 0;
@@ -164,7 +164,8 @@ __global__ void __launch_bounds__(256) k_t1_pack(const CbDesc* cbs, int ncb, con
         word |= (uint64_t)((mag & 0x7FFF) | (neg << 15)) << (16 * k);
       }
     }
-    mg[(size_t)(s * 64 + x) * 64] = word;
+    mg[(size_t)((s * 64 + x) * 2 + 0) * lanes] = (uint32_t)word;
+    mg[(size_t)((s * 64 + x) * 2 + 1) * lanes] = (uint32_t)(word >> 32);
   }
   smax[threadIdx.x] = mymax;
   __syncthreads();
@@ -179,33 +180,92 @@ __global__ void __launch_bounds__(256) k_t1_pack(const CbDesc* cbs, int ncb, con
     if (nb > cb.Mb || nb > 15) atomicOr(err, 1);  // magnitude does not fit M_b / the 15-bit lane format
   }
 }
-void launch_t1_pack(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef, uint64_t* mags,
-                    int* nbps, int* err, bool reversible) {
-  if (reversible) hipLaunchKernelGGL(k_t1_pack<true>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err);
-  else hipLaunchKernelGGL(k_t1_pack<false>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err);
+void launch_t1_pack(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef, uint32_t* mags,
+                    int* nbps, int* err, bool reversible, int lanes) {
+  if (reversible) hipLaunchKernelGGL(k_t1_pack<true>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err, lanes);
+  else hipLaunchKernelGGL(k_t1_pack<false>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err, lanes);
 }
 
 // ---------------------------------------------------------------------------------------------
-// EBCOT Tier-1: one wavefront = 64 code-blocks.
+// EBCOT Tier-1: one wavefront = 64 code-blocks, one per lane (t1_core.h).
+//
+// Block state streams through an LDS window: per pass every flag row (66 words x 64 lanes) and every
+// stripe's magnitudes are brought in ONCE by LDS-DMA (global_load_lds, 256 contiguous bytes per
+// wave-instruction, no VGPR round trip), one stripe ahead of the stripe being coded, and each flag row is
+// written back once.  The coding loop itself touches only LDS and registers, so the serial per-lane chain
+// never waits on HBM.  LDS per wave: 4 flag-row slots (67.6 KB) + 2 magnitude buffers (64 KB) + coder
+// tables (3 KB): one workgroup per CU.
 __constant__ uint32_t c_mqtab[47] = T1_MQ_TABLE_INIT;
 
-__global__ void __launch_bounds__(64) k_t1_encode(const CbDesc* cbs, int ncb, const int* nbps_in, const uint64_t* mags,
-                                                   uint32_t* flags, uint8_t* outbuf, int outcap, CbOut* res, int* pass_len,
-                                                   long long* pass_dist, int want_dist) {
-  __shared__ uint8_t s_cx[19 * 64];
-  __shared__ uint32_t s_mq[47];
-  __shared__ uint8_t s_zc[3 * 512];
-  int lane = threadIdx.x, g = blockIdx.x, b = g * 64 + lane;
-  if (lane < 47) s_mq[lane] = c_mqtab[lane];
-  for (int i = lane; i < 3 * 512; i += 64) {
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int LANES>
+struct T1LdsStore {
+  uint32_t* F;            // LDS [4][T1_FW][LANES]
+  uint32_t* M;            // LDS [2][128][LANES]
+  uint32_t* gflags;       // this group's flag words in HBM (lane-interleaved); already offset by lane
+  const uint32_t* gmags;  // this group's magnitude words in HBM; already offset by lane
+  int lane;
+  __device__ __forceinline__ uint32_t ld(int r, int c) const { return F[((r & 3) * T1_FW + c) * LANES + lane]; }
+  __device__ __forceinline__ void st(int r, int c, uint32_t v) { F[((r & 3) * T1_FW + c) * LANES + lane] = v; }
+  __device__ __forceinline__ void orr(int r, int c, uint32_t b) { F[((r & 3) * T1_FW + c) * LANES + lane] |= b; }
+  __device__ __forceinline__ uint64_t mag(int s, int x) const {
+    const uint32_t* m = M + ((s & 1) * 128 + x * 2) * LANES + lane;
+    return (uint64_t)m[0] | ((uint64_t)m[LANES] << 32);
+  }
+  __device__ __forceinline__ void dma_row(int r) {  // flag row r -> slot r&3
+    const uint32_t* g = gflags + (size_t)r * T1_FW * LANES;
+    uint32_t* l = F + (r & 3) * T1_FW * LANES;
+#pragma unroll 6
+    for (int c = 0; c < T1_FW; c++)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + c * LANES), (lds_ptr_t)(l + c * LANES), 4, 0, 0);
+  }
+  __device__ __forceinline__ void dma_mags(int s) {  // magnitudes of stripe s -> buffer s&1
+    const uint32_t* g = gmags + (size_t)s * 128 * LANES;
+    uint32_t* l = M + (s & 1) * 128 * LANES;
+#pragma unroll 8
+    for (int i = 0; i < 128; i++)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * LANES), (lds_ptr_t)(l + i * LANES), 4, 0, 0);
+  }
+  __device__ __forceinline__ void wb_row(int r) {  // slot r&3 -> flag row r in HBM
+    uint32_t* g = gflags + (size_t)r * T1_FW * LANES;
+    const uint32_t* l = F + (r & 3) * T1_FW * LANES + lane;
+#pragma unroll 6
+    for (int c = 0; c < T1_FW; c++) g[c * LANES] = l[c * LANES];
+  }
+  __device__ __forceinline__ void pass_begin(int nstripes) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the previous pass's write-backs
+    dma_row(0); dma_row(1); dma_row(2);
+    dma_mags(0);
+  }
+  __device__ __forceinline__ void stripe_begin(int s, int nstripes) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows <= s+2 and magnitudes of stripe s have landed
+    if (s + 1 < nstripes) { dma_row(s + 3); dma_mags(s + 1); }  // one stripe ahead; slot (s+3)&3 held row s-1
+  }
+  __device__ __forceinline__ void stripe_end(int s) { wb_row(s); }
+  __device__ __forceinline__ void pass_end(int nstripes) { wb_row(nstripes); wb_row(nstripes + 1); }
+};
+
+template <int LANES>
+__global__ void __launch_bounds__(LANES) k_t1_encode(const CbDesc* cbs, int ncb, const int* nbps_in, const uint32_t* mags,
+                                                      uint32_t* flags, uint8_t* outbuf, int outcap, CbOut* res, int* pass_len,
+                                                      long long* pass_dist, int want_dist) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* s_F = (uint32_t*)smem;                           // 4*66*LANES words
+  uint32_t* s_M = s_F + 4 * T1_FW * LANES;                   // 2*128*LANES words
+  uint32_t* s_mq = s_M + 2 * 128 * LANES;                    // 47 (padded to 64)
+  uint8_t* s_zc = (uint8_t*)(s_mq + 64);                     // 3*512
+  uint8_t* s_cx = s_zc + 3 * 512;                            // 19*LANES
+  int lane = threadIdx.x, g = blockIdx.x, b = g * LANES + lane;
+  for (int i = lane; i < 47; i += LANES) s_mq[i] = c_mqtab[i];
+  for (int i = lane; i < 3 * 512; i += LANES) {
     int c = i >> 9;
     s_zc[i] = (uint8_t)t1_zc_from_nb(i & 511, c == 0 ? 0 : (c == 1 ? 1 : 3));
   }
   __syncthreads();
   T1Lane t;
-  t.flags = flags + (size_t)g * T1_FLAGS_PER_GROUP + lane;
-  t.mags = mags + (size_t)g * T1_MAGS_PER_GROUP + lane;
-  t.cx = s_cx + lane; t.cs = 64; t.ls = 64;
+  t.cx = s_cx + lane; t.cs = LANES;
   t.mqtab = s_mq; t.zclut = s_zc;
   t.w = 0; t.h = 0; t.orient = 0; t.nbps = 0;
   t.out = outbuf; t.cap = 0;
@@ -214,28 +274,49 @@ __global__ void __launch_bounds__(64) k_t1_encode(const CbDesc* cbs, int ncb, co
     t.w = cb.w; t.h = cb.h; t.orient = cb.orient; t.nbps = nbps_in[b];
     t.out = outbuf + (size_t)b * outcap; t.cap = outcap;
   }
+  T1LdsStore<LANES> S;
+  S.F = s_F; S.M = s_M; S.lane = lane;
+  S.gflags = flags + (size_t)g * T1_FLAGS_WORDS * LANES + lane;
+  S.gmags = mags + (size_t)g * T1_MAGS_WORDS * LANES + lane;
   // wave-uniform scan bounds
   int top = t.nbps - 1, wmax = t.nbps ? t.w : 0, hmax = t.nbps ? t.h : 0;
-  for (int o = 32; o >= 1; o >>= 1) {
+  for (int o = LANES / 2; o >= 1; o >>= 1) {
     int a = __shfl_xor(top, o, 64), c = __shfl_xor(wmax, o, 64), d = __shfl_xor(hmax, o, 64);
     top = a > top ? a : top; wmax = c > wmax ? c : wmax; hmax = d > hmax ? d : hmax;
   }
+  top = __builtin_amdgcn_readfirstlane(top); wmax = __builtin_amdgcn_readfirstlane(wmax); hmax = __builtin_amdgcn_readfirstlane(hmax);
   T1Result r;
   int bb = b < ncb ? b : 0;
   r.pass_len = pass_len + (size_t)bb * T1_MAXPASS;
   r.pass_dist = want_dist ? pass_dist + (size_t)bb * T1_MAXPASS : nullptr;
-  t1_encode_lane(t, top, wmax, hmax, want_dist != 0, r);
+  t1_encode_lane(t, S, top, wmax, hmax, want_dist != 0, r);
   if (b < ncb) {
     CbOut o;
     o.len = r.len; o.npasses = r.npasses; o.nbps = r.nbps; o.overflow = r.overflow; o.nsym = r.nsym;
     res[b] = o;
   }
 }
-void launch_t1_encode(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint64_t* mags, uint32_t* flags,
-                      uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist) {
-  int ngroups = (ncb + 63) / 64;
-  hipLaunchKernelGGL(k_t1_encode, dim3(ngroups), dim3(64), 0, st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len,
-                     pass_dist, want_dist);
+template <int LANES>
+static void launch_t1_encode_n(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint32_t* mags, uint32_t* flags,
+                               uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist) {
+  const int smem = ((4 * T1_FW + 2 * 128) * LANES + 64) * 4 + 3 * 512 + 19 * LANES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_t1_encode<LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  int ngroups = (ncb + LANES - 1) / LANES;
+  hipLaunchKernelGGL(k_t1_encode<LANES>, dim3(ngroups), dim3(LANES), smem, st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res,
+                     pass_len, pass_dist, want_dist);
+}
+void launch_t1_encode(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint32_t* mags, uint32_t* flags,
+                      uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist, int lanes) {
+  switch (lanes) {
+    case 8: launch_t1_encode_n<8>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
+    case 16: launch_t1_encode_n<16>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
+    case 32: launch_t1_encode_n<32>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
+    default: launch_t1_encode_n<64>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
+  }
 }
 
 // gather: segment of block b (bytes 1..len of its lane buffer) -> dst + offs[b]

@@ -2,8 +2,9 @@
 //
 // Mapping: 64 code-blocks are coded by the 64 lanes of one wavefront in lock-step over the common
 // scan (bit-plane -> pass -> stripe -> column); each lane carries its own MQ coder and block state.
-// Block state lives in HBM in a lane-interleaved layout so that the wave's accesses coalesce:
-//   mags : [stripe-column][lane] u64 = 4 x (sign<<15 | 15-bit magnitude), rows 4s..4s+3 of column x
+// Block state lives in HBM in a lane-interleaved layout so that the wave's accesses coalesce, and is
+// streamed through an LDS window one stripe row at a time (j2k_kernels.hip):
+//   mags : [stripe-column][half][lane] u32 pairs = 4 x (sign<<15 | 15-bit magnitude), rows 4s..4s+3 of column x
 //   flags: [(stripe+1)*66 + (x+1)][lane] u32, one word per stripe-column with a one-cell apron:
 //            bits 0-17  significance of the 6x3 neighbourhood (rows 4s-1..4s+4, cols x-1..x+1), bit 3r+c
 //            bits 18-23 sign of the centre column's rows 4s-1..4s+4 (set when they become significant)
@@ -17,8 +18,10 @@
 
 #if defined(__HIPCC__)
 #define T1HD __host__ __device__ __forceinline__
+#define T1HD_M __host__ __device__ __forceinline__
 #else
 #define T1HD static inline
+#define T1HD_M inline
 #endif
 
 namespace qsvc {
@@ -77,15 +80,20 @@ struct T1Result {  // per code-block outputs besides the bytes
   unsigned long long nsym;
 };
 
-// One lane's view of its block.  `ls` = lane stride (64 on the GPU, 1 on the host harness).
+// One lane's MQ coder + block geometry.  Block state (flag words, magnitudes) is reached through a
+// `Store` policy so the same code runs over plain arrays on the host and over the LDS window on the GPU:
+//   uint32_t ld(int r, int c)            flag word of stripe-row r (= stripe+1), column c (= x+1)
+//   void     st(int r, int c, uint32_t)  store it
+//   void     orr(int r, int c, uint32_t) OR bits into it
+//   uint64_t mag(int s, int x)           4 x (sign<<15 | magnitude) of stripe s, column x
+//   void pass_begin(int nstripes) / stripe_begin(int s, int nstripes) / stripe_end(int s) / pass_end(int nstripes)
+//        wave-uniform window management (no-ops on the host)
 struct T1Lane {
-  uint32_t* flags;        // this lane's first flag word; word i at flags[i*ls]
-  const uint64_t* mags;   // this lane's first mags word; word i at mags[i*ls]
   uint8_t* cx;            // this lane's context-state bytes (index<<1 | mps); context c at cx[c*cs]
   const uint32_t* mqtab;  // [47]
   const uint8_t* zclut;   // [3][512] zero-coding LUT (class 0: LL/LH, 1: HL, 2: HH)
   uint8_t* out;           // out[0] is a scratch byte; the segment is out[1..]
-  int ls, cs;
+  int cs;
   int cap;                // bytes available at out (incl. the scratch byte)
   int w, h, orient, nbps;
   // MQ registers
@@ -147,30 +155,31 @@ T1HD int mq_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment lengt
 T1HD int t1_mag(uint64_t m, int k) { return (int)((m >> (16 * k)) & 0x7FFF); }
 T1HD int t1_neg(uint64_t m, int k) { return (int)((m >> (16 * k + 15)) & 1); }
 
-// sample (stripe s, column x, row-in-stripe k) has just become significant with sign `neg`:
-// publish it to every flag word whose neighbourhood contains it.  fw = index of word (s, x).
-T1HD void t1_set_sig(T1Lane& t, int fw, uint32_t& own, int k, int neg) {
-  int ls = t.ls;
+// sample (stripe-row r, column c, row-in-stripe k) has just become significant with sign `neg`:
+// publish it to every flag word whose neighbourhood contains it.  `own` is word (r, c) held in a register.
+template <class Store>
+T1HD void t1_set_sig(Store& S, int r, int c, uint32_t& own, int k, int neg) {
   own |= (1u << (3 * (k + 1) + 1)) | ((uint32_t)neg << (T1_CHI_SHIFT + k + 1));
-  t.flags[(fw - 1) * ls] |= 1u << (3 * (k + 1) + 2);
-  t.flags[(fw + 1) * ls] |= 1u << (3 * (k + 1) + 0);
-  if (k == 0) {  // also row 4 (r = 5) of the stripe above
-    t.flags[(fw - T1_FW) * ls] |= (1u << 16) | ((uint32_t)neg << (T1_CHI_SHIFT + 5));
-    t.flags[(fw - T1_FW - 1) * ls] |= 1u << 17;
-    t.flags[(fw - T1_FW + 1) * ls] |= 1u << 15;
-  } else if (k == 3) {  // also row -1 (r = 0) of the stripe below
-    t.flags[(fw + T1_FW) * ls] |= (1u << 1) | ((uint32_t)neg << (T1_CHI_SHIFT + 0));
-    t.flags[(fw + T1_FW - 1) * ls] |= 1u << 2;
-    t.flags[(fw + T1_FW + 1) * ls] |= 1u << 0;
+  S.orr(r, c - 1, 1u << (3 * (k + 1) + 2));
+  S.orr(r, c + 1, 1u << (3 * (k + 1) + 0));
+  if (k == 0) {  // also row 4 (index 5) of the stripe above
+    S.orr(r - 1, c, (1u << 16) | ((uint32_t)neg << (T1_CHI_SHIFT + 5)));
+    S.orr(r - 1, c - 1, 1u << 17);
+    S.orr(r - 1, c + 1, 1u << 15);
+  } else if (k == 3) {  // also row -1 (index 0) of the stripe below
+    S.orr(r + 1, c, (1u << 1) | ((uint32_t)neg << (T1_CHI_SHIFT + 0)));
+    S.orr(r + 1, c - 1, 1u << 2);
+    S.orr(r + 1, c + 1, 1u << 0);
   }
 }
 // sign coding (T.800 D.3.2, Tables D.2/D.3)
-T1HD void t1_code_sign(T1Lane& t, int fw, uint32_t own, int k, int neg) {
-  uint32_t l = t.flags[(fw - 1) * t.ls], r = t.flags[(fw + 1) * t.ls];
+template <class Store>
+T1HD void t1_code_sign(T1Lane& t, Store& S, int r, int c, uint32_t own, int k, int neg) {
+  uint32_t l = S.ld(r, c - 1), rr = S.ld(r, c + 1);
   int nb = (own >> (3 * k)) & 0x1FF;
   int hc = 0, vc = 0;
   if (nb & (1 << 3)) hc += ((l >> (T1_CHI_SHIFT + k + 1)) & 1) ? -1 : 1;
-  if (nb & (1 << 5)) hc += ((r >> (T1_CHI_SHIFT + k + 1)) & 1) ? -1 : 1;
+  if (nb & (1 << 5)) hc += ((rr >> (T1_CHI_SHIFT + k + 1)) & 1) ? -1 : 1;
   if (nb & (1 << 1)) vc += ((own >> (T1_CHI_SHIFT + k)) & 1) ? -1 : 1;
   if (nb & (1 << 7)) vc += ((own >> (T1_CHI_SHIFT + k + 2)) & 1) ? -1 : 1;
   hc = hc > 1 ? 1 : (hc < -1 ? -1 : hc);
@@ -193,8 +202,9 @@ T1HD long long t1_dist_ref(int m, int p) {
 
 // The whole block.  `top` = highest bit-plane index any lane of the wave codes (uniform loop bound);
 // wmax/hmax = uniform scan bounds (max over the wave).  A lane with nbps == 0 emits nothing.
-T1HD void t1_encode_lane(T1Lane& t, int top, int wmax, int hmax, bool want_dist, T1Result& res) {
-  const int ls = t.ls;
+// Control flow over (bit-plane, pass, stripe, column) is wave-uniform; `on` predicates the lane.
+template <class Store>
+T1HD void t1_encode_lane(T1Lane& t, Store& S, int top, int wmax, int hmax, bool want_dist, T1Result& res) {
   const uint8_t* zc = t.zclut + 512 * (t.orient == 1 ? 1 : (t.orient == 3 ? 2 : 0));
   for (int c = 0; c < 19; c++) t.cx[c * t.cs] = 0;
   t.cx[0 * t.cs] = 4 << 1; t.cx[T1_CTX_RUN * t.cs] = 3 << 1; t.cx[T1_CTX_UNI * t.cs] = 46 << 1;
@@ -204,107 +214,94 @@ T1HD void t1_encode_lane(T1Lane& t, int top, int wmax, int hmax, bool want_dist,
   for (int p = top; p >= 0; p--) {
     const bool active = p < t.nbps;
     const bool first = p == t.nbps - 1;
-    // ---- significance propagation pass (D.3.1) ----
-    if (active && !first) {
+    for (int pass = 0; pass < 3; pass++) {
+      // pass 0: significance propagation (D.3.1), 1: magnitude refinement (D.3.3), 2: clean-up (D.3.4)
+      if (pass < 2 && p == top) continue;  // every lane is at (or above) its first plane: clean-up only
+      const bool lane_pass = active && (pass == 2 || !first);
       long long dist = 0;
-      for (int s = 0; s < nstripes; s++)
+      S.pass_begin(nstripes);
+      for (int s = 0; s < nstripes; s++) {
+        S.stripe_begin(s, nstripes);
+        const int r = s + 1;
         for (int x = 0; x < wmax; x++) {
-          if (x >= t.w || 4 * s >= t.h) continue;
-          int fw = (s + 1) * T1_FW + x + 1;
-          uint32_t f = t.flags[fw * ls];
-          if ((f & T1_SIG_ALL) == 0) continue;
-          uint64_t m = t.mags[(s * 64 + x) * ls];
-          uint32_t f0 = f;
-          for (int k = 0; k < 4 && 4 * s + k < t.h; k++) {
-            int nb = (f >> (3 * k)) & 0x1FF;
-            if ((nb & 0x10) || (nb & 0x1EF) == 0) continue;
-            int mag = t1_mag(m, k), bit = (mag >> p) & 1;
-            mq_encode(t, zc[nb & 0x1EF], bit);
-            if (bit) {
-              int neg = t1_neg(m, k);
-              t1_code_sign(t, fw, f, k, neg);
-              t1_set_sig(t, fw, f, k, neg);
-              if (want_dist) dist += t1_dist_sig(mag, p);
-            }
-            f |= 1u << (T1_PI_SHIFT + k);
-          }
-          if (f != f0) t.flags[fw * ls] = f;
-        }
-      res.pass_len[np] = t.n + 4; if (res.pass_dist) res.pass_dist[np] = dist; np++;
-    }
-    // ---- magnitude refinement pass (D.3.3) ----
-    if (active && !first) {
-      long long dist = 0;
-      for (int s = 0; s < nstripes; s++)
-        for (int x = 0; x < wmax; x++) {
-          if (x >= t.w || 4 * s >= t.h) continue;
-          int fw = (s + 1) * T1_FW + x + 1;
-          uint32_t f = t.flags[fw * ls];
-          uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);  // sigma of rows 0..3
-          uint32_t todo = own & ~(f >> T1_PI_SHIFT) & 0xF;
-          if (!todo) continue;
-          uint64_t m = t.mags[(s * 64 + x) * ls];
-          uint32_t f0 = f;
-          for (int k = 0; k < 4; k++) {
-            if (!((todo >> k) & 1)) continue;
-            int nb = (f >> (3 * k)) & 0x1FF;
-            int cx = ((f >> (T1_MU_SHIFT + k)) & 1) ? 16 : ((nb & 0x1EF) ? 15 : 14);
-            int mag = t1_mag(m, k);
-            mq_encode(t, cx, (mag >> p) & 1);
-            f |= 1u << (T1_MU_SHIFT + k);
-            if (want_dist) dist += t1_dist_ref(mag, p);
-          }
-          if (f != f0) t.flags[fw * ls] = f;
-        }
-      res.pass_len[np] = t.n + 4; if (res.pass_dist) res.pass_dist[np] = dist; np++;
-    }
-    // ---- clean-up pass (D.3.4) ----
-    if (active) {
-      long long dist = 0;
-      for (int s = 0; s < nstripes; s++)
-        for (int x = 0; x < wmax; x++) {
-          if (x >= t.w || 4 * s >= t.h) continue;
-          int fw = (s + 1) * T1_FW + x + 1;
-          uint32_t f = t.flags[fw * ls];
-          uint32_t f0 = f;
-          uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);
-          uint32_t done = (own | (f >> T1_PI_SHIFT)) & 0xF;
-          int rows = t.h - 4 * s; if (rows > 4) rows = 4;
-          if (done != 0xF || rows < 4) {
-            uint64_t m = t.mags[(s * 64 + x) * ls];
-            int k = 0;
-            if (rows == 4 && (f & (T1_SIG_ALL | (0xFu << T1_PI_SHIFT))) == 0) {  // run-length mode
-              int b0 = (t1_mag(m, 0) >> p) & 1, b1 = (t1_mag(m, 1) >> p) & 1, b2 = (t1_mag(m, 2) >> p) & 1, b3 = (t1_mag(m, 3) >> p) & 1;
-              if (!(b0 | b1 | b2 | b3)) { mq_encode(t, T1_CTX_RUN, 0); k = 4; }
-              else {
-                int fk = b0 ? 0 : (b1 ? 1 : (b2 ? 2 : 3));
-                mq_encode(t, T1_CTX_RUN, 1);
-                mq_encode(t, T1_CTX_UNI, fk >> 1);
-                mq_encode(t, T1_CTX_UNI, fk & 1);
-                int neg = t1_neg(m, fk);
-                t1_code_sign(t, fw, f, fk, neg);
-                t1_set_sig(t, fw, f, fk, neg);
-                if (want_dist) dist += t1_dist_sig(t1_mag(m, fk), p);
-                k = fk + 1;
-              }
-            }
-            for (; k < rows; k++) {
+          const bool on = lane_pass && x < t.w && 4 * s < t.h;
+          if (!on) continue;
+          const int c = x + 1;
+          uint32_t f = S.ld(r, c);
+          const uint32_t f0 = f;
+          if (pass == 0) {
+            if ((f & T1_SIG_ALL) == 0) continue;
+            uint64_t m = S.mag(s, x);
+            for (int k = 0; k < 4 && 4 * s + k < t.h; k++) {
               int nb = (f >> (3 * k)) & 0x1FF;
-              if ((nb & 0x10) || ((f >> (T1_PI_SHIFT + k)) & 1)) continue;
+              if ((nb & 0x10) || (nb & 0x1EF) == 0) continue;
               int mag = t1_mag(m, k), bit = (mag >> p) & 1;
               mq_encode(t, zc[nb & 0x1EF], bit);
               if (bit) {
                 int neg = t1_neg(m, k);
-                t1_code_sign(t, fw, f, k, neg);
-                t1_set_sig(t, fw, f, k, neg);
+                t1_code_sign(t, S, r, c, f, k, neg);
+                t1_set_sig(S, r, c, f, k, neg);
                 if (want_dist) dist += t1_dist_sig(mag, p);
               }
+              f |= 1u << (T1_PI_SHIFT + k);
             }
+          } else if (pass == 1) {
+            uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);  // sigma of rows 0..3
+            uint32_t todo = own & ~(f >> T1_PI_SHIFT) & 0xF;
+            if (!todo) continue;
+            uint64_t m = S.mag(s, x);
+            for (int k = 0; k < 4; k++) {
+              if (!((todo >> k) & 1)) continue;
+              int nb = (f >> (3 * k)) & 0x1FF;
+              int cx = ((f >> (T1_MU_SHIFT + k)) & 1) ? 16 : ((nb & 0x1EF) ? 15 : 14);
+              int mag = t1_mag(m, k);
+              mq_encode(t, cx, (mag >> p) & 1);
+              f |= 1u << (T1_MU_SHIFT + k);
+              if (want_dist) dist += t1_dist_ref(mag, p);
+            }
+          } else {
+            uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);
+            uint32_t done = (own | (f >> T1_PI_SHIFT)) & 0xF;
+            int rows = t.h - 4 * s; if (rows > 4) rows = 4;
+            if (done != 0xF || rows < 4) {
+              uint64_t m = S.mag(s, x);
+              int k = 0;
+              if (rows == 4 && (f & (T1_SIG_ALL | (0xFu << T1_PI_SHIFT))) == 0) {  // run-length mode
+                int b0 = (t1_mag(m, 0) >> p) & 1, b1 = (t1_mag(m, 1) >> p) & 1, b2 = (t1_mag(m, 2) >> p) & 1, b3 = (t1_mag(m, 3) >> p) & 1;
+                if (!(b0 | b1 | b2 | b3)) { mq_encode(t, T1_CTX_RUN, 0); k = 4; }
+                else {
+                  int fk = b0 ? 0 : (b1 ? 1 : (b2 ? 2 : 3));
+                  mq_encode(t, T1_CTX_RUN, 1);
+                  mq_encode(t, T1_CTX_UNI, fk >> 1);
+                  mq_encode(t, T1_CTX_UNI, fk & 1);
+                  int neg = t1_neg(m, fk);
+                  t1_code_sign(t, S, r, c, f, fk, neg);
+                  t1_set_sig(S, r, c, f, fk, neg);
+                  if (want_dist) dist += t1_dist_sig(t1_mag(m, fk), p);
+                  k = fk + 1;
+                }
+              }
+              for (; k < rows; k++) {
+                int nb = (f >> (3 * k)) & 0x1FF;
+                if ((nb & 0x10) || ((f >> (T1_PI_SHIFT + k)) & 1)) continue;
+                int mag = t1_mag(m, k), bit = (mag >> p) & 1;
+                mq_encode(t, zc[nb & 0x1EF], bit);
+                if (bit) {
+                  int neg = t1_neg(m, k);
+                  t1_code_sign(t, S, r, c, f, k, neg);
+                  t1_set_sig(S, r, c, f, k, neg);
+                  if (want_dist) dist += t1_dist_sig(mag, p);
+                }
+              }
+            }
+            f &= ~(0xFu << T1_PI_SHIFT);  // the "visited" marks last one bit-plane
           }
-          f &= ~(0xFu << T1_PI_SHIFT);  // the "visited" marks last one bit-plane
-          if (f != f0) t.flags[fw * ls] = f;
+          if (f != f0) S.st(r, c, f);
         }
-      res.pass_len[np] = t.n + 4; if (res.pass_dist) res.pass_dist[np] = dist; np++;
+        S.stripe_end(s);
+      }
+      S.pass_end(nstripes);
+      if (lane_pass) { res.pass_len[np] = t.n + 4; if (res.pass_dist) res.pass_dist[np] = dist; np++; }
     }
   }
   res.npasses = np;
@@ -315,5 +312,20 @@ T1HD void t1_encode_lane(T1Lane& t, int top, int wmax, int hmax, bool want_dist,
   for (int i = 0; i < np; i++) if (res.pass_len[i] > res.len) res.pass_len[i] = res.len;
   if (np) res.pass_len[np - 1] = res.len;
 }
+
+// Host/array store: lane stride ls (1 on the host harness).
+struct T1ArrayStore {
+  uint32_t* flags;       // word (r, c) at flags[(r*T1_FW + c)*ls]
+  const uint64_t* mags;  // word (s, x) at mags[(s*64 + x)*ls]
+  int ls;
+  T1HD_M uint32_t ld(int r, int c) const { return flags[(r * T1_FW + c) * ls]; }
+  T1HD_M void st(int r, int c, uint32_t v) { flags[(r * T1_FW + c) * ls] = v; }
+  T1HD_M void orr(int r, int c, uint32_t b) { flags[(r * T1_FW + c) * ls] |= b; }
+  T1HD_M uint64_t mag(int s, int x) const { return mags[(s * 64 + x) * ls]; }
+  T1HD_M void pass_begin(int) {}
+  T1HD_M void stripe_begin(int, int) {}
+  T1HD_M void stripe_end(int) {}
+  T1HD_M void pass_end(int) {}
+};
 
 }  // namespace qsvc

@@ -22,7 +22,7 @@ SYMBOLS = [
     "qsvc_get_frame_types", "qsvc_get_histograms", "qsvc_motion_estimate", "qsvc_decorrelate", "qsvc_update",
     "qsvc_analyze_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_dwt53_trunc",
-    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_plane", "qsvc_j2k_dwt", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_dwt", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
 ]
 
 
@@ -75,6 +75,8 @@ def load_library() -> C.CDLL:
     L.qsvc_halo_exchange.argtypes = [vp, i]
     L.qsvc_dwt53_trunc.argtypes = [vp, i16p, i, i, i, i, i]
     L.qsvc_j2k_encode_frames.argtypes = [vp, i, i, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.qsvc_j2k_encode_multi.argtypes = [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_encode_plane.argtypes = [vp, u8p, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_dwt.argtypes = [vp, u8p, i, i, i, i, vp]
     L.qsvc_j2k_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -222,6 +224,30 @@ class Engine:
         self._chk(self.L.qsvc_j2k_encode_frames(self.h, kind, t, first, count, C.byref(params), out.ctypes.data, cap, offs))
         o = list(offs)
         return [out[o[k]:o[k + 1]].tobytes() for k in range(3 * count)]
+
+    def j2k_encode_multi(self, items):
+        """items: [(kind, t, first, count, J2kParams)] -> list (per item) of lists of code-streams, one batch on the GPU."""
+        items = [it for it in items if it[3] > 0]
+        n = len(items)
+        if n == 0:
+            return []
+        IA = C.c_int * n
+        kinds, ts = IA(*[it[0] for it in items]), IA(*[it[1] for it in items])
+        firsts, counts = IA(*[it[2] for it in items]), IA(*[it[3] for it in items])
+        prms = (J2kParams * n)(*[it[4] for it in items])
+        total = sum(it[3] for it in items)
+        cap = total * self.F * 2 + (1 << 20)
+        if getattr(self, "_j2k_out", None) is None or self._j2k_out.size < cap:
+            self._j2k_out = np.empty(cap, dtype=np.uint8)
+        out = self._j2k_out
+        offs = (C.c_size_t * (3 * total + 1))()
+        self._chk(self.L.qsvc_j2k_encode_multi(self.h, n, kinds, ts, firsts, counts, prms, out.ctypes.data, out.size, offs))
+        o = list(offs)
+        res, k = [], 0
+        for it in items:
+            res.append([out[o[k + j]:o[k + j + 1]].tobytes() for j in range(3 * it[3])])
+            k += 3 * it[3]
+        return res
 
     def j2k_encode_plane(self, plane: np.ndarray, params: J2kParams) -> bytes:
         p = np.ascontiguousarray(plane, dtype=np.uint8)

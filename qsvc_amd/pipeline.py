@@ -84,10 +84,9 @@ class Compressor:
 
     def texture(self, low_first=0):
         """-> {(kind, t): [code-stream bytes per (picture, component)]}"""
-        out = {}
-        for (kind, t, first, count, prm) in self.texture_items(low_first):
-            out[(kind, t)] = self.e.j2k_encode_frames(kind, t, first, count, prm) if count > 0 else []
-        return out
+        items = [it for it in self.texture_items(low_first) if it[3] > 0]
+        streams = self.e.j2k_encode_multi(items)  # one batch: every subband picture of the sequence
+        return {(it[0], it[1]): s for it, s in zip(items, streams)}
 
     def compress(self):
         if self.p.TRLs > 1:

@@ -160,12 +160,13 @@ extern "C" int emul_t1_block(const int32_t* vals, int w, int h, int orient, uint
   uint8_t cx[19];
   std::vector<uint8_t> buf((size_t)w * h * 4 + 64);
   T1Lane t;
-  t.flags = flags.data(); t.mags = mags.data(); t.cx = cx; t.mqtab = mqtab; t.zclut = zclut; t.out = buf.data();
-  t.ls = 1; t.cs = 1; t.cap = (int)buf.size(); t.w = w; t.h = h; t.orient = orient; t.nbps = nb;
+  t.cx = cx; t.mqtab = mqtab; t.zclut = zclut; t.out = buf.data();
+  t.cs = 1; t.cap = (int)buf.size(); t.w = w; t.h = h; t.orient = orient; t.nbps = nb;
+  T1ArrayStore S{flags.data(), mags.data(), 1};
   T1Result r;
   int pl[T1_MAXPASS]; long long pd[T1_MAXPASS];
   r.pass_len = pl; r.pass_dist = pd;
-  t1_encode_lane(t, nb - 1, w, h, true, r);
+  t1_encode_lane(t, S, nb - 1, w, h, true, r);
   if (r.overflow) return -2;
   memcpy(out, buf.data() + 1, r.len);
   *npasses = r.npasses; *nbps = r.nbps;

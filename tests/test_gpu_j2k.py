@@ -95,3 +95,22 @@ def test_frames_1080p_lossless(eng):
             np.testing.assert_array_equal(J.decode(streams[3 * i + k]), pl)
     assert streams[0] == J.encode_plane(clip[0][:W * H].reshape(H, W), reversible=True, levels=4)
     assert streams[4] == J.encode_plane(clip[1][W * H:W * H + (W // 2) * (H // 2)].reshape(H // 2, W // 2), reversible=True, levels=4)
+
+
+def test_multi_sequence_batch_equals_single_calls(eng):
+    """One batched launch set for all temporal subbands == the per-sequence calls (texture_compress.py:183-217)."""
+    from qsvc_amd import hip
+    W, H, bs = 192, 128, 16
+    clip = make_clip("pan_noise", 9, W, H, 5)
+    eng.seq_config(W, H)
+    eng.put_frames(hip.LOW, 0, clip)
+    eng.analyze_step(1, 9, bs, 4)
+    eng.analyze_step(2, 5, bs, 8)
+    items = [(hip.HIGH, 1, 0, 4, hip.j2k_params(reversible=False, levels=3, layers=3, slopes=(47500, 46500, 45500))),
+             (hip.HIGH, 2, 0, 2, hip.j2k_params(reversible=False, levels=3, layers=3, slopes=(47300, 46300, 45300))),
+             (hip.LOW, 2, 1, 2, hip.j2k_params(reversible=False, levels=3, layers=2, slopes=(46000, 45000)))]
+    multi = eng.j2k_encode_multi(items)
+    for it, got in zip(items, multi):
+        assert got == eng.j2k_encode_frames(*it)
+    hi = eng.get_frames(hip.HIGH, 2, 1, 1)[0]
+    assert multi[1][3] == J.encode_plane(hi[:W * H].reshape(H, W), reversible=False, levels=3, layers=3, slopes=(47300, 46300, 45300))

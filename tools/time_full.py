@@ -1,32 +1,29 @@
-import sys, time, numpy as np
+import sys, time, os, numpy as np
 sys.path.insert(0, '.')
 from qsvc_amd import hip
+from qsvc_amd.pipeline import CompressParams, Compressor
 from qsvc_amd.synth import make_clip
-W,H,bs=1920,1080,8
-P=17
+W,H=1920,1080
 kind = sys.argv[1] if len(sys.argv)>1 else "pan_noise"
-rev = (sys.argv[2] != "97") if len(sys.argv)>2 else True
-clip = make_clip(kind, P, W, H, 43)
+mode = sys.argv[2] if len(sys.argv)>2 else "53"
+gops = int(sys.argv[3]) if len(sys.argv)>3 else 2
 e = hip.Engine(0)
-e.seq_config(W,H)
-e.put_frames(hip.LOW,0,clip)
-prm = hip.j2k_params(reversible=rev, levels=4)
+prm = CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=4, GOPs=gops, block_size=8, block_size_min=8, search_range=4, SRLs=5,
+                     lossless=(mode=="53"), reversible=False)
+comp = Compressor(e, prm)
+clip = make_clip(kind, comp.pictures, W, H, 43)
+comp.configure(); comp.load(clip)
 def run():
-    p, S = P, 4
-    sizes=0
-    for t in range(1,4):
-        e.analyze_step(t,p,bs,S)
-        nB=p//2
-        cs = e.j2k_encode_frames(hip.HIGH,t,0,nB,prm); sizes+=sum(map(len,cs))
-        p=(p+1)//2; S*=2
-    cs = e.j2k_encode_frames(hip.LOW,3,0,p,prm); sizes+=sum(map(len,cs))
-    return sizes
+    comp.analyze()
+    out = comp.texture()
+    return sum(len(c) for v in out.values() for c in v)
 sz=run(); e.sync()
 e.set_profiling(True)
 N=3
 t0=time.time()
 for _ in range(N): run()
 e.sync(); dt=(time.time()-t0)/N
-print(f"{kind} rev={rev}: full encode 17 frames: {dt*1e3:.1f} ms -> {16/dt:.1f} fps; bytes {sz} ({sz*8/(17*W*H):.2f} bpp)")
+P=comp.pictures
+print(f"LANES={os.environ.get('QSVC_T1_LANES','64')} {kind} mode={mode} pictures={P}: {dt*1e3:.1f} ms -> {P/dt:.1f} fps; bytes {sz} ({sz*8/(P*W*H):.2f} bpp)")
 for k,(ms,n) in e.timings().items(): print(f"  {k:20s} {ms/N:8.3f} ms/iter  ({n//N} launches/iter)")
-print(e.j2k_stats())
+print(" ", e.j2k_stats())
