@@ -1,0 +1,5 @@
+"""`mctf texture_compress` entry point -- see qsvc_amd/cli/drivers.py."""
+from .drivers import texture_compress as main
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,25 @@ def main():
     np.savez_compressed(os.path.join(HERE, "dwt_kat.npz"), **kat)
     print("dwt_kat", len(kat))
 
+    # header_size (trunk/src/header_size.c compiled into oracle/_ref) on deterministic marker streams
+    import json, subprocess, tempfile
+    hs = []
+    rng = np.random.default_rng(11)
+    for case in range(8):
+        body = bytearray(b"\xff\x4f" + bytes(rng.integers(0, 255, size=int(rng.integers(20, 90)), dtype=np.uint8)))
+        for k in range(int(rng.integers(1, 7))):
+            body += b"\xff\x91\x00\x04" + bytes([0, k])
+            n = int(rng.choice([1, 1, 5, 40]))
+            body += bytes(rng.integers(0, 255, size=n, dtype=np.uint8))
+        body += b"\xff\xd9"
+        with tempfile.NamedTemporaryFile(suffix=".j2c", delete=False) as f:
+            f.write(bytes(body))
+        out = subprocess.run([os.path.join(O.REF_DIR, "header_size"), f.name], capture_output=True, text=True).stdout
+        os.unlink(f.name)
+        hs.append({"hex": bytes(body).hex(), "out": int([l for l in out.splitlines() if l.startswith("OUT")][0][4:])})
+    json.dump(hs, open(os.path.join(HERE, "header_size.json"), "w"))
+    print("header_size", [h["out"] for h in hs])
+
 
 if __name__ == "__main__":
     main()

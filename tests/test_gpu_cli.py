@@ -1,0 +1,79 @@
+"""GPU: the drop-in executables (bin/mctf <tool>) in a scratch directory against the oracle's files."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from qsvc_amd.synth import make_clip
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MCTF = os.path.join(ROOT, "bin", "mctf")
+J = pytest.importorskip("oracle.j2k")
+
+
+def run(cwd, *args):
+    r = subprocess.run([MCTF] + [str(a) for a in args], cwd=cwd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def rd(d, name, dtype=np.uint8):
+    return np.fromfile(os.path.join(d, name), dtype=dtype)
+
+
+def test_stage_tools_chain_like_analyze_step(oracle, tmp_path):
+    W, H, bs, S, P = 128, 96, 16, 4, 5
+    clip = make_clip("pan_noise", P, W, H, 3)
+    clip.tofile(tmp_path / "low_0")
+    geo = [f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--pictures={P}"]
+    run(tmp_path, "split", "--even_fn=even_1", "--low_fn=low_0", "--odd_fn=odd_1", *geo)
+    run(tmp_path, "motion_estimate", f"--block_size={bs}", "--even_fn=even_1", "--motion_fn=motion_1", "--odd_fn=odd_1",
+        f"--search_range={S}", *geo)
+    run(tmp_path, "decorrelate", f"--block_size={bs}", "--even_fn=even_1", "--frame_types_fn=frame_types_1", "--high_fn=high_1",
+        "--motion_in_fn=motion_1", "--motion_out_fn=motion_filtered_1", "--odd_fn=odd_1", f"--search_range={S}", *geo)
+    run(tmp_path, "update", f"--block_size={bs}", "--even_fn=even_1", "--frame_types_fn=frame_types_1", "--high_fn=high_1",
+        "--low_fn=low_1", "--motion_fn=motion_filtered_1", "--update_factor=0.25", *geo)
+    want = oracle.analyze_step(clip, W, H, bs, S, want_prediction=True)
+    np.testing.assert_array_equal(rd(tmp_path, "motion_1", np.int16), want["motion"].reshape(-1))
+    np.testing.assert_array_equal(rd(tmp_path, "motion_filtered_1", np.int16), want["motion_filtered"].reshape(-1))
+    assert rd(tmp_path, "frame_types_1").tobytes() == want["frame_types"]
+    np.testing.assert_array_equal(rd(tmp_path, "high_1"), want["high"].reshape(-1))
+    np.testing.assert_array_equal(rd(tmp_path, "low_1"), want["low"].reshape(-1))
+    np.testing.assert_array_equal(rd(tmp_path, "prediction_even_1"), want["prediction"].reshape(-1))
+    assert "mctf update" in open(tmp_path / "trace").read()
+
+
+def test_compress_writes_the_reference_file_layout(oracle, tmp_path):
+    W, H, TRLs, GOPs, bs = 128, 96, 3, 1, 16
+    P = GOPs * 2 ** (TRLs - 1) + 1
+    clip = make_clip("pan_noise", P, W, H, 4)
+    clip.tofile(tmp_path / "low_0")
+    run(tmp_path, "compress", f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", f"--GOPs={GOPs}",
+        f"--block_size={bs}", f"--block_size_min={bs}", "--SRLs=4", "--nLayers=3", "--lossless=1")
+    want = oracle.analyze(clip, W, H, TRLs, bs, 4)
+    for t, lv in enumerate(want, 1):
+        assert rd(tmp_path, f"frame_types_{t}").tobytes() == lv["frame_types"]
+        np.testing.assert_array_equal(rd(tmp_path, f"high_{t}"), lv["high"].reshape(-1))
+        np.testing.assert_array_equal(rd(tmp_path, f"low_{t}"), lv["low"].reshape(-1))
+        np.testing.assert_array_equal(rd(tmp_path, f"motion_filtered_{t}", np.int16), lv["motion_filtered"].reshape(-1))
+    assert open(tmp_path / "slopes").read().splitlines()[0] == "[45000, 47000, 49000]"
+    # every <sub>_{Y,U,V}_NNNN.j2c decodes (independent decoder) to the subband picture; index file has one line per picture
+    F = W * H * 3 // 2
+    for name, pics in (("high_1", want[0]["high"]), ("high_2", want[1]["high"]), ("low_2", want[1]["low"])):
+        assert len(open(tmp_path / f"{name}.j2c").read().split()) == len(pics)
+        for i, f in enumerate(pics):
+            planes = (f[:W * H].reshape(H, W), f[W * H:W * H + W * H // 4].reshape(H // 2, W // 2), f[W * H + W * H // 4:].reshape(H // 2, W // 2))
+            for comp, pl in zip("YUV", planes):
+                cs = open(tmp_path / f"{name}_{comp}_{i:04d}.j2c", "rb").read()
+                np.testing.assert_array_equal(J.decode(cs), pl)
+
+
+def test_unsupported_requests_exit_nonzero(tmp_path):
+    make_clip("pan", 5, 64, 64, 1).tofile(tmp_path / "low_0")
+    r = subprocess.run([MCTF, "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=3", "--block_overlaping=2"],
+                       cwd=tmp_path, capture_output=True)
+    assert r.returncode != 0
+    r = subprocess.run([MCTF, "transcode"], cwd=tmp_path, capture_output=True)
+    assert r.returncode != 0

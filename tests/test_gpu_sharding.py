@@ -1,0 +1,40 @@
+"""GPU: two rank processes (both on GPU 0, gloo host-staged halo exchange) == one process over the whole sequence."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_gpu_shards_equal_single_process(tmp_path):
+    from qsvc_amd import hip
+    from qsvc_amd.pipeline import CompressParams, Compressor
+    from qsvc_amd.synth import make_clip
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "shard_check.py"), str(tmp_path)], env=dict(env, RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    W, H = 192, 128
+    clip = make_clip("pan_noise", 17, W, H, 21)
+    e = hip.Engine(0)
+    try:
+        prm = CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=4, GOPs=2, block_size=16, block_size_min=16, search_range=4, SRLs=4, lossless=True)
+        comp = Compressor(e, prm)
+        comp.configure(); comp.load(clip)
+        comp.analyze()
+        out = comp.texture()
+        low3, high1, high3 = e.get_frames(hip.LOW, 3, 0, 3), e.get_frames(hip.HIGH, 1, 0, 8), e.get_frames(hip.HIGH, 3, 0, 2)
+    finally:
+        e.close()
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["low3"][-1], r1["low3"][0])
+    np.testing.assert_array_equal(np.concatenate([r0["low3"], r1["low3"][1:]]), low3)
+    np.testing.assert_array_equal(np.concatenate([r0["high1"], r1["high1"]]), high1)
+    np.testing.assert_array_equal(np.concatenate([r0["high3"], r1["high3"]]), high3)
+    assert r0["low_stream0"].tobytes() == out[(hip.LOW, 3)][0]
+    assert r1["low_stream0"].tobytes() == out[(hip.LOW, 3)][2 * 3]   # rank 1 starts at its second low picture
