@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -192,6 +193,8 @@ struct HostCb {  // host view of one coded block
 
 struct J2kState {
   DevBuf coefA, coefB, planes_d, cbs_d, nbps_d, mags, flags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
+  DevBuf waves_d, joboff_d, segs_d, cnt_d, dist_d;  // split Tier-1
+  std::vector<int> h_nbps, h_joboff, h_waves;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
   std::vector<PlaneDesc> planes;
   std::vector<CbDesc> cbs;
@@ -206,7 +209,7 @@ void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->coefB, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->flags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d};
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->waves_d, &s->joboff_d, &s->segs_d, &s->cnt_d, &s->dist_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   delete s;
@@ -364,7 +367,11 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
           d.orient = (short)s.orient; d.Mb = (short)s.Mb; d.delta = s.delta;
         }
   }
-  static const int lanes = [] { const char* e = getenv("QSVC_T1_LANES"); int v = e ? atoi(e) : 8; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 8; }();
+  // Tier-1 form: "split" (default) = bit-plane-parallel context modelling + MQ kernel; "fused" = one kernel,
+  // `lanes` code-blocks per wave through an LDS window.
+  static const bool split = [] { const char* e = getenv("QSVC_T1_MODE"); return !(e && !strcmp(e, "fused")); }();
+  static const int lanes_env = [] { const char* e = getenv("QSVC_T1_LANES"); int v = e ? atoi(e) : 8; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 8; }();
+  const int lanes = split ? 64 : lanes_env;
   const int ngroups = (ncb + lanes - 1) / lanes;
   const bool want_dist = any_dist;
   int r;
@@ -374,7 +381,6 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
   if ((r = S.cbs_d.ensure(c, (size_t)ncb * sizeof(CbDesc)))) return r;
   if ((r = S.nbps_d.ensure(c, (size_t)ncb * 4))) return r;
   if ((r = S.mags.ensure(c, (size_t)ngroups * lanes * T1_MAGS_WORDS * 4))) return r;
-  if ((r = S.flags.ensure(c, (size_t)ngroups * lanes * T1_FLAGS_WORDS * 4))) return r;
   if ((r = S.outbuf.ensure(c, (size_t)ncb * J2K_OUTCAP))) return r;
   if ((r = S.res_d.ensure(c, (size_t)ncb * sizeof(CbOut)))) return r;
   if ((r = S.plen_d.ensure(c, (size_t)ncb * T1_MAXPASS * 4))) return r;
@@ -390,15 +396,53 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
   launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, S.coefA.p, S.coefB.p, maxL, rev);
   pf.end(c);
   pf.begin(c, "j2k_t1_pack");
-  HIPCHK(c, hipMemsetAsync(S.flags.p, 0, (size_t)ngroups * lanes * T1_FLAGS_WORDS * 4, c->st));
   launch_t1_pack(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (uint32_t*)S.mags.p, (int*)S.nbps_d.p,
                  (int*)S.err_d.p, rev, lanes);
   pf.end(c);
-  pf.begin(c, "j2k_t1_encode");
-  launch_t1_encode(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const uint32_t*)S.mags.p, (uint32_t*)S.flags.p,
-                   (uint8_t*)S.outbuf.p, J2K_OUTCAP, (CbOut*)S.res_d.p, (int*)S.plen_d.p, want_dist ? (long long*)S.pdist_d.p : nullptr,
-                   want_dist ? 1 : 0, lanes);
-  pf.end(c);
+  if (!split) {
+    if ((r = S.flags.ensure(c, (size_t)ngroups * lanes * T1_FLAGS_WORDS * 4))) return r;
+    pf.begin(c, "j2k_t1_encode");
+    HIPCHK(c, hipMemsetAsync(S.flags.p, 0, (size_t)ngroups * lanes * T1_FLAGS_WORDS * 4, c->st));
+    launch_t1_encode(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const uint32_t*)S.mags.p, (uint32_t*)S.flags.p,
+                     (uint8_t*)S.outbuf.p, J2K_OUTCAP, (CbOut*)S.res_d.p, (int*)S.plen_d.p, want_dist ? (long long*)S.pdist_d.p : nullptr,
+                     want_dist ? 1 : 0, lanes);
+    pf.end(c);
+  } else {
+    // the per-block bit-plane counts decide the job list: one (group, plane) wave per plane any block of the group has
+    S.h_nbps.resize(ncb);
+    HIPCHK(c, hipMemcpyAsync(S.h_nbps.data(), S.nbps_d.p, (size_t)ncb * 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    S.h_joboff.resize(ncb);
+    S.h_waves.clear();
+    size_t njobs = 0;
+    for (int g = 0; g < ngroups; g++) {
+      int mx = 0;
+      for (int b = g * 64; b < std::min(ncb, g * 64 + 64); b++) {
+        int nb = S.h_nbps[b] > 15 ? 15 : S.h_nbps[b];  // > 15 is reported through err_d below
+        S.h_joboff[b] = (int)njobs; njobs += nb; mx = std::max(mx, nb);
+      }
+      for (int p = 0; p < mx; p++) S.h_waves.push_back((g << 8) | p);
+    }
+    const int nwaves = (int)S.h_waves.size();
+    if (nwaves) {
+      if ((r = S.waves_d.ensure(c, (size_t)nwaves * 4))) return r;
+      if ((r = S.joboff_d.ensure(c, (size_t)ncb * 4))) return r;
+      if ((r = S.flags.ensure(c, (size_t)nwaves * T1_FLAGS_WORDS * 64 * 4))) return r;
+      if ((r = S.segs_d.ensure(c, (njobs ? njobs : 1) * (size_t)T1_SEG_BYTES))) return r;
+      if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
+      if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
+      HIPCHK(c, hipMemcpyAsync(S.waves_d.p, S.h_waves.data(), (size_t)nwaves * 4, hipMemcpyHostToDevice, c->st));
+      HIPCHK(c, hipMemcpyAsync(S.joboff_d.p, S.h_joboff.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
+    }
+    for (int stage = 0; stage < 3; stage++) {
+      if (!nwaves && stage < 2) continue;
+      pf.begin(c, stage == 0 ? "j2k_t1_flags" : (stage == 1 ? "j2k_t1_cm" : "j2k_t1_mq"));
+      launch_t1_split(c->st, (const int*)S.waves_d.p, nwaves, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p,
+                      (const uint32_t*)S.mags.p, (uint32_t*)S.flags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p,
+                      (uint8_t*)S.outbuf.p, J2K_OUTCAP, (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, stage);
+      pf.end(c);
+    }
+  }
   S.res.resize(ncb);
   int err = 0;
   HIPCHK(c, hipMemcpyAsync(S.res.data(), S.res_d.p, (size_t)ncb * sizeof(CbOut), hipMemcpyDeviceToHost, c->st));

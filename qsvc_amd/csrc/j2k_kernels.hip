@@ -7,6 +7,7 @@
 //   * gather of the code-block segments into one contiguous buffer for the host's Tier-2.
 // No MFMA: integer/bit work and short float lifting chains.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "j2k_kernels.h"
 
 namespace qsvc {
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(LANES) k_t1_encode(const CbDesc* cbs, int ncb,
   uint32_t* s_M = s_F + 4 * T1_FW * LANES;                   // 2*128*LANES words
   uint32_t* s_mq = s_M + 2 * 128 * LANES;                    // 47 (padded to 64)
   uint8_t* s_zc = (uint8_t*)(s_mq + 64);                     // 3*512
-  uint8_t* s_cx = s_zc + 3 * 512;                            // 19*LANES
+  uint32_t* s_cx = (uint32_t*)(s_zc + 3 * 512);              // 19*LANES words
   int lane = threadIdx.x, g = blockIdx.x, b = g * LANES + lane;
   for (int i = lane; i < 47; i += LANES) s_mq[i] = c_mqtab[i];
   for (int i = lane; i < 3 * 512; i += LANES) {
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(LANES) k_t1_encode(const CbDesc* cbs, int ncb,
 template <int LANES>
 static void launch_t1_encode_n(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint32_t* mags, uint32_t* flags,
                                uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist) {
-  const int smem = ((4 * T1_FW + 2 * 128) * LANES + 64) * 4 + 3 * 512 + 19 * LANES;
+  const int smem = ((4 * T1_FW + 2 * 128) * LANES + 64) * 4 + 3 * 512 + 19 * LANES * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_t1_encode<LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -316,6 +317,161 @@ void launch_t1_encode(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbp
     case 16: launch_t1_encode_n<16>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
     case 32: launch_t1_encode_n<32>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
     default: launch_t1_encode_n<64>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split Tier-1: bit-plane-parallel context modelling + MQ kernel (t1_core.h "Split form").
+// A CM wave = (group of 64 code-blocks, bit-plane p): its 64 lanes model plane p of 64 different blocks.
+// The start-of-plane flag words are a pure function of the magnitudes, produced by k_t1_flags_init
+// (thread per flag word), so all ~10 planes of all blocks run concurrently: ~10x the waves of the fused
+// kernel, each with 1/10 of its serial chain.  Decisions (cx | d<<5, one byte) go to per-(block, plane, pass)
+// segments; k_t1_mq runs the MQ coder of each block over its segments, 16 blocks per wave.
+struct T1GlobalStore {  // flag words and magnitudes straight from HBM/L2, lane stride 64
+  uint32_t* flags;
+  const uint32_t* mags;
+  __device__ __forceinline__ uint32_t ld(int r, int c) const { return flags[(r * T1_FW + c) * 64]; }
+  __device__ __forceinline__ void st(int r, int c, uint32_t v) { flags[(r * T1_FW + c) * 64] = v; }
+  __device__ __forceinline__ void orr(int r, int c, uint32_t b) { flags[(r * T1_FW + c) * 64] |= b; }
+  __device__ __forceinline__ uint64_t mag(int s, int x) const {
+    const uint32_t* m = mags + (size_t)((s * 64 + x) * 2) * 64;
+    return (uint64_t)m[0] | ((uint64_t)m[64] << 32);
+  }
+  __device__ __forceinline__ void pass_begin(int) {}
+  __device__ __forceinline__ void stripe_begin(int, int) {}
+  __device__ __forceinline__ void stripe_end(int) {}
+  __device__ __forceinline__ void pass_end(int) {}
+};
+
+// waves[k] = group << 8 | plane.  One thread per (flag word, lane) of a CM wave.
+__global__ void __launch_bounds__(256) k_t1_flags_init(const int* waves, const CbDesc* cbs, int ncb, const int* nbps_in,
+                                                        const uint32_t* mags, uint32_t* flags) {
+  int wv = blockIdx.y, g = waves[wv] >> 8, p = waves[wv] & 255;
+  int idx = blockIdx.x * 256 + threadIdx.x;  // word*64 + lane
+  if (idx >= T1_FLAGS_WORDS * 64) return;
+  int lane = idx & 63, word = idx >> 6, r = word / T1_FW, c = word % T1_FW;
+  int b = g * 64 + lane;
+  uint32_t f = 0;
+  if (b < ncb && r >= 1 && r <= 16 && c >= 1 && c <= 64 && p < nbps_in[b]) {
+    CbDesc cb = cbs[b];
+    int s = r - 1, x = c - 1, nstr = (cb.h + 3) >> 2;
+    if (x < cb.w && s < nstr) {
+      const uint32_t* mg = mags + (size_t)g * T1_MAGS_WORDS * 64 + lane;
+      auto M = [&](int ss, int xx) {
+        const uint32_t* m = mg + (size_t)((ss * 64 + xx) * 2) * 64;
+        return (uint64_t)m[0] | ((uint64_t)m[64] << 32);
+      };
+      f = t1_initial_flag(M, s, x, p, nstr, cb.w);
+    }
+  }
+  flags[(size_t)wv * T1_FLAGS_WORDS * 64 + idx] = f;
+}
+
+__global__ void __launch_bounds__(64) k_t1_cm(const int* waves, const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
+                                               const uint32_t* mags, uint32_t* flags, uint8_t* segs, int* cnt, long long* dist,
+                                               int want_dist) {
+  __shared__ uint8_t s_zc[3 * 512];
+  int wv = blockIdx.x, g = waves[wv] >> 8, p = waves[wv] & 255;
+  int lane = threadIdx.x, b = g * 64 + lane;
+  for (int i = lane; i < 3 * 512; i += 64) {
+    int c = i >> 9;
+    s_zc[i] = (uint8_t)t1_zc_from_nb(i & 511, c == 0 ? 0 : (c == 1 ? 1 : 3));
+  }
+  __syncthreads();
+  int w = 0, h = 0, orient = 0, nb = 0;
+  if (b < ncb) { CbDesc cb = cbs[b]; w = cb.w; h = cb.h; orient = cb.orient; nb = nbps_in[b]; }
+  const bool mine = p < nb;
+  int wmax = mine ? w : 0, hmax = mine ? h : 0;
+  for (int o = 32; o >= 1; o >>= 1) {
+    int a = __shfl_xor(wmax, o, 64), d = __shfl_xor(hmax, o, 64);
+    wmax = a > wmax ? a : wmax; hmax = d > hmax ? d : hmax;
+  }
+  wmax = __builtin_amdgcn_readfirstlane(wmax); hmax = __builtin_amdgcn_readfirstlane(hmax);
+  T1GlobalStore S;
+  S.flags = flags + (size_t)wv * T1_FLAGS_WORDS * 64 + lane;
+  S.mags = mags + (size_t)g * T1_MAGS_WORDS * 64 + lane;
+  size_t job = mine ? (size_t)joboff[b] + p : 0;
+  int c3[3]; long long d3[3];
+  t1_cm_plane(S, s_zc, segs + job * T1_SEG_BYTES, p, w, h, orient, mine ? nb : 0, wmax, hmax, want_dist != 0, c3, d3);
+  if (mine) {
+    for (int k = 0; k < 3; k++) { cnt[job * 3 + k] = c3[k]; if (want_dist) dist[job * 3 + k] = d3[k]; }
+  }
+}
+
+template <int T1_MQ_LANES>
+__global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
+                                                        const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf,
+                                                        int outcap, CbOut* res, int* pass_len, long long* pass_dist) {
+  __shared__ uint32_t s_cx[19 * T1_MQ_LANES];
+  __shared__ uint32_t s_mq[64];
+  int lane = threadIdx.x, b = blockIdx.x * T1_MQ_LANES + lane;
+  for (int i = lane; i < 47; i += T1_MQ_LANES) s_mq[i] = c_mqtab[i];
+  __syncthreads();
+  T1Lane t;
+  t.cx = s_cx + lane; t.cs = T1_MQ_LANES; t.mqtab = s_mq; t.zclut = nullptr;
+  t.w = t.h = t.orient = 0; t.nbps = 0; t.out = outbuf; t.cap = 0;
+  size_t job0 = 0;
+  if (b < ncb) { t.nbps = nbps_in[b]; t.out = outbuf + (size_t)b * outcap; t.cap = outcap; job0 = (size_t)joboff[b]; }
+  int top = t.nbps - 1;
+  for (int o = T1_MQ_LANES / 2; o >= 1; o >>= 1) { int a = __shfl_xor(top, o, 64); top = a > top ? a : top; }
+  top = __builtin_amdgcn_readfirstlane(top);
+  int bb = b < ncb ? b : 0;
+  int* pl = pass_len + (size_t)bb * T1_MAXPASS;
+  long long* pd = pass_dist ? pass_dist + (size_t)bb * T1_MAXPASS : nullptr;
+  t1_lane_init(t);
+  int np = 0;
+  for (int p = top; p >= 0; p--) {
+    const bool active = p < t.nbps, first = p == t.nbps - 1;
+    const size_t job = job0 + (active ? p : 0);
+    for (int pass = 0; pass < 3; pass++) {
+      if (pass < 2 && p == top) continue;
+      const bool lane_pass = active && (pass == 2 || !first);
+      const int n = lane_pass ? cnt[job * 3 + pass] : 0;
+      int nmax = n;
+      for (int o = T1_MQ_LANES / 2; o >= 1; o >>= 1) { int a = __shfl_xor(nmax, o, 64); nmax = a > nmax ? a : nmax; }
+      nmax = __builtin_amdgcn_readfirstlane(nmax);
+      const uint4* sg = (const uint4*)(segs + job * T1_SEG_BYTES + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2)));
+      uint4 cur = make_uint4(0, 0, 0, 0);
+      if (n > 0) cur = sg[0];
+      for (int i = 0; i < nmax; i += 16) {
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (i + 16 < n) nxt = sg[(i >> 4) + 1];  // next 16 decisions in flight while these are coded
+        uint32_t wds[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          if (i + j < n) {
+            int v = (wds[j >> 2] >> (8 * (j & 3))) & 0xFF;
+            mq_encode(t, v & 31, v >> 5);
+          }
+        }
+        cur = nxt;
+      }
+      if (lane_pass) { pl[np] = t.n + 4; if (pd) pd[np] = dist[job * 3 + pass]; np++; }
+    }
+  }
+  T1Result r;
+  r.pass_len = pl; r.pass_dist = pd;
+  t1_lane_finish(t, np, r);
+  if (b < ncb) {
+    CbOut o;
+    o.len = r.len; o.npasses = r.npasses; o.nbps = r.nbps; o.overflow = r.overflow; o.nsym = r.nsym;
+    res[b] = o;
+  }
+}
+
+void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff,
+                     const uint32_t* mags, uint32_t* flags, uint8_t* segs, int* cnt, long long* dist, uint8_t* outbuf, int outcap,
+                     CbOut* res, int* pass_len, long long* pass_dist, int want_dist, int stage) {
+  if (stage == 0) {
+    hipLaunchKernelGGL(k_t1_flags_init, dim3((T1_FLAGS_WORDS * 64 + 255) / 256, nwaves), dim3(256), 0, st, waves, cbs, ncb, nbps, mags, flags);
+  } else if (stage == 1) {
+    hipLaunchKernelGGL(k_t1_cm, dim3(nwaves), dim3(64), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
+  } else {
+    static const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 4; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 4; }();
+    long long* pdp = want_dist ? pass_dist : nullptr;
+#define MQ_LAUNCH(N) hipLaunchKernelGGL(k_t1_mq<N>, dim3((ncb + N - 1) / N), dim3(N), 0, st, cbs, ncb, nbps, joboff, segs, cnt, dist, outbuf, outcap, res, pass_len, pdp)
+    switch (ml) { case 8: MQ_LAUNCH(8); break; case 16: MQ_LAUNCH(16); break; case 32: MQ_LAUNCH(32); break; case 64: MQ_LAUNCH(64); break; default: MQ_LAUNCH(4); }
+#undef MQ_LAUNCH
   }
 }
 

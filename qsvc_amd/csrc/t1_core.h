@@ -89,22 +89,28 @@ struct T1Result {  // per code-block outputs besides the bytes
 //   void pass_begin(int nstripes) / stripe_begin(int s, int nstripes) / stripe_end(int s) / pass_end(int nstripes)
 //        wave-uniform window management (no-ops on the host)
 struct T1Lane {
-  uint8_t* cx;            // this lane's context-state bytes (index<<1 | mps); context c at cx[c*cs]
+  uint32_t* cx;           // this lane's context states, one packed word each: the state's table entry
+                          // (qe | nmps<<16 | nlps<<22 | switch<<28) | mps<<29; context c at cx[c*cs]
   const uint32_t* mqtab;  // [47]
   const uint8_t* zclut;   // [3][512] zero-coding LUT (class 0: LL/LH, 1: HL, 2: HH)
-  uint8_t* out;           // out[0] is a scratch byte; the segment is out[1..]
+  uint8_t* out;           // 4-byte aligned; out[0] is a scratch byte; the segment is out[1..]
   int cs;
-  int cap;                // bytes available at out (incl. the scratch byte)
+  int cap;                // bytes available at out (incl. the scratch byte), multiple of 4
   int w, h, orient, nbps;
   // MQ registers
   uint32_t A, C;
   int CT, B, n;           // B: byte register (not yet in memory), n: bytes emitted incl. the scratch byte
+  uint32_t ob;            // emitted bytes not yet stored (stores go out one aligned u32 at a time)
   unsigned long long nsym;
 };
 
 T1HD void mq_emit(T1Lane& t) {
-  if (t.n < t.cap) t.out[t.n] = (uint8_t)t.B;
+  t.ob |= (uint32_t)(t.B & 0xFF) << (8 * (t.n & 3));
   t.n++;
+  if ((t.n & 3) == 0) {
+    if (t.n <= t.cap) *(uint32_t*)(t.out + t.n - 4) = t.ob;
+    t.ob = 0;
+  }
 }
 T1HD void mq_byteout(T1Lane& t) {  // BYTEOUT, T.800 C.2.7, with the byte register held in t.B
   if (t.B == 0xFF) {
@@ -121,26 +127,36 @@ T1HD void mq_byteout(T1Lane& t) {  // BYTEOUT, T.800 C.2.7, with the byte regist
     }
   }
 }
+T1HD int t1_clz32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __clz((int)v);
+#else
+  return __builtin_clz(v);
+#endif
+}
 T1HD void mq_encode(T1Lane& t, int cx, int d) {  // ENCODE/CODEMPS/CODELPS/RENORME, T.800 C.2.2-C.2.6
-  uint8_t st = t.cx[cx * t.cs];
-  uint32_t e = t.mqtab[st >> 1];
+  uint32_t e = t.cx[cx * t.cs];
   uint32_t qe = e & 0xFFFF;
-  int mps = st & 1;
+  uint32_t mps = (e >> 29) & 1;
+  uint32_t nidx;
   t.nsym++;
   t.A -= qe;
-  if (d == mps) {
+  if ((uint32_t)d == mps) {
     if (t.A & 0x8000) { t.C += qe; return; }
     if (t.A < qe) t.A = qe; else t.C += qe;
-    t.cx[cx * t.cs] = (uint8_t)((((e >> 16) & 63) << 1) | mps);
+    nidx = (e >> 16) & 63;
   } else {
     if (t.A < qe) t.C += qe; else t.A = qe;
-    if ((e >> 28) & 1) mps ^= 1;
-    t.cx[cx * t.cs] = (uint8_t)((((e >> 22) & 63) << 1) | mps);
+    mps ^= (e >> 28) & 1;
+    nidx = (e >> 22) & 63;
   }
-  do {
-    t.A <<= 1; t.C <<= 1; t.CT--;
-    if (t.CT == 0) mq_byteout(t);
-  } while ((t.A & 0x8000) == 0);
+  t.cx[cx * t.cs] = t.mqtab[nidx] | (mps << 29);
+  // RENORME in one step: A is in [1, 0x7FFF] here, shift it up to bit 15; C moves with it, a byte leaves whenever
+  // CT bits have gone
+  int sh = t1_clz32(t.A) - 16;
+  t.A <<= sh;
+  while (sh >= t.CT) { t.C <<= t.CT; sh -= t.CT; mq_byteout(t); }
+  t.C <<= sh; t.CT -= sh;
 }
 T1HD int mq_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment length
   uint32_t tempc = t.C + t.A;
@@ -149,6 +165,7 @@ T1HD int mq_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment lengt
   t.C <<= t.CT; mq_byteout(t);
   t.C <<= t.CT; mq_byteout(t);
   if (t.B != 0xFF) mq_emit(t);
+  if ((t.n & 3) && (t.n & ~3) + 4 <= t.cap) *(uint32_t*)(t.out + (t.n & ~3)) = t.ob;  // the partial last word
   return t.n - 1;
 }
 
@@ -172,9 +189,9 @@ T1HD void t1_set_sig(Store& S, int r, int c, uint32_t& own, int k, int neg) {
     S.orr(r + 1, c + 1, 1u << 0);
   }
 }
-// sign coding (T.800 D.3.2, Tables D.2/D.3)
-template <class Store>
-T1HD void t1_code_sign(T1Lane& t, Store& S, int r, int c, uint32_t own, int k, int neg) {
+// sign coding (T.800 D.3.2, Tables D.2/D.3).  `K.sym(cx, d)` consumes one binary decision.
+template <class Store, class Sink>
+T1HD void t1_code_sign(Sink& K, Store& S, int r, int c, uint32_t own, int k, int neg) {
   uint32_t l = S.ld(r, c - 1), rr = S.ld(r, c + 1);
   int nb = (own >> (3 * k)) & 0x1FF;
   int hc = 0, vc = 0;
@@ -187,7 +204,7 @@ T1HD void t1_code_sign(T1Lane& t, Store& S, int r, int c, uint32_t own, int k, i
   int xr = hc < 0 || (hc == 0 && vc < 0);
   if (xr) { hc = -hc; vc = -vc; }  // after the flip: hc in {0,1}; hc == 0 -> vc in {0,1}
   int cx = hc == 1 ? 12 + vc : (vc == 1 ? 10 : 9);
-  mq_encode(t, cx, neg ^ xr);
+  K.sym(cx, neg ^ xr);
 }
 T1HD long long t1_dist_sig(int m, int p) {  // distortion decrease, midpoint reconstruction
   long long r = (long long)((m >> p) << p) + (p ? (1 << (p - 1)) : 0);
@@ -200,117 +217,225 @@ T1HD long long t1_dist_ref(int m, int p) {
   return d0 * d0 - d1 * d1;
 }
 
-// The whole block.  `top` = highest bit-plane index any lane of the wave codes (uniform loop bound);
-// wmax/hmax = uniform scan bounds (max over the wave).  A lane with nbps == 0 emits nothing.
-// Control flow over (bit-plane, pass, stripe, column) is wave-uniform; `on` predicates the lane.
+// One coding pass (0 significance propagation D.3.1, 1 magnitude refinement D.3.3, 2 clean-up D.3.4) of
+// bit-plane p over the whole block.  Control flow over (stripe, column) is wave-uniform; `lane_pass`
+// predicates the lane.  Decisions go to the Sink in scan order; returns the pass's distortion decrease.
+template <class Store, class Sink>
+T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, int w, int h, int wmax, int nstripes,
+                       bool lane_pass, bool want_dist) {
+  long long dist = 0;
+  S.pass_begin(nstripes);
+  for (int s = 0; s < nstripes; s++) {
+    S.stripe_begin(s, nstripes);
+    const int r = s + 1;
+    for (int x = 0; x < wmax; x++) {
+      const bool on = lane_pass && x < w && 4 * s < h;
+      if (!on) continue;
+      const int c = x + 1;
+      uint32_t f = S.ld(r, c);
+      const uint32_t f0 = f;
+      if (pass == 0) {
+        if ((f & T1_SIG_ALL) == 0) continue;
+        uint64_t m = S.mag(s, x);
+        for (int k = 0; k < 4 && 4 * s + k < h; k++) {
+          int nb = (f >> (3 * k)) & 0x1FF;
+          if ((nb & 0x10) || (nb & 0x1EF) == 0) continue;
+          int mag = t1_mag(m, k), bit = (mag >> p) & 1;
+          K.sym(zc[nb & 0x1EF], bit);
+          if (bit) {
+            int neg = t1_neg(m, k);
+            t1_code_sign(K, S, r, c, f, k, neg);
+            t1_set_sig(S, r, c, f, k, neg);
+            if (want_dist) dist += t1_dist_sig(mag, p);
+          }
+          f |= 1u << (T1_PI_SHIFT + k);
+        }
+      } else if (pass == 1) {
+        uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);  // sigma of rows 0..3
+        uint32_t todo = own & ~(f >> T1_PI_SHIFT) & 0xF;
+        if (!todo) continue;
+        uint64_t m = S.mag(s, x);
+        for (int k = 0; k < 4; k++) {
+          if (!((todo >> k) & 1)) continue;
+          int nb = (f >> (3 * k)) & 0x1FF;
+          int cx = ((f >> (T1_MU_SHIFT + k)) & 1) ? 16 : ((nb & 0x1EF) ? 15 : 14);
+          int mag = t1_mag(m, k);
+          K.sym(cx, (mag >> p) & 1);
+          f |= 1u << (T1_MU_SHIFT + k);
+          if (want_dist) dist += t1_dist_ref(mag, p);
+        }
+      } else {
+        uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);
+        uint32_t done = (own | (f >> T1_PI_SHIFT)) & 0xF;
+        int rows = h - 4 * s; if (rows > 4) rows = 4;
+        if (done != 0xF || rows < 4) {
+          uint64_t m = S.mag(s, x);
+          int k = 0;
+          if (rows == 4 && (f & (T1_SIG_ALL | (0xFu << T1_PI_SHIFT))) == 0) {  // run-length mode
+            int b0 = (t1_mag(m, 0) >> p) & 1, b1 = (t1_mag(m, 1) >> p) & 1, b2 = (t1_mag(m, 2) >> p) & 1, b3 = (t1_mag(m, 3) >> p) & 1;
+            if (!(b0 | b1 | b2 | b3)) { K.sym(T1_CTX_RUN, 0); k = 4; }
+            else {
+              int fk = b0 ? 0 : (b1 ? 1 : (b2 ? 2 : 3));
+              K.sym(T1_CTX_RUN, 1);
+              K.sym(T1_CTX_UNI, fk >> 1);
+              K.sym(T1_CTX_UNI, fk & 1);
+              int neg = t1_neg(m, fk);
+              t1_code_sign(K, S, r, c, f, fk, neg);
+              t1_set_sig(S, r, c, f, fk, neg);
+              if (want_dist) dist += t1_dist_sig(t1_mag(m, fk), p);
+              k = fk + 1;
+            }
+          }
+          for (; k < rows; k++) {
+            int nb = (f >> (3 * k)) & 0x1FF;
+            if ((nb & 0x10) || ((f >> (T1_PI_SHIFT + k)) & 1)) continue;
+            int mag = t1_mag(m, k), bit = (mag >> p) & 1;
+            K.sym(zc[nb & 0x1EF], bit);
+            if (bit) {
+              int neg = t1_neg(m, k);
+              t1_code_sign(K, S, r, c, f, k, neg);
+              t1_set_sig(S, r, c, f, k, neg);
+              if (want_dist) dist += t1_dist_sig(mag, p);
+            }
+          }
+        }
+        f &= ~(0xFu << T1_PI_SHIFT);  // the "visited" marks last one bit-plane
+      }
+      if (f != f0) S.st(r, c, f);
+    }
+    S.stripe_end(s);
+  }
+  S.pass_end(nstripes);
+  return dist;
+}
+
+struct T1MqSink {  // decisions go straight into the lane's MQ coder (fused kernel)
+  T1Lane* t;
+  T1HD_M void sym(int cx, int d) { mq_encode(*t, cx, d); }
+};
+
+T1HD void t1_lane_init(T1Lane& t) {  // context reset (T.800 Table D.7) + INITENC (C.2.8)
+  for (int c = 0; c < 19; c++) t.cx[c * t.cs] = t.mqtab[0];
+  t.cx[0 * t.cs] = t.mqtab[4]; t.cx[T1_CTX_RUN * t.cs] = t.mqtab[3]; t.cx[T1_CTX_UNI * t.cs] = t.mqtab[46];
+  t.A = 0x8000; t.C = 0; t.CT = 12; t.B = 0; t.n = 0; t.ob = 0; t.nsym = 0;
+}
+T1HD void t1_lane_finish(T1Lane& t, int np, T1Result& res) {
+  res.npasses = np;
+  res.nbps = t.nbps;
+  res.len = t.nbps ? mq_flush(t) : 0;
+  res.overflow = ((t.n + 3) & ~3) > t.cap;
+  res.nsym = t.nsym;
+  for (int i = 0; i < np; i++) if (res.pass_len[i] > res.len) res.pass_len[i] = res.len;
+  if (np) res.pass_len[np - 1] = res.len;
+}
+
+// The whole block, context modelling and MQ coding fused.  `top` = highest bit-plane index any lane of the
+// wave codes (uniform loop bound); wmax/hmax = uniform scan bounds.  A lane with nbps == 0 emits nothing.
 template <class Store>
 T1HD void t1_encode_lane(T1Lane& t, Store& S, int top, int wmax, int hmax, bool want_dist, T1Result& res) {
   const uint8_t* zc = t.zclut + 512 * (t.orient == 1 ? 1 : (t.orient == 3 ? 2 : 0));
-  for (int c = 0; c < 19; c++) t.cx[c * t.cs] = 0;
-  t.cx[0 * t.cs] = 4 << 1; t.cx[T1_CTX_RUN * t.cs] = 3 << 1; t.cx[T1_CTX_UNI * t.cs] = 46 << 1;
-  t.A = 0x8000; t.C = 0; t.CT = 12; t.B = 0; t.n = 0; t.nsym = 0;
+  t1_lane_init(t);
+  T1MqSink K{&t};
   int np = 0;
   const int nstripes = (hmax + 3) >> 2;
   for (int p = top; p >= 0; p--) {
     const bool active = p < t.nbps;
     const bool first = p == t.nbps - 1;
     for (int pass = 0; pass < 3; pass++) {
-      // pass 0: significance propagation (D.3.1), 1: magnitude refinement (D.3.3), 2: clean-up (D.3.4)
       if (pass < 2 && p == top) continue;  // every lane is at (or above) its first plane: clean-up only
       const bool lane_pass = active && (pass == 2 || !first);
-      long long dist = 0;
-      S.pass_begin(nstripes);
-      for (int s = 0; s < nstripes; s++) {
-        S.stripe_begin(s, nstripes);
-        const int r = s + 1;
-        for (int x = 0; x < wmax; x++) {
-          const bool on = lane_pass && x < t.w && 4 * s < t.h;
-          if (!on) continue;
-          const int c = x + 1;
-          uint32_t f = S.ld(r, c);
-          const uint32_t f0 = f;
-          if (pass == 0) {
-            if ((f & T1_SIG_ALL) == 0) continue;
-            uint64_t m = S.mag(s, x);
-            for (int k = 0; k < 4 && 4 * s + k < t.h; k++) {
-              int nb = (f >> (3 * k)) & 0x1FF;
-              if ((nb & 0x10) || (nb & 0x1EF) == 0) continue;
-              int mag = t1_mag(m, k), bit = (mag >> p) & 1;
-              mq_encode(t, zc[nb & 0x1EF], bit);
-              if (bit) {
-                int neg = t1_neg(m, k);
-                t1_code_sign(t, S, r, c, f, k, neg);
-                t1_set_sig(S, r, c, f, k, neg);
-                if (want_dist) dist += t1_dist_sig(mag, p);
-              }
-              f |= 1u << (T1_PI_SHIFT + k);
-            }
-          } else if (pass == 1) {
-            uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);  // sigma of rows 0..3
-            uint32_t todo = own & ~(f >> T1_PI_SHIFT) & 0xF;
-            if (!todo) continue;
-            uint64_t m = S.mag(s, x);
-            for (int k = 0; k < 4; k++) {
-              if (!((todo >> k) & 1)) continue;
-              int nb = (f >> (3 * k)) & 0x1FF;
-              int cx = ((f >> (T1_MU_SHIFT + k)) & 1) ? 16 : ((nb & 0x1EF) ? 15 : 14);
-              int mag = t1_mag(m, k);
-              mq_encode(t, cx, (mag >> p) & 1);
-              f |= 1u << (T1_MU_SHIFT + k);
-              if (want_dist) dist += t1_dist_ref(mag, p);
-            }
-          } else {
-            uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);
-            uint32_t done = (own | (f >> T1_PI_SHIFT)) & 0xF;
-            int rows = t.h - 4 * s; if (rows > 4) rows = 4;
-            if (done != 0xF || rows < 4) {
-              uint64_t m = S.mag(s, x);
-              int k = 0;
-              if (rows == 4 && (f & (T1_SIG_ALL | (0xFu << T1_PI_SHIFT))) == 0) {  // run-length mode
-                int b0 = (t1_mag(m, 0) >> p) & 1, b1 = (t1_mag(m, 1) >> p) & 1, b2 = (t1_mag(m, 2) >> p) & 1, b3 = (t1_mag(m, 3) >> p) & 1;
-                if (!(b0 | b1 | b2 | b3)) { mq_encode(t, T1_CTX_RUN, 0); k = 4; }
-                else {
-                  int fk = b0 ? 0 : (b1 ? 1 : (b2 ? 2 : 3));
-                  mq_encode(t, T1_CTX_RUN, 1);
-                  mq_encode(t, T1_CTX_UNI, fk >> 1);
-                  mq_encode(t, T1_CTX_UNI, fk & 1);
-                  int neg = t1_neg(m, fk);
-                  t1_code_sign(t, S, r, c, f, fk, neg);
-                  t1_set_sig(S, r, c, f, fk, neg);
-                  if (want_dist) dist += t1_dist_sig(t1_mag(m, fk), p);
-                  k = fk + 1;
-                }
-              }
-              for (; k < rows; k++) {
-                int nb = (f >> (3 * k)) & 0x1FF;
-                if ((nb & 0x10) || ((f >> (T1_PI_SHIFT + k)) & 1)) continue;
-                int mag = t1_mag(m, k), bit = (mag >> p) & 1;
-                mq_encode(t, zc[nb & 0x1EF], bit);
-                if (bit) {
-                  int neg = t1_neg(m, k);
-                  t1_code_sign(t, S, r, c, f, k, neg);
-                  t1_set_sig(S, r, c, f, k, neg);
-                  if (want_dist) dist += t1_dist_sig(mag, p);
-                }
-              }
-            }
-            f &= ~(0xFu << T1_PI_SHIFT);  // the "visited" marks last one bit-plane
-          }
-          if (f != f0) S.st(r, c, f);
-        }
-        S.stripe_end(s);
-      }
-      S.pass_end(nstripes);
+      long long dist = t1_pass(K, S, zc, pass, p, t.w, t.h, wmax, nstripes, lane_pass, want_dist);
       if (lane_pass) { res.pass_len[np] = t.n + 4; if (res.pass_dist) res.pass_dist[np] = dist; np++; }
     }
   }
-  res.npasses = np;
-  res.nbps = t.nbps;
-  res.len = t.nbps ? mq_flush(t) : 0;
-  res.overflow = t.n > t.cap;
-  res.nsym = t.nsym;
-  for (int i = 0; i < np; i++) if (res.pass_len[i] > res.len) res.pass_len[i] = res.len;
-  if (np) res.pass_len[np - 1] = res.len;
+  t1_lane_finish(t, np, res);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split form: bit-plane-parallel context modelling + a separate MQ kernel.
+// The significance state at the START of bit-plane p is a pure function of the magnitudes
+// (sigma = mag >> (p+1) != 0, "refined before" = mag >> (p+2) != 0), so every (block, bit-plane) pair
+// can be modelled independently; only the MQ coder is serial over the block's whole decision stream.
+// A decision is one byte: cx | d << 5.  Segments per (block, plane): pass 0 at +0, pass 1 at +T1_SEG1,
+// pass 2 at +T1_SEG2; T1_SEG_BYTES in all (worst cases: 2*4096, 4096, 10*1024).
+#define T1_SEG1 8192
+#define T1_SEG2 12288
+#define T1_SEG_BYTES 22528
+
+// initial flag word (r = stripe+1, c = x+1) of bit-plane p from the magnitudes; M(s, x) returns the packed
+// magnitudes (0 outside the block).
+template <class MagF>
+T1HD uint32_t t1_initial_flag(const MagF& M, int s, int x, int p, int nstripes_blk, int w) {
+  uint32_t f = 0;
+  for (int dc = 0; dc < 3; dc++) {
+    int xx = x - 1 + dc;
+    if (xx < 0 || xx >= w) continue;
+    uint64_t mu = s > 0 ? M(s - 1, xx) : 0, mc = M(s, xx), md = s + 1 < nstripes_blk ? M(s + 1, xx) : 0;
+    // rows -1..4 of the neighbourhood: last row of the stripe above, the 4 own rows, first row of the stripe below
+    int mags[6] = {t1_mag(mu, 3), t1_mag(mc, 0), t1_mag(mc, 1), t1_mag(mc, 2), t1_mag(mc, 3), t1_mag(md, 0)};
+    int negs[6] = {t1_neg(mu, 3), t1_neg(mc, 0), t1_neg(mc, 1), t1_neg(mc, 2), t1_neg(mc, 3), t1_neg(md, 0)};
+    for (int rr = 0; rr < 6; rr++) {
+      if ((mags[rr] >> (p + 1)) == 0) continue;
+      f |= 1u << (3 * rr + dc);
+      if (dc == 1) {
+        f |= (uint32_t)negs[rr] << (T1_CHI_SHIFT + rr);
+        if (rr >= 1 && rr <= 4 && (mags[rr] >> (p + 2))) f |= 1u << (T1_MU_SHIFT + rr - 1);
+      }
+    }
+  }
+  return f;
+}
+
+struct T1SymSink {  // decisions are appended to the (block, plane, pass) segment, 4 per u32 store
+  uint8_t* seg;
+  int n;
+  uint32_t acc;
+  T1HD_M void begin(uint8_t* s) { seg = s; n = 0; acc = 0; }
+  T1HD_M void sym(int cx, int d) {
+    acc |= (uint32_t)(cx | (d << 5)) << (8 * (n & 3));
+    n++;
+    if ((n & 3) == 0) { *(uint32_t*)(seg + n - 4) = acc; acc = 0; }
+  }
+  T1HD_M int end() {
+    if (n & 3) *(uint32_t*)(seg + (n & ~3)) = acc;
+    return n;
+  }
+};
+
+// Context modelling of ONE bit-plane of one block (lane): the flag words must hold t1_initial_flag().
+// cnt[3]/dist[3] receive the decisions and the distortion decrease of each pass.
+template <class Store>
+T1HD void t1_cm_plane(Store& S, const uint8_t* zclut, uint8_t* seg, int p, int w, int h, int orient, int nbps, int wmax,
+                      int hmax, bool want_dist, int* cnt, long long* dist) {
+  const uint8_t* zc = zclut + 512 * (orient == 1 ? 1 : (orient == 3 ? 2 : 0));
+  const int nstripes = (hmax + 3) >> 2;
+  const bool active = p < nbps, first = p == nbps - 1;
+  T1SymSink K;
+  for (int pass = 0; pass < 3; pass++) {
+    const bool lane_pass = active && (pass == 2 || !first);
+    K.begin(seg + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2)));
+    long long d = t1_pass(K, S, zc, pass, p, w, h, wmax, nstripes, lane_pass, want_dist);
+    int n = K.end();
+    if (lane_pass) { cnt[pass] = n; dist[pass] = d; } else { cnt[pass] = 0; dist[pass] = 0; }
+  }
+}
+
+// MQ coding of one block from its decision segments.  Seg(p) -> base of plane p's segments,
+// Cnt(p, pass) -> decisions in that pass.  Sequential per lane; different lanes run different lengths.
+template <class SegF, class CntF, class DistF>
+T1HD void t1_mq_block(T1Lane& t, const SegF& Seg, const CntF& Cnt, const DistF& Dist, T1Result& res) {
+  t1_lane_init(t);
+  int np = 0;
+  for (int p = t.nbps - 1; p >= 0; p--)
+    for (int pass = (p == t.nbps - 1 ? 2 : 0); pass < 3; pass++) {
+      const uint8_t* sg = Seg(p) + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
+      int n = Cnt(p, pass);
+      for (int i = 0; i < n; i++) { int v = sg[i]; mq_encode(t, v & 31, v >> 5); }
+      res.pass_len[np] = t.n + 4;
+      if (res.pass_dist) res.pass_dist[np] = Dist(p, pass);
+      np++;
+    }
+  t1_lane_finish(t, np, res);
 }
 
 // Host/array store: lane stride ls (1 on the host harness).

@@ -157,18 +157,74 @@ extern "C" int emul_t1_block(const int32_t* vals, int w, int h, int orient, uint
     }
   int nb = 0;
   while (maxm >> nb) nb++;
-  uint8_t cx[19];
-  std::vector<uint8_t> buf((size_t)w * h * 4 + 64);
+  uint32_t cx[19];
+  std::vector<uint32_t> buf32((size_t)w * h + 16);
+  uint8_t* bufp = (uint8_t*)buf32.data();
   T1Lane t;
-  t.cx = cx; t.mqtab = mqtab; t.zclut = zclut; t.out = buf.data();
-  t.cs = 1; t.cap = (int)buf.size(); t.w = w; t.h = h; t.orient = orient; t.nbps = nb;
+  t.cx = cx; t.mqtab = mqtab; t.zclut = zclut; t.out = bufp;
+  t.cs = 1; t.cap = (int)buf32.size() * 4; t.w = w; t.h = h; t.orient = orient; t.nbps = nb;
   T1ArrayStore S{flags.data(), mags.data(), 1};
   T1Result r;
   int pl[T1_MAXPASS]; long long pd[T1_MAXPASS];
   r.pass_len = pl; r.pass_dist = pd;
   t1_encode_lane(t, S, nb - 1, w, h, true, r);
   if (r.overflow) return -2;
-  memcpy(out, buf.data() + 1, r.len);
+  memcpy(out, bufp + 1, r.len);
+  *npasses = r.npasses; *nbps = r.nbps;
+  for (int i = 0; i < r.npasses; i++) { pass_len[i] = pl[i]; if (pass_dist) pass_dist[i] = pd[i]; }
+  return r.len;
+}
+
+// ---- split form: per-plane context modelling from initial flags + MQ over the decision segments ----
+extern "C" int emul_t1_block_split(const int32_t* vals, int w, int h, int orient, uint8_t* out, int* npasses, int* nbps,
+                                   int* pass_len, long long* pass_dist) {
+  static const uint32_t mqtab[47] = T1_MQ_TABLE_INIT;
+  static uint8_t zclut[3 * 512];
+  static bool init = false;
+  if (!init) {
+    for (int c = 0; c < 3; c++)
+      for (int nb = 0; nb < 512; nb++) zclut[c * 512 + nb] = (uint8_t)t1_zc_from_nb(nb, c == 0 ? 0 : (c == 1 ? 1 : 3));
+    init = true;
+  }
+  std::vector<uint64_t> mags(16 * 64, 0);
+  int maxm = 0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int v = vals[y * w + x];
+      int m = v < 0 ? -v : v;
+      if (m > 0x7FFF) return -1;
+      if (m > maxm) maxm = m;
+      mags[(y >> 2) * 64 + x] |= (uint64_t)(m | (v < 0 ? 0x8000 : 0)) << (16 * (y & 3));
+    }
+  int nb = 0;
+  while (maxm >> nb) nb++;
+  int nstr = (h + 3) >> 2;
+  std::vector<uint8_t> segs((size_t)(nb ? nb : 1) * T1_SEG_BYTES);
+  std::vector<int> cnt((size_t)(nb ? nb : 1) * 3, 0);
+  std::vector<long long> dist((size_t)(nb ? nb : 1) * 3, 0);
+  auto M = [&](int s, int x) { return mags[s * 64 + x]; };
+  for (int p = 0; p < nb; p++) {  // every plane independently, from its initial flags
+    std::vector<uint32_t> flags(18 * T1_FW, 0);
+    for (int s = 0; s < nstr; s++)
+      for (int x = 0; x < w; x++) flags[(s + 1) * T1_FW + x + 1] = t1_initial_flag(M, s, x, p, nstr, w);
+    T1ArrayStore S{flags.data(), mags.data(), 1};
+    t1_cm_plane(S, zclut, segs.data() + (size_t)p * T1_SEG_BYTES, p, w, h, orient, nb, w, h, true, &cnt[p * 3], &dist[p * 3]);
+  }
+  uint32_t cx[19];
+  std::vector<uint32_t> buf32((size_t)w * h + 16);
+  uint8_t* bufp = (uint8_t*)buf32.data();
+  T1Lane t;
+  t.cx = cx; t.mqtab = mqtab; t.zclut = zclut; t.out = bufp;
+  t.cs = 1; t.cap = (int)buf32.size() * 4; t.w = w; t.h = h; t.orient = orient; t.nbps = nb;
+  T1Result r;
+  int pl[T1_MAXPASS]; long long pd[T1_MAXPASS];
+  r.pass_len = pl; r.pass_dist = pd;
+  auto Seg = [&](int p) { return (const uint8_t*)segs.data() + (size_t)p * T1_SEG_BYTES; };
+  auto Cnt = [&](int p, int pass) { return cnt[p * 3 + pass]; };
+  auto Dist = [&](int p, int pass) { return dist[p * 3 + pass]; };
+  t1_mq_block(t, Seg, Cnt, Dist, r);
+  if (r.overflow) return -2;
+  memcpy(out, bufp + 1, r.len);
   *npasses = r.npasses; *nbps = r.nbps;
   for (int i = 0; i < r.npasses; i++) { pass_len[i] = pl[i]; if (pass_dist) pass_dist[i] = pd[i]; }
   return r.len;
