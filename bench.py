@@ -62,6 +62,34 @@ def cpu_baseline():
             "mctf_s": round(t1 - t0, 3), "j2k_s": round(t2 - t1, 3), "codeblocks_per_s": round(ncb / (t2 - t1), 1)}
 
 
+def multi_session(nctx, prm, clip, steps=3):
+    """Informational (N=1): several independent encoder contexts in flight on the one GPU, one host thread each.
+    Tier-1 is a long serial chain per code-block that leaves most of the chip idle; a second and third sequence fill it."""
+    import copy
+    import threading
+    from qsvc_amd import hip
+    from qsvc_amd.pipeline import Compressor
+    comps = []
+    for _ in range(nctx):
+        c = Compressor(hip.Engine(0), copy.deepcopy(prm))
+        c.configure(); c.load(clip); c.analyze(); c.texture(copy=False); c.e.sync()
+        comps.append(c)
+
+    def work(c):
+        for _ in range(steps):
+            c.analyze(); c.texture(copy=False)
+        c.e.sync()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(c,)) for c in comps]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    for c in comps:
+        c.e.close()
+    return {"sessions": nctx, "steps_per_session": steps, "value": round(clip.shape[0] * nctx * steps / dt, 2), "unit": "frames/s",
+            "ms_per_step_amortised": round(dt / (nctx * steps) * 1e3, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clip", default="pan_noise")
+    ap.add_argument("--sessions", type=int, default=4, help="extra (N=1 only): throughput with this many encoder contexts in flight")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,7 +146,7 @@ def main():
 
     def step():
         comp.analyze()
-        out = comp.texture(low_first)
+        out = comp.texture(low_first, copy=False)  # code-streams stay in the engine's host buffer (no Python copies)
         return sum(len(c) for v in out.values() for c in v)
 
     def barrier():
@@ -161,6 +190,9 @@ def main():
         nB = [8, 4, 2]
         alg = {
             "j2k_t1_encode": ncb_step * 8192 + nbytes,
+            "j2k_t1_cm": ncb_step * 8192 + int(stats["symbols"]),      # int16 coefficients in, one byte per decision out
+            "j2k_t1_mq": int(stats["symbols"]) + nbytes,               # decisions in, code bytes out
+            "j2k_t1_flags": ncb_step * 8192,
             "predict": sum(nB) * 4 * F,
             "update": sum(n + 1 for n in nB) * 4 * F - 3 * 2 * F,
             "me_search_l0": sum(nB) * 3 * W * H,
@@ -180,8 +212,8 @@ def main():
                     "launch_ms": round(per[dom]["ms_per_step"] / launches, 4),
                     "algorithmic_bytes_per_launch": int(alg[dom] / launches),
                     "note": "EBCOT Tier-1 is serial-dependency bound, not HBM bound (SURVEY.md H4/8d); fraction quoted for completeness"
-                    if dom == "j2k_t1_encode" else ""}
-        t1ms = per.get("j2k_t1_encode", {}).get("ms_per_step", 0)
+                    if dom.startswith("j2k_t1") else ""}
+        t1ms = sum(per.get(k, {}).get("ms_per_step", 0) for k in ("j2k_t1_encode", "j2k_t1_flags", "j2k_t1_cm", "j2k_t1_mq"))
         line = {
             "metric": "1080p encode fps (MCTF + 5/3 DWT + EBCOT)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
@@ -195,6 +227,8 @@ def main():
             "codestream_bytes_per_step": int(nbytes), "mq_symbols_per_step": int(stats["symbols"]),
             "kernels": per, "roofline": roof,
         }
+        if world == 1 and args.sessions > 1:
+            line["multi_session"] = multi_session(args.sessions, prm, seq_local)
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()

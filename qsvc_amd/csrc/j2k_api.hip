@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 
 #include "j2k_kernels.h"
 #include "qsvc_ctx.h"
@@ -195,6 +196,7 @@ struct J2kState {
   DevBuf coefA, coefB, planes_d, cbs_d, nbps_d, mags, flags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
   DevBuf waves_d, joboff_d, segs_d, cnt_d, dist_d;  // split Tier-1
   std::vector<int> h_nbps, h_joboff, h_waves;
+  std::vector<uint8_t> t2scratch;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
   std::vector<PlaneDesc> planes;
   std::vector<CbDesc> cbs;
@@ -509,18 +511,48 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
   if (gtotal) HIPCHK(c, hipMemcpyAsync(S.gath_h, S.gath_d.p, gtotal, hipMemcpyDeviceToHost, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   HIPCHK(c, hipGetLastError());
-  // host: Tier-2, one code-stream per plane
-  size_t pos = 0;
-  for (int p = 0; p < np; p++) {
-    offs[p] = pos;
-    long n = write_codestream(plans[plan_of[p]], *src[p].prm, src[p].prm->layers < 1 ? 1 : src[p].prm->layers, cbw, cbh, S.hcb.data() + first_cb[p],
-                              S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS, S.gath_h, out + pos, cap - pos);
-    if (n < 0) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes)", cap);
-    pos += (size_t)n;
+  // host: Tier-2, one code-stream per plane.  Planes are independent: worker threads write each plane into a
+  // scratch slot (size bound known from its body bytes), then copy to the packed positions.
+  {
+    std::vector<size_t> slot(np + 1, 0), plen_out(np, 0);
+    for (int p = 0; p < np; p++) {
+      size_t body = 0;
+      for (int k = first_cb[p]; k < first_cb[p + 1]; k++) body += (size_t)glens[k];
+      const PlanePlan& pl = plans[plan_of[p]];
+      int layers = src[p].prm->layers < 1 ? 1 : src[p].prm->layers;
+      slot[p + 1] = slot[p] + body + 64 * (size_t)pl.ncb * layers + 16 * (size_t)layers * (pl.L + 1) + 512;
+    }
+    if (S.t2scratch.size() < slot[np]) S.t2scratch.resize(slot[np] + slot[np] / 8);
+    const int nthreads = std::max(1, std::min(8, np));
+    std::vector<long> rc(np, 0);
+    auto worker = [&](int tid) {
+      for (int p = tid; p < np; p += nthreads)
+        rc[p] = write_codestream(plans[plan_of[p]], *src[p].prm, src[p].prm->layers < 1 ? 1 : src[p].prm->layers, cbw, cbh,
+                                 S.hcb.data() + first_cb[p], S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS, S.gath_h,
+                                 S.t2scratch.data() + slot[p], slot[p + 1] - slot[p]);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : th) t.join();
+    size_t pos = 0;
+    for (int p = 0; p < np; p++) {
+      if (rc[p] < 0) return c->fail(QSVC_ERR_NOMEM, "internal Tier-2 scratch too small");
+      offs[p] = pos; pos += (size_t)rc[p];
+    }
+    offs[np] = pos;
+    if (pos > cap) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes needed, %zu given)", pos, cap);
+    auto copier = [&](int tid) {
+      for (int p = tid; p < np; p += nthreads) memcpy(out + offs[p], S.t2scratch.data() + slot[p], (size_t)rc[p]);
+    };
+    th.clear();
+    for (int t = 1; t < nthreads; t++) th.emplace_back(copier, t);
+    copier(0);
+    for (auto& t : th) t.join();
   }
-  offs[np] = pos;
   return QSVC_OK;
 }
+
 
 extern "C" {
 

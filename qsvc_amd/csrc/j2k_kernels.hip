@@ -330,9 +330,17 @@ void launch_t1_encode(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbp
 struct T1GlobalStore {  // flag words and magnitudes straight from HBM/L2, lane stride 64
   uint32_t* flags;
   const uint32_t* mags;
-  __device__ __forceinline__ uint32_t ld(int r, int c) const { return flags[(r * T1_FW + c) * 64]; }
-  __device__ __forceinline__ void st(int r, int c, uint32_t v) { flags[(r * T1_FW + c) * 64] = v; }
-  __device__ __forceinline__ void orr(int r, int c, uint32_t b) { flags[(r * T1_FW + c) * 64] |= b; }
+  // Neighbour updates are fire-and-forget L2 atomics (no round trip in the lane's dependent chain); flag loads
+  // and stores are agent-scope so they meet those atomics in L2 instead of a stale L1 line.
+  __device__ __forceinline__ uint32_t ld(int r, int c) const {
+    return __hip_atomic_load(flags + (r * T1_FW + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ void st(int r, int c, uint32_t v) {
+    __hip_atomic_store(flags + (r * T1_FW + c) * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ void orr(int r, int c, uint32_t b) {
+    (void)__hip_atomic_fetch_or(flags + (r * T1_FW + c) * 64, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __device__ __forceinline__ uint64_t mag(int s, int x) const {
     const uint32_t* m = mags + (size_t)((s * 64 + x) * 2) * 64;
     return (uint64_t)m[0] | ((uint64_t)m[64] << 32);
@@ -367,13 +375,14 @@ __global__ void __launch_bounds__(256) k_t1_flags_init(const int* waves, const C
   flags[(size_t)wv * T1_FLAGS_WORDS * 64 + idx] = f;
 }
 
-__global__ void __launch_bounds__(64) k_t1_cm(const int* waves, const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
+template <int CML>  // lanes per CM wave: 64, 32 or 16 consecutive blocks of the group
+__global__ void __launch_bounds__(CML) k_t1_cm(const int* waves, const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
                                                const uint32_t* mags, uint32_t* flags, uint8_t* segs, int* cnt, long long* dist,
                                                int want_dist) {
   __shared__ uint8_t s_zc[3 * 512];
   int wv = blockIdx.x, g = waves[wv] >> 8, p = waves[wv] & 255;
-  int lane = threadIdx.x, b = g * 64 + lane;
-  for (int i = lane; i < 3 * 512; i += 64) {
+  int lane = blockIdx.y * CML + threadIdx.x, b = g * 64 + lane;
+  for (int i = threadIdx.x; i < 3 * 512; i += CML) {
     int c = i >> 9;
     s_zc[i] = (uint8_t)t1_zc_from_nb(i & 511, c == 0 ? 0 : (c == 1 ? 1 : 3));
   }
@@ -382,7 +391,7 @@ __global__ void __launch_bounds__(64) k_t1_cm(const int* waves, const CbDesc* cb
   if (b < ncb) { CbDesc cb = cbs[b]; w = cb.w; h = cb.h; orient = cb.orient; nb = nbps_in[b]; }
   const bool mine = p < nb;
   int wmax = mine ? w : 0, hmax = mine ? h : 0;
-  for (int o = 32; o >= 1; o >>= 1) {
+  for (int o = CML / 2; o >= 1; o >>= 1) {
     int a = __shfl_xor(wmax, o, 64), d = __shfl_xor(hmax, o, 64);
     wmax = a > wmax ? a : wmax; hmax = d > hmax ? d : hmax;
   }
@@ -434,6 +443,9 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
       uint4 cur = make_uint4(0, 0, 0, 0);
       if (n > 0) cur = sg[0];
       for (int i = 0; i < nmax; i += 16) {
+        // `cur` must have LANDED before the next chunk's load is issued: otherwise hipcc, which cannot count the
+        // divergent stores in between, waits vmcnt(0) at the first use of `cur` and so also for the prefetch.
+        asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w)::"memory");
         uint4 nxt = make_uint4(0, 0, 0, 0);
         if (i + 16 < n) nxt = sg[(i >> 4) + 1];  // next 16 decisions in flight while these are coded
         uint32_t wds[4] = {cur.x, cur.y, cur.z, cur.w};
@@ -465,7 +477,10 @@ void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc*
   if (stage == 0) {
     hipLaunchKernelGGL(k_t1_flags_init, dim3((T1_FLAGS_WORDS * 64 + 255) / 256, nwaves), dim3(256), 0, st, waves, cbs, ncb, nbps, mags, flags);
   } else if (stage == 1) {
-    hipLaunchKernelGGL(k_t1_cm, dim3(nwaves), dim3(64), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
+    static const int cl = [] { const char* e = getenv("QSVC_CM_LANES"); int v = e ? atoi(e) : 64; return (v == 16 || v == 32) ? v : 64; }();
+    if (cl == 16) hipLaunchKernelGGL(k_t1_cm<16>, dim3(nwaves, 4), dim3(16), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
+    else if (cl == 32) hipLaunchKernelGGL(k_t1_cm<32>, dim3(nwaves, 2), dim3(32), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
+    else hipLaunchKernelGGL(k_t1_cm<64>, dim3(nwaves, 1), dim3(64), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
   } else {
     static const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 4; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 4; }();
     long long* pdp = want_dist ? pass_dist : nullptr;

@@ -16,6 +16,14 @@
 #pragma once
 #include <stdint.h>
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// "this value has landed": forces the wait for a pending load to sit HERE, before younger loads are issued.
+// hipcc cannot count the divergent stores between a load and its use, so it falls back to vmcnt(0) at the
+// first use -- which would also wait for every prefetch issued in between (cdna guide 5, "mixing load kinds").
+#define T1_PIN32(x) asm volatile("" : "+v"(x)::"memory")
+#else
+#define T1_PIN32(x) ((void)0)
+#endif
 #if defined(__HIPCC__)
 #define T1HD __host__ __device__ __forceinline__
 #define T1HD_M __host__ __device__ __forceinline__
@@ -101,31 +109,28 @@ struct T1Lane {
   uint32_t A, C;
   int CT, B, n;           // B: byte register (not yet in memory), n: bytes emitted incl. the scratch byte
   uint32_t ob;            // emitted bytes not yet stored (stores go out one aligned u32 at a time)
-  unsigned long long nsym;
+  uint32_t nsym;
 };
 
 T1HD void mq_emit(T1Lane& t) {
-  t.ob |= (uint32_t)(t.B & 0xFF) << (8 * (t.n & 3));
+  t.ob |= (uint32_t)t.B << (8 * (t.n & 3));
   t.n++;
   if ((t.n & 3) == 0) {
     if (t.n <= t.cap) *(uint32_t*)(t.out + t.n - 4) = t.ob;
     t.ob = 0;
   }
 }
-T1HD void mq_byteout(T1Lane& t) {  // BYTEOUT, T.800 C.2.7, with the byte register held in t.B
-  if (t.B == 0xFF) {
-    mq_emit(t); t.B = t.C >> 20; t.C &= 0xFFFFF; t.CT = 7;
-  } else if (t.C < 0x8000000u) {
-    mq_emit(t); t.B = t.C >> 19; t.C &= 0x7FFFF; t.CT = 8;
-  } else {
-    t.B++;
-    if (t.B == 0xFF) {
-      t.C &= 0x7FFFFFF;
-      mq_emit(t); t.B = t.C >> 20; t.C &= 0xFFFFF; t.CT = 7;
-    } else {
-      mq_emit(t); t.B = t.C >> 19; t.C &= 0x7FFFF; t.CT = 8;
-    }
-  }
+// BYTEOUT (T.800 C.2.7) with the byte register held in t.B (always < 256), written with selects instead of the
+// flow chart's nested branches: on a GPU every branch of a lane is paid by the whole wave.
+T1HD void mq_byteout(T1Lane& t) {
+  uint32_t carry = (t.C >> 27) & (uint32_t)(t.B != 0xFF);  // a carry never enters a byte that is 0xFF (bit stuffing)
+  t.B += (int)carry;
+  const bool ff = t.B == 0xFF;                               // was 0xFF, or became 0xFF by the carry
+  if (carry && ff) t.C &= 0x7FFFFFF;
+  mq_emit(t);
+  t.B = ff ? (int)((t.C >> 20) & 0xFF) : (int)((t.C >> 19) & 0xFF);
+  t.C &= ff ? 0xFFFFFu : 0x7FFFFu;
+  t.CT = ff ? 7 : 8;
 }
 T1HD int t1_clz32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -134,29 +139,35 @@ T1HD int t1_clz32(uint32_t v) {
   return __builtin_clz(v);
 #endif
 }
-T1HD void mq_encode(T1Lane& t, int cx, int d) {  // ENCODE/CODEMPS/CODELPS/RENORME, T.800 C.2.2-C.2.6
-  uint32_t e = t.cx[cx * t.cs];
-  uint32_t qe = e & 0xFFFF;
+// ENCODE / CODEMPS / CODELPS / RENORME (T.800 C.2.2-C.2.6), select form:
+//   MPS, A still >= 0x8000 ....... C += Qe, nothing else
+//   MPS, A < 0x8000 .............. conditional exchange (A < Qe: A = Qe, else C += Qe), next = NMPS, renormalise
+//   LPS .......................... conditional exchange (A < Qe: C += Qe, else A = Qe), MPS flips on SWITCH,
+//                                  next = NLPS, renormalise
+T1HD void mq_encode(T1Lane& t, int cx, int d) {
+  const uint32_t e = t.cx[cx * t.cs];
+  const uint32_t qe = e & 0xFFFF;
   uint32_t mps = (e >> 29) & 1;
-  uint32_t nidx;
   t.nsym++;
-  t.A -= qe;
-  if ((uint32_t)d == mps) {
-    if (t.A & 0x8000) { t.C += qe; return; }
-    if (t.A < qe) t.A = qe; else t.C += qe;
-    nidx = (e >> 16) & 63;
-  } else {
-    if (t.A < qe) t.C += qe; else t.A = qe;
-    mps ^= (e >> 28) & 1;
-    nidx = (e >> 22) & 63;
+  uint32_t A = t.A - qe;
+  const bool ismps = (uint32_t)d == mps;
+  const bool small = (A & 0x8000) == 0;
+  const bool lt = A < qe;
+  const bool ren = !ismps || small;
+  const bool addc = ismps ? !(small && lt) : lt;
+  const bool seta = ismps ? (small && lt) : !lt;
+  t.C += addc ? qe : 0;
+  A = seta ? qe : A;
+  if (ren) {
+    const uint32_t nidx = ismps ? (e >> 16) & 63 : (e >> 22) & 63;
+    mps ^= ismps ? 0u : (e >> 28) & 1;
+    t.cx[cx * t.cs] = t.mqtab[nidx] | (mps << 29);
+    int sh = t1_clz32(A) - 16;  // A is in [1, 0x7FFF]: bring it back to bit 15 in one step
+    A <<= sh;
+    while (sh >= t.CT) { t.C <<= t.CT; sh -= t.CT; mq_byteout(t); }  // a byte leaves whenever CT bits have gone
+    t.C <<= sh; t.CT -= sh;
   }
-  t.cx[cx * t.cs] = t.mqtab[nidx] | (mps << 29);
-  // RENORME in one step: A is in [1, 0x7FFF] here, shift it up to bit 15; C moves with it, a byte leaves whenever
-  // CT bits have gone
-  int sh = t1_clz32(t.A) - 16;
-  t.A <<= sh;
-  while (sh >= t.CT) { t.C <<= t.CT; sh -= t.CT; mq_byteout(t); }
-  t.C <<= sh; t.CT -= sh;
+  t.A = A;
 }
 T1HD int mq_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment length
   uint32_t tempc = t.C + t.A;
@@ -174,11 +185,13 @@ T1HD int t1_neg(uint64_t m, int k) { return (int)((m >> (16 * k + 15)) & 1); }
 
 // sample (stripe-row r, column c, row-in-stripe k) has just become significant with sign `neg`:
 // publish it to every flag word whose neighbourhood contains it.  `own` is word (r, c) held in a register.
+// `nxt` is the already-fetched copy of word (r, c+1): it receives the same update (forwarding).
 template <class Store>
-T1HD void t1_set_sig(Store& S, int r, int c, uint32_t& own, int k, int neg) {
+T1HD void t1_set_sig(Store& S, int r, int c, uint32_t& own, uint32_t& nxt, int k, int neg) {
   own |= (1u << (3 * (k + 1) + 1)) | ((uint32_t)neg << (T1_CHI_SHIFT + k + 1));
   S.orr(r, c - 1, 1u << (3 * (k + 1) + 2));
   S.orr(r, c + 1, 1u << (3 * (k + 1) + 0));
+  nxt |= 1u << (3 * (k + 1) + 0);
   if (k == 0) {  // also row 4 (index 5) of the stripe above
     S.orr(r - 1, c, (1u << 16) | ((uint32_t)neg << (T1_CHI_SHIFT + 5)));
     S.orr(r - 1, c - 1, 1u << 17);
@@ -190,9 +203,10 @@ T1HD void t1_set_sig(Store& S, int r, int c, uint32_t& own, int k, int neg) {
   }
 }
 // sign coding (T.800 D.3.2, Tables D.2/D.3).  `K.sym(cx, d)` consumes one binary decision.
-template <class Store, class Sink>
-T1HD void t1_code_sign(Sink& K, Store& S, int r, int c, uint32_t own, int k, int neg) {
-  uint32_t l = S.ld(r, c - 1), rr = S.ld(r, c + 1);
+// l / rr: the flag words of the left / right neighbour columns (already in registers: the previous column's
+// final word and the prefetched next one), own: this column's word.
+template <class Sink>
+T1HD void t1_code_sign(Sink& K, uint32_t l, uint32_t rr, uint32_t own, int k, int neg) {
   int nb = (own >> (3 * k)) & 0x1FF;
   int hc = 0, vc = 0;
   if (nb & (1 << 3)) hc += ((l >> (T1_CHI_SHIFT + k + 1)) & 1) ? -1 : 1;
@@ -228,15 +242,26 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
   for (int s = 0; s < nstripes; s++) {
     S.stripe_begin(s, nstripes);
     const int r = s + 1;
+    const bool row_on = lane_pass && 4 * s < h;
+    // software pipeline: the flag word and magnitudes of column x+1 are fetched while column x is coded
+    uint32_t fpre = 0, fprv = 0;  // fprv: the previous column's word as it was left (apron word for x = 0)
+    uint64_t mpre = 0;
+    if (row_on && 0 < w) { fpre = S.ld(r, 1); mpre = S.mag(s, 0); }
     for (int x = 0; x < wmax; x++) {
-      const bool on = lane_pass && x < w && 4 * s < h;
-      if (!on) continue;
+      const bool on = row_on && x < w;
       const int c = x + 1;
-      uint32_t f = S.ld(r, c);
+      uint32_t f = fpre;
+      uint32_t mlo = (uint32_t)mpre, mhi = (uint32_t)(mpre >> 32);
+      T1_PIN32(f); T1_PIN32(mlo); T1_PIN32(mhi);
+      const uint64_t m = (uint64_t)mlo | ((uint64_t)mhi << 32);
+      uint32_t fnx = 0;
+      uint64_t mnx = 0;
+      if (row_on && x + 1 < w) { fnx = S.ld(r, c + 1); mnx = S.mag(s, x + 1); }
       const uint32_t f0 = f;
+      do {  // one stripe column (break = nothing (more) to code here)
+      if (!on) break;
       if (pass == 0) {
-        if ((f & T1_SIG_ALL) == 0) continue;
-        uint64_t m = S.mag(s, x);
+        if ((f & T1_SIG_ALL) == 0) break;
         for (int k = 0; k < 4 && 4 * s + k < h; k++) {
           int nb = (f >> (3 * k)) & 0x1FF;
           if ((nb & 0x10) || (nb & 0x1EF) == 0) continue;
@@ -244,8 +269,8 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
           K.sym(zc[nb & 0x1EF], bit);
           if (bit) {
             int neg = t1_neg(m, k);
-            t1_code_sign(K, S, r, c, f, k, neg);
-            t1_set_sig(S, r, c, f, k, neg);
+            t1_code_sign(K, fprv, fnx, f, k, neg);
+            t1_set_sig(S, r, c, f, fnx, k, neg);
             if (want_dist) dist += t1_dist_sig(mag, p);
           }
           f |= 1u << (T1_PI_SHIFT + k);
@@ -253,8 +278,7 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
       } else if (pass == 1) {
         uint32_t own = ((f >> 4) & 1) | ((f >> 6) & 2) | ((f >> 8) & 4) | ((f >> 10) & 8);  // sigma of rows 0..3
         uint32_t todo = own & ~(f >> T1_PI_SHIFT) & 0xF;
-        if (!todo) continue;
-        uint64_t m = S.mag(s, x);
+        if (!todo) break;
         for (int k = 0; k < 4; k++) {
           if (!((todo >> k) & 1)) continue;
           int nb = (f >> (3 * k)) & 0x1FF;
@@ -269,7 +293,6 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
         uint32_t done = (own | (f >> T1_PI_SHIFT)) & 0xF;
         int rows = h - 4 * s; if (rows > 4) rows = 4;
         if (done != 0xF || rows < 4) {
-          uint64_t m = S.mag(s, x);
           int k = 0;
           if (rows == 4 && (f & (T1_SIG_ALL | (0xFu << T1_PI_SHIFT))) == 0) {  // run-length mode
             int b0 = (t1_mag(m, 0) >> p) & 1, b1 = (t1_mag(m, 1) >> p) & 1, b2 = (t1_mag(m, 2) >> p) & 1, b3 = (t1_mag(m, 3) >> p) & 1;
@@ -280,8 +303,8 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
               K.sym(T1_CTX_UNI, fk >> 1);
               K.sym(T1_CTX_UNI, fk & 1);
               int neg = t1_neg(m, fk);
-              t1_code_sign(K, S, r, c, f, fk, neg);
-              t1_set_sig(S, r, c, f, fk, neg);
+              t1_code_sign(K, fprv, fnx, f, fk, neg);
+              t1_set_sig(S, r, c, f, fnx, fk, neg);
               if (want_dist) dist += t1_dist_sig(t1_mag(m, fk), p);
               k = fk + 1;
             }
@@ -293,15 +316,18 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
             K.sym(zc[nb & 0x1EF], bit);
             if (bit) {
               int neg = t1_neg(m, k);
-              t1_code_sign(K, S, r, c, f, k, neg);
-              t1_set_sig(S, r, c, f, k, neg);
+              t1_code_sign(K, fprv, fnx, f, k, neg);
+              t1_set_sig(S, r, c, f, fnx, k, neg);
               if (want_dist) dist += t1_dist_sig(mag, p);
             }
           }
         }
         f &= ~(0xFu << T1_PI_SHIFT);  // the "visited" marks last one bit-plane
       }
+      } while (0);
       if (f != f0) S.st(r, c, f);
+      fprv = f;
+      fpre = fnx; mpre = mnx;  // includes whatever this column forwarded into its right neighbour
     }
     S.stripe_end(s);
   }

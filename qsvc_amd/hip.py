@@ -225,8 +225,9 @@ class Engine:
         o = list(offs)
         return [out[o[k]:o[k + 1]].tobytes() for k in range(3 * count)]
 
-    def j2k_encode_multi(self, items):
-        """items: [(kind, t, first, count, J2kParams)] -> list (per item) of lists of code-streams, one batch on the GPU."""
+    def j2k_encode_multi(self, items, copy=True):
+        """items: [(kind, t, first, count, J2kParams)] -> list (per item) of lists of code-streams, one batch on the GPU.
+        copy=False returns memoryviews into a buffer owned by the engine, valid until its next j2k call."""
         items = [it for it in items if it[3] > 0]
         n = len(items)
         if n == 0:
@@ -245,7 +246,11 @@ class Engine:
         o = list(offs)
         res, k = [], 0
         for it in items:
-            res.append([out[o[k + j]:o[k + j + 1]].tobytes() for j in range(3 * it[3])])
+            if copy:
+                res.append([out[o[k + j]:o[k + j + 1]].tobytes() for j in range(3 * it[3])])
+            else:
+                mv = memoryview(out)
+                res.append([mv[o[k + j]:o[k + j + 1]] for j in range(3 * it[3])])
             k += 3 * it[3]
         return res
 

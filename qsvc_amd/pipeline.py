@@ -82,10 +82,10 @@ class Compressor:
         items.append((LOW, T, low_first, nlow - low_first, self.j2k_params_for(0)))
         return items
 
-    def texture(self, low_first=0):
-        """-> {(kind, t): [code-stream bytes per (picture, component)]}"""
+    def texture(self, low_first=0, copy=True):
+        """-> {(kind, t): [code-stream per (picture, component)]}; copy=False: views valid until the next call."""
         items = [it for it in self.texture_items(low_first) if it[3] > 0]
-        streams = self.e.j2k_encode_multi(items)  # one batch: every subband picture of the sequence
+        streams = self.e.j2k_encode_multi(items, copy=copy)  # one batch: every subband picture of the sequence
         return {(it[0], it[1]): s for it, s in zip(items, streams)}
 
     def compress(self):
