@@ -76,10 +76,56 @@ __global__ void __launch_bounds__(256) k_pred_luma(PredArgs a) {
   if (h[0][tid]) atomicAdd(&gh[tid], h[0][tid]);
   if (h[1][tid]) atomicAdd(&gh[256 + tid], h[1][tid]);
 }
+// Chroma: a 32x8 tile of half-resolution outputs per workgroup.  The full-resolution prediction the tile's
+// chroma/2 analysis needs (rows 2j-2..2j+2, columns 2i-2..2i+2: 20 x 68 samples) is evaluated ONCE into LDS,
+// then the row pass (20 x 32 lows) and the column pass run out of LDS.  Same per-sample functions as
+// pred_chroma_thread (mctf_threads.h), 5x fewer interpolated-chroma evaluations per output.
+#define PC_TW 32
+#define PC_TH 8
+#define PC_FW (2 * PC_TW + 4)
+#define PC_FH (2 * PC_TH + 4)
 __global__ void __launch_bounds__(256) k_pred_chroma(PredArgs a) {
-  int ci = blockIdx.x * 64 + threadIdx.x, cj = blockIdx.y * 4 + threadIdx.y;
-  int i = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
-  if (ci < a.g.W / 2 && cj < a.g.H / 2) pred_chroma_thread(a, ci, cj, i, c);
+  __shared__ int16_t sP[PC_FH][PC_FW];
+  __shared__ int16_t sL[PC_FH][PC_TW];
+  const LevelGeom& g = a.g;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int i = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
+  const int i0 = blockIdx.x * PC_TW, j0 = blockIdx.y * PC_TH;
+  const int cw = g.W / 2, chh = g.H / 2;
+  const int xb = 2 * i0 - 2, yb = 2 * j0 - 2;  // full-resolution origin of the footprint (may be -2)
+  BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+  MvField mv = {a.mv + (size_t)i * 4 * g.BY * g.BX, g.BY, g.BX};
+  const uint8_t* u0 = frame_c(a.frames, g, 2 * i, c);
+  const uint8_t* u1 = frame_c(a.frames, g, 2 * i + 2, c);
+  for (int k = tid; k < PC_FH * PC_FW; k += 256) {
+    int yy = yb + k / PC_FW, xx = xb + k % PC_FW;
+    int v = 0;
+    if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) v = predict_chroma_full(u0, u1, bg, mv, g.bs, yy, xx);
+    sP[k / PC_FW][k % PC_FW] = (int16_t)v;
+  }
+  __syncthreads();
+  for (int k = tid; k < PC_FH * PC_TW; k += 256) {
+    int ry = k / PC_TW, ci = i0 + k % PC_TW;
+    int yy = yb + ry;
+    int v = 0;
+    if (yy >= 0 && yy < g.H && ci < cw) {
+      auto row = [&](int xx) { return (int)sP[ry][xx - xb]; };
+      v = a53_low(row, ci, g.W);
+    }
+    sL[ry][k % PC_TW] = (int16_t)v;
+  }
+  __syncthreads();
+  const int ci = i0 + (tid & (PC_TW - 1)), cj = j0 + tid / PC_TW;
+  if (ci < cw && cj < chh) {
+    const int lx = tid & (PC_TW - 1);
+    auto col = [&](int yy) { return (int)sL[yy - yb][lx]; };
+    int ll = (int16_t)a53_low(col, cj, g.H);
+    int o = frame_c(a.frames, g, 2 * i + 1, c)[(size_t)cj * cw + ci];
+    int val = iclamp(o - ll, -128, 127);
+    size_t off = (size_t)i * g.F + (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh + (size_t)cj * cw + ci;
+    a.high[off] = (uint8_t)(val + 128);
+    if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;
+  }
 }
 // histogram of the motion components + 128 (decorrelate.cpp:805-812)
 __global__ void __launch_bounds__(256) k_mv_hist(const int16_t* mv, size_t per_pic, unsigned* hist) {
@@ -98,7 +144,7 @@ void launch_predict(hipStream_t st, const PredArgs& a) {
   hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
   dim3 block(64, 4);
   hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);
-  hipLaunchKernelGGL(k_pred_chroma, dim3((g.W / 2 + 63) / 64, (g.H / 2 + 3) / 4, g.nB * 2), block, 0, st, a);
+  hipLaunchKernelGGL(k_pred_chroma, dim3((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, g.nB * 2), block, 0, st, a);
   size_t per_pic = (size_t)4 * g.BY * g.BX;
   int nblk = (int)((per_pic + 255) / 256);
   if (nblk > 64) nblk = 64;
@@ -111,16 +157,65 @@ __global__ void __launch_bounds__(256) k_upd_luma(UpdArgs a) {
   int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
   if (x < a.g.W && y < a.g.H) upd_luma_thread(a, x, y, j);
 }
+// Chroma: same 32x8 tiling as k_pred_chroma.  Tiles out of reach of the top-left quadrant (Q3) or without any
+// contributing B picture are a plain copy; otherwise the updated full-resolution samples of the footprint are
+// gathered once into LDS and the chroma/2 analysis runs out of LDS.
 __global__ void __launch_bounds__(256) k_upd_chroma(UpdArgs a) {
-  int ci = blockIdx.x * 64 + threadIdx.x, cj = blockIdx.y * 4 + threadIdx.y;
-  int j = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
-  if (ci < a.g.W / 2 && cj < a.g.H / 2) upd_chroma_thread(a, ci, cj, j, c);
+  __shared__ int16_t sP[PC_FH][PC_FW];
+  __shared__ int16_t sL[PC_FH][PC_TW];
+  const LevelGeom& g = a.g;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int j = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
+  const int i0 = blockIdx.x * PC_TW, j0 = blockIdx.y * PC_TH;
+  const int cw = g.W / 2, chh = g.H / 2;
+  const int xb = 2 * i0 - 2, yb = 2 * j0 - 2;
+  const uint8_t* u = frame_c(a.frames, g, 2 * j, c);
+  const size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh;
+  UpdSide s[2];
+  upd_sides(a, j, s);
+  const int ci = i0 + (tid & (PC_TW - 1)), cj = j0 + tid / PC_TW;
+  const bool untouched = (!s[0].high && !s[1].high) || yb >= chh + a.reach || xb >= cw + a.reach;  // wave-uniform
+  if (untouched) {
+    if (ci < cw && cj < chh) a.low[(size_t)j * g.F + coff + (size_t)cj * cw + ci] = u[(size_t)cj * cw + ci];
+    return;
+  }
+  for (int k = tid; k < PC_FH * PC_FW; k += 256) {
+    int yy = yb + k / PC_FW, xx = xb + k % PC_FW;
+    int v = 0;
+    if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
+      v = chroma_up(u, yy, xx, g.H, g.W);
+      for (int q = 0; q < 2; q++)
+        if (s[q].high) {
+          const uint8_t* h = s[q].high + coff;
+          auto R = [&](int sy, int sx) { return (int)h[(size_t)sy * cw + sx] - 128; };
+          v = update_gather(v, R, s[q].mvx, s[q].mvy, g.BY, g.BX, g.bs, g.H, g.W, chh, cw, a.reach, yy, xx, a.uf);
+        }
+    }
+    sP[k / PC_FW][k % PC_FW] = (int16_t)v;
+  }
+  __syncthreads();
+  for (int k = tid; k < PC_FH * PC_TW; k += 256) {
+    int ry = k / PC_TW, cx = i0 + k % PC_TW;
+    int yy = yb + ry;
+    int v = 0;
+    if (yy >= 0 && yy < g.H && cx < cw) {
+      auto row = [&](int xx) { return (int)sP[ry][xx - xb]; };
+      v = a53_low(row, cx, g.W);
+    }
+    sL[ry][k % PC_TW] = (int16_t)v;
+  }
+  __syncthreads();
+  if (ci < cw && cj < chh) {
+    const int lx = tid & (PC_TW - 1);
+    auto col = [&](int yy) { return (int)sL[yy - yb][lx]; };
+    a.low[(size_t)j * g.F + coff + (size_t)cj * cw + ci] = (uint8_t)(int16_t)a53_low(col, cj, g.H);
+  }
 }
 void launch_update(hipStream_t st, const UpdArgs& a) {
   const LevelGeom& g = a.g;
   dim3 block(64, 4);
   hipLaunchKernelGGL(k_upd_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB + 1), block, 0, st, a);
-  hipLaunchKernelGGL(k_upd_chroma, dim3((g.W / 2 + 63) / 64, (g.H / 2 + 3) / 4, (g.nB + 1) * 2), block, 0, st, a);
+  hipLaunchKernelGGL(k_upd_chroma, dim3((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, (g.nB + 1) * 2), block, 0, st, a);
 }
 
 // max |component| of a motion buffer -> *out (int, pre-zeroed)
