@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 W, H, TRLS, GOPS, BS, S0, SRLS = 1920, 1080, 4, 2, 8, 4, 5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_FILE = "r01_v1_pmc_hbm.json"
 
 
 def log(*a):
@@ -207,8 +208,18 @@ def main():
         if dom and dom in alg:
             launches = max(per[dom]["launches_per_step"], 1)
             a = gbs(alg[dom], dom)
+            traffic = None
+            try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+                kname = {"j2k_t1_mq": "k_t1_mq<4>", "j2k_t1_cm": "k_t1_cm<64>", "j2k_t1_encode": "k_t1_encode<8>"}.get(dom)
+                if kname in pmc:
+                    traffic = pmc[kname]["hbm_bytes_per_launch_raw"]
+            except Exception:
+                pass
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(a, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 6), "traffic": None,
+                    "frac": round(a / HBM_PEAK_GBS, 6), "traffic": traffic,
+                    "traffic_source": ("profiles/" + PMC_FILE + " (FETCH_SIZE+WRITE_SIZE, KiB->bytes, raw: FETCH_SIZE is "
+                                       "uncalibrated for this kernel's 16-byte-per-lane gathers)") if traffic else None,
                     "launch_ms": round(per[dom]["ms_per_step"] / launches, 4),
                     "algorithmic_bytes_per_launch": int(alg[dom] / launches),
                     "note": "EBCOT Tier-1 is serial-dependency bound, not HBM bound (SURVEY.md H4/8d); fraction quoted for completeness"

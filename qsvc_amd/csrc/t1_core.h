@@ -144,8 +144,11 @@ T1HD int t1_clz32(uint32_t v) {
 //   MPS, A < 0x8000 .............. conditional exchange (A < Qe: A = Qe, else C += Qe), next = NMPS, renormalise
 //   LPS .......................... conditional exchange (A < Qe: C += Qe, else A = Qe), MPS flips on SWITCH,
 //                                  next = NLPS, renormalise
-T1HD void mq_encode(T1Lane& t, int cx, int d) {
-  const uint32_t e = t.cx[cx * t.cs];
+// `e` is the context's packed state, already fetched by the caller (so the fetch for the NEXT decision can be in
+// flight while this one is coded); both successor entries are fetched up front, off the dependent chain.
+// Returns the context's new packed state (also stored).
+T1HD uint32_t mq_encode_e(T1Lane& t, int cx, int d, uint32_t e) {
+  const uint32_t tm = t.mqtab[(e >> 16) & 63], tl = t.mqtab[(e >> 22) & 63];
   const uint32_t qe = e & 0xFFFF;
   uint32_t mps = (e >> 29) & 1;
   t.nsym++;
@@ -159,16 +162,18 @@ T1HD void mq_encode(T1Lane& t, int cx, int d) {
   t.C += addc ? qe : 0;
   A = seta ? qe : A;
   if (ren) {
-    const uint32_t nidx = ismps ? (e >> 16) & 63 : (e >> 22) & 63;
     mps ^= ismps ? 0u : (e >> 28) & 1;
-    t.cx[cx * t.cs] = t.mqtab[nidx] | (mps << 29);
+    e = (ismps ? tm : tl) | (mps << 29);
+    t.cx[cx * t.cs] = e;
     int sh = t1_clz32(A) - 16;  // A is in [1, 0x7FFF]: bring it back to bit 15 in one step
     A <<= sh;
     while (sh >= t.CT) { t.C <<= t.CT; sh -= t.CT; mq_byteout(t); }  // a byte leaves whenever CT bits have gone
     t.C <<= sh; t.CT -= sh;
   }
   t.A = A;
+  return e;
 }
+T1HD void mq_encode(T1Lane& t, int cx, int d) { (void)mq_encode_e(t, cx, d, t.cx[cx * t.cs]); }
 T1HD int mq_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment length
   uint32_t tempc = t.C + t.A;
   t.C |= 0xFFFF;
