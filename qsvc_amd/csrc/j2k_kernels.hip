@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(CML) k_t1_cm(const int* waves, const CbDesc* c
 template <int T1_MQ_LANES>
 __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
                                                         const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf,
-                                                        int outcap, CbOut* res, int* pass_len, long long* pass_dist, int dbg) {
+                                                        int outcap, CbOut* res, int* pass_len, long long* pass_dist) {
   __shared__ uint32_t s_cx[19 * T1_MQ_LANES];
   __shared__ uint32_t s_mq[64];
   int lane = threadIdx.x, b = blockIdx.x * T1_MQ_LANES + lane;
@@ -447,24 +447,14 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
         // divergent stores in between, waits vmcnt(0) at the first use of `cur` and so also for the prefetch.
         asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w)::"memory");
         uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (i + 16 < n && dbg != 2) nxt = sg[(i >> 4) + 1];  // next 16 decisions in flight while these are coded
+        if (i + 16 < n) nxt = sg[(i >> 4) + 1];  // next 16 decisions in flight while these are coded
         uint32_t wds[4] = {cur.x, cur.y, cur.z, cur.w};
-        // software pipeline over the decisions of the chunk: the context state of decision j+1 is fetched from
-        // LDS before decision j is coded (and patched if both use the same context)
-        uint32_t e_cur = t.cx[(wds[0] & 31) * t.cs];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-          const int v = (wds[j >> 2] >> (8 * (j & 3))) & 0xFF;
-          const int vn = j < 15 ? (wds[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFF : 0;
-          uint32_t e_next = j < 15 ? t.cx[(vn & 31) * t.cs] : 0;
           if (i + j < n) {
-            if (dbg == 1) { t.C += v; t.nsym++; }  // timing experiment: stream traffic and loop overhead only
-            else {
-              uint32_t e_new = mq_encode_e(t, v & 31, v >> 5, e_cur);
-              if ((vn & 31) == (v & 31)) e_next = e_new;
-            }
+            const int v = (wds[j >> 2] >> (8 * (j & 3))) & 0xFF;
+            mq_encode(t, v & 31, v >> 5);
           }
-          e_cur = e_next;
         }
         cur = nxt;
       }
@@ -492,11 +482,10 @@ void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc*
     else if (cl == 32) hipLaunchKernelGGL(k_t1_cm<32>, dim3(nwaves, 2), dim3(32), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
     else hipLaunchKernelGGL(k_t1_cm<64>, dim3(nwaves, 1), dim3(64), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
   } else {
-    static const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 4; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 4; }();
+    static const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 16; return (v == 4 || v == 8 || v == 32 || v == 64) ? v : 16; }();
     long long* pdp = want_dist ? pass_dist : nullptr;
-    static const int dbg = [] { const char* e = getenv("QSVC_MQ_DEBUG"); return e ? atoi(e) : 0; }();
-#define MQ_LAUNCH(N) hipLaunchKernelGGL(k_t1_mq<N>, dim3((ncb + N - 1) / N), dim3(N), 0, st, cbs, ncb, nbps, joboff, segs, cnt, dist, outbuf, outcap, res, pass_len, pdp, dbg)
-    switch (ml) { case 8: MQ_LAUNCH(8); break; case 16: MQ_LAUNCH(16); break; case 32: MQ_LAUNCH(32); break; case 64: MQ_LAUNCH(64); break; default: MQ_LAUNCH(4); }
+#define MQ_LAUNCH(N) hipLaunchKernelGGL(k_t1_mq<N>, dim3((ncb + N - 1) / N), dim3(N), 0, st, cbs, ncb, nbps, joboff, segs, cnt, dist, outbuf, outcap, res, pass_len, pdp)
+    switch (ml) { case 4: MQ_LAUNCH(4); break; case 8: MQ_LAUNCH(8); break; case 32: MQ_LAUNCH(32); break; case 64: MQ_LAUNCH(64); break; default: MQ_LAUNCH(16); }
 #undef MQ_LAUNCH
   }
 }

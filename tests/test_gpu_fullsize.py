@@ -1,0 +1,94 @@
+"""GPU: BASELINE.json's full-size configurations, checked through size-independent properties (the oracle is
+only run on bounded sub-problems): lossless round trips through an independent decoder, shard == whole,
+determinism, known motion of a synthetic pan, 9/7 PSNR."""
+import numpy as np
+import pytest
+
+from qsvc_amd.synth import make_clip
+
+pytestmark = pytest.mark.gpu
+J = pytest.importorskip("oracle.j2k")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from qsvc_amd import hip
+    e = hip.Engine(0)
+    yield e
+    e.close()
+
+
+def planes_of(frame, W, H):
+    return (frame[:W * H].reshape(H, W), frame[W * H:W * H + W * H // 4].reshape(H // 2, W // 2),
+            frame[W * H + W * H // 4:].reshape(H // 2, W // 2))
+
+
+def test_config3_1080p_gop16_three_levels(eng, oracle):
+    """1920x1080, 17 pictures, TRLs=4, block 8, search 4/8/16, lossless 5/3 + EBCOT of every subband picture."""
+    from qsvc_amd import hip
+    from qsvc_amd.pipeline import CompressParams, Compressor
+    W, H = 1920, 1080
+    clip = make_clip("pan", 17, W, H, 42)
+    comp = Compressor(eng, CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=4, GOPs=2, block_size=8, block_size_min=8, SRLs=5, lossless=True))
+    comp.configure(); comp.load(clip)
+    out = comp.compress()
+    assert sorted(len(v) for v in out.values()) == [6, 9, 12, 24]         # high_3, low_3, high_2, high_1 (x3 components)
+    assert eng.j2k_stats()["codeblocks"] == 17 * 921
+    # the synthetic pan shows texture[t+y, 2t+x]: picture t equals picture t-1 displaced by (+1,+2), t+1 by (-1,-2)
+    mv = eng.get_motion(hip.MOTION_RAW, 1, 8, 8)
+    inner = mv[:, :, 8:-8, 8:-8]
+    for k, want in enumerate((2, 1, -2, -1)):  # PREV-X, PREV-Y, NEXT-X, NEXT-Y
+        assert (inner[:, k] == want).mean() > 0.97
+    # every code-stream decodes (independent decoder) to the subband picture it was made from: sample a few
+    for (kind, t), idx in (((hip.HIGH, 1), 5), ((hip.HIGH, 3), 1), ((hip.LOW, 3), 2)):
+        n = {(hip.HIGH, 1): 8, (hip.HIGH, 3): 2, (hip.LOW, 3): 3}[(kind, t)]
+        f = eng.get_frames(kind, t, 0, n)[idx]
+        for c, pl in enumerate(planes_of(f, W, H)):
+            np.testing.assert_array_equal(J.decode(out[(kind, t)][3 * idx + c]), pl)
+    # level 1 of the first 5 pictures == oracle (update of picture 2 only depends on B pictures 1 and 3)
+    want = oracle.analyze_step(clip[:5], W, H, 8, 4)
+    np.testing.assert_array_equal(eng.get_frames(hip.HIGH, 1, 0, 2), want["high"])
+    np.testing.assert_array_equal(eng.get_frames(hip.LOW, 1, 0, 2), want["low"][:2])
+    # determinism: a second run gives the same bytes
+    out2 = comp.compress()
+    assert all(out[k] == out2[k] for k in out)
+
+
+def test_config4_4k_gop32_97(eng, oracle):
+    """3840x2160, 33 pictures, TRLs=5 (search 4..32), block 16, 9/7 irreversible, 5 spatial levels."""
+    from qsvc_amd import hip
+    from qsvc_amd.pipeline import CompressParams, Compressor
+    W, H = 3840, 2160
+    clip = make_clip("pan_noise", 33, W, H, 43)
+    comp = Compressor(eng, CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=5, GOPs=2, block_size=16, block_size_min=16, SRLs=6,
+                                          nLayers=1, reversible=False))
+    comp.configure(); comp.load(clip)
+    out = comp.compress()
+    assert sum(len(v) for v in out.values()) == 33 * 3
+    assert eng.j2k_stats()["codeblocks"] == 33 * 3261
+    types = b"".join(eng.get_frame_types(t, n) for t, n in ((1, 16), (2, 8), (3, 4), (4, 2)))
+    assert set(types) <= {ord("I"), ord("B")}
+    low = eng.get_frames(hip.LOW, 4, 0, 3)[1]
+    for c, pl in enumerate(planes_of(low, W, H)):
+        assert J.psnr(J.decode(out[(hip.LOW, 4)][3 + c]), pl) > 50
+    # bounded oracle comparison: level 1 on the first 3 pictures (one B picture; its high picture needs nothing else)
+    want = oracle.analyze_step(clip[:3], W, H, 16, 4)
+    np.testing.assert_array_equal(eng.get_motion(hip.MOTION_RAW, 1, 16, 16)[0], want["motion"][0])
+    np.testing.assert_array_equal(eng.get_frames(hip.HIGH, 1, 0, 1), want["high"])
+
+
+def test_config5_8k_one_gop_shard(eng):
+    """One GPU's shard of the 8K configuration: 7680x4320, 9 pictures (one GOP of 8 + shared boundary), TRLs=4, block 32."""
+    from qsvc_amd import hip
+    from qsvc_amd.pipeline import CompressParams, Compressor
+    W, H = 7680, 4320
+    clip = make_clip("pan", 9, W, H, 42)
+    comp = Compressor(eng, CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=4, GOPs=1, block_size=32, block_size_min=32, SRLs=5, lossless=True))
+    comp.configure(); comp.load(clip)
+    out = comp.compress()
+    assert sum(len(v) for v in out.values()) == 9 * 3
+    assert eng.j2k_stats()["codeblocks"] == 9 * 12421
+    f = eng.get_frames(hip.HIGH, 2, 0, 2)[1]
+    np.testing.assert_array_equal(J.decode(out[(hip.HIGH, 2)][3 + 1]), planes_of(f, W, H)[1])   # a 3840x2160 chroma plane, lossless
+    mv = eng.get_motion(hip.MOTION_RAW, 1, 4, 32)
+    assert (mv[:, 0, 2:-2, 2:-2] == 2).mean() > 0.97 and (mv[:, 3, 2:-2, 2:-2] == -1).mean() > 0.97
