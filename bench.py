@@ -108,29 +108,49 @@ def main():
     if world > 1:
         import torch  # noqa: F401  (CPU only: rendezvous, barrier, max-reduce)
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo's C++ side prints "[Gloo] Rank ... connected" on fd 1: keep stdout clean for the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import numpy as np
     from qsvc_amd import hip, sharding
     from qsvc_amd.pipeline import CompressParams, Compressor
     from qsvc_amd.synth import make_clip
 
-    eng = hip.Engine(local if world > 1 else 0)
+    dev = os.environ.get("QSVC_BENCH_DEVICE")  # test hook: several ranks on one GPU (forces the host-staged exchange)
+    eng = hip.Engine(int(dev) if dev is not None else (local if world > 1 else 0))
     exchange, exchange_kind = None, "none"
     if world > 1:
         import torch
-        try:  # RCCL over xGMI; the id travels through gloo
-            uid = [hip.Engine.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            exchange = sharding.RcclExchange(eng, rank, world, uid[0])
-            exchange_kind = "rccl"
-        except Exception as ex:  # transport fallback only (never a compute fallback)
-            log(f"[rank {rank}] RCCL unavailable ({ex}); halo records go host-staged over gloo")
-            exchange = sharding.HostExchange(dist, rank, world)
-            exchange_kind = "gloo-host"
-        flag = torch.tensor([1 if exchange_kind == "rccl" else 0])
+        # RCCL over xGMI; the id travels through gloo.  Every rank takes the same branch at every step, so a failure
+        # anywhere degrades ALL ranks to the host-staged transport (a transport fallback, never a compute fallback).
+        uid = [None]
+        if rank == 0 and dev is None and os.environ.get("QSVC_EXCHANGE", "rccl") == "rccl":
+            try:
+                uid = [hip.Engine.comm_unique_id()]
+            except Exception as ex:
+                log(f"[rank 0] RCCL unavailable ({ex})")
+        dist.broadcast_object_list(uid, src=0)
+        ok = 0
+        if uid[0] is not None:
+            try:
+                exchange = sharding.RcclExchange(eng, rank, world, uid[0])
+                ok = 1
+            except Exception as ex:
+                log(f"[rank {rank}] qsvc_comm_init failed ({ex})")
+        flag = torch.tensor([ok])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() == 0 and exchange_kind == "rccl":
+        if flag.item() == 1:
+            exchange_kind = "rccl"
+        else:
             exchange = sharding.HostExchange(dist, rank, world)
             exchange_kind = "gloo-host"
 
