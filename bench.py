@@ -101,6 +101,11 @@ def main():
     ap.add_argument("--sessions", type=int, default=4, help="extra (N=1 only): throughput with this many encoder contexts in flight")
     args = ap.parse_args()
 
+    # Native libraries (gloo, RCCL) print banners on fd 1; stdout must carry exactly ONE JSON line, so fd 1 points at
+    # stderr until the result is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,17 +113,8 @@ def main():
     if world > 1:
         import torch  # noqa: F401  (CPU only: rendezvous, barrier, max-reduce)
         import torch.distributed as dist
-        # gloo's C++ side prints "[Gloo] Rank ... connected" on fd 1: keep stdout clean for the ONE JSON line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
 
     import numpy as np
     from qsvc_amd import hip, sharding
@@ -265,7 +261,10 @@ def main():
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as ex:  # the baseline is a reported extra; never fail the GPU measurement on it
                 line["cpu_baseline"] = {"error": repr(ex)}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -451,8 +451,10 @@ struct Rccl {
 static Rccl g_rccl;
 static const char* rccl_load() {
   if (g_rccl.h) return nullptr;
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  // absolute path first: a process that imported torch already holds torch's own (ROCm 7.0) librccl, which is bound
+  // to a different HIP runtime than this library's
+  void* h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!h) return dlerror();
 #define SYM(field, name) *(void**)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) return "missing symbol " name;
   SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
