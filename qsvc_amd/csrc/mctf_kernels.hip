@@ -32,33 +32,112 @@ void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int 
 // ---------------------------------------------------------------------------------------------
 // ME search: one wave per MC block; lanes split the block's pixels, 18 SADs reduced across the
 // wave with DPP-free xor shuffles (64 lanes).
-template <class T>
+// LPB = lanes per MC block: 64 (one block per wave) or 16 (four 8x8 blocks per wave, 4 pixels per lane: the
+// xor-shuffle reduction then needs 4 steps instead of 6 and serves four blocks at once).
+template <class T, int LPB>
 __global__ void __launch_bounds__(64) k_me_search(MeArgs a) {
-  int bx = blockIdx.x, by = blockIdx.y, i = blockIdx.z;
-  int lane = threadIdx.x;
+  const int sub = threadIdx.x / LPB, lane = threadIdx.x % LPB;
+  const int bx = blockIdx.x * (64 / LPB) + sub, by = blockIdx.y, i = blockIdx.z;
+  const bool live = bx < a.nbx;
   MePlane<T> r0, r1, pr;
   me_block_setup<T>(a, i, r0, r1, pr);
-  int pvx, pvy, nvx, nvy;
-  me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
+  int pvx = 0, pvy = 0, nvx = 0, nvy = 0;
   int sad[18];
-  me_block_sads<T>(r0, r1, pr, a.g.bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad);
+  if (live) {
+    me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
+    me_block_sads<T>(r0, r1, pr, a.g.bs, by, bx, pvy, pvx, nvy, nvx, lane, LPB, sad);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 18; k++) sad[k] = 0;
+  }
 #pragma unroll
   for (int k = 0; k < 18; k++) {
     int v = sad[k];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = LPB / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     sad[k] = v;
   }
-  if (lane == 0) me_block_store(a, i, by, bx, sad, pvx, pvy, nvx, nvy);
+  if (live && lane == 0) me_block_store(a, i, by, bx, sad, pvx, pvy, nvx, nvy);
 }
 void launch_me_search(hipStream_t st, const MeArgs& a) {
-  dim3 grid(a.nbx, a.nby, a.g.nB), block(64);
-  if (a.l == 0) hipLaunchKernelGGL(k_me_search<uint8_t>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(k_me_search<int16_t>, grid, block, 0, st, a);
+  dim3 block(64);
+  if (a.g.bs * a.g.bs <= 64) {
+    dim3 grid((a.nbx + 3) / 4, a.nby, a.g.nB);
+    if (a.l == 0) hipLaunchKernelGGL((k_me_search<uint8_t, 16>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_me_search<int16_t, 16>), grid, block, 0, st, a);
+  } else {
+    dim3 grid(a.nbx, a.nby, a.g.nB);
+    if (a.l == 0) hipLaunchKernelGGL((k_me_search<uint8_t, 64>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_me_search<int16_t, 64>), grid, block, 0, st, a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-// predict + residue, luma: thread per pixel, LDS histograms (odd picture, residue+128).
+// predict + residue, luma.  Fast form (block size a multiple of 8): a thread owns 8 consecutive pixels of one row --
+// they share one MC block, so the two displaced reference runs are two unaligned 8-byte loads when they lie inside
+// the picture (the common case); runs that touch the replicate border fall back to the per-pixel border rule
+// (Q1/Q2).  The odd picture is read and the high picture written 8 bytes at a time.  LDS histograms as before.
+__device__ __forceinline__ uint64_t ld8u(const uint8_t* p) {  // unaligned 8-byte load
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+__global__ void __launch_bounds__(256) k_pred_luma8(PredArgs a) {
+  __shared__ unsigned h[2][256];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  h[0][tid] = 0; h[1][tid] = 0;
+  __syncthreads();
+  const LevelGeom& g = a.g;
+  const int x = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+  if (x < g.W && y < g.H) {
+    const uint8_t* r0 = frame_y(a.frames, g, 2 * i);
+    const uint8_t* r1 = frame_y(a.frames, g, 2 * i + 2);
+    const uint8_t* od = frame_y(a.frames, g, 2 * i + 1) + (size_t)y * g.W + x;
+    const int by = y / g.bs, bx = x / g.bs;
+    const size_t fld = (size_t)g.BY * g.BX;
+    const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)by * g.BX + bx;
+    const int x0 = x + m[0], y0 = y + m[fld], x1 = x + m[2 * fld], y1 = y + m[3 * fld];
+    const int n = g.W - x < 8 ? g.W - x : 8;
+    uint8_t p0[8], p1[8], o[8];
+    if (n == 8 && y0 >= 0 && y0 < g.H && x0 >= 0 && x0 + 8 <= g.W) {
+      uint64_t v = ld8u(r0 + (size_t)y0 * g.W + x0);
+      __builtin_memcpy(p0, &v, 8);
+    } else {
+      BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+      for (int k = 0; k < 8; k++) p0[k] = (uint8_t)luma_b(r0, bg, y0, x0 + k);
+    }
+    if (n == 8 && y1 >= 0 && y1 < g.H && x1 >= 0 && x1 + 8 <= g.W) {
+      uint64_t v = ld8u(r1 + (size_t)y1 * g.W + x1);
+      __builtin_memcpy(p1, &v, 8);
+    } else {
+      BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+      for (int k = 0; k < 8; k++) p1[k] = (uint8_t)luma_b(r1, bg, y1, x1 + k);
+    }
+    if (n == 8) { uint64_t v = ld8u(od); __builtin_memcpy(o, &v, 8); }
+    else for (int k = 0; k < n; k++) o[k] = od[k];
+    uint8_t hi[8], pr[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int p = ((int)p0[k] + (int)p1[k]) >> 1;           // decorrelate.cpp:99-107 (both operands 0..255)
+      int val = iclamp((int)o[k] - p, -128, 127);        // decorrelate.cpp:920-929
+      hi[k] = (uint8_t)(val + 128); pr[k] = (uint8_t)p;
+      if (k < n) { atomicAdd(&h[0][o[k]], 1u); atomicAdd(&h[1][val + 128], 1u); }
+    }
+    const size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
+    if (n == 8) {
+      uint64_t v;
+      __builtin_memcpy(&v, hi, 8); __builtin_memcpy(a.high + off, &v, 8);
+      if (a.pred_dump) { __builtin_memcpy(&v, pr, 8); __builtin_memcpy(a.pred_dump + off, &v, 8); }
+    } else {
+      for (int k = 0; k < n; k++) { a.high[off + k] = hi[k]; if (a.pred_dump) a.pred_dump[off + k] = pr[k]; }
+    }
+  }
+  __syncthreads();
+  unsigned* gh = a.hist + (size_t)i * 3 * 256;
+  if (h[0][tid]) atomicAdd(&gh[tid], h[0][tid]);
+  if (h[1][tid]) atomicAdd(&gh[256 + tid], h[1][tid]);
+}
+// predict + residue, luma, general form: thread per pixel, LDS histograms (odd picture, residue+128).
 __global__ void __launch_bounds__(256) k_pred_luma(PredArgs a) {
   __shared__ unsigned h[2][256];
   int tid = threadIdx.y * 64 + threadIdx.x;
@@ -143,7 +222,8 @@ void launch_predict(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
   hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
   dim3 block(64, 4);
-  hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);
+  if (g.bs % 8 == 0) hipLaunchKernelGGL(k_pred_luma8, dim3((g.W + 511) / 512, (g.H + 3) / 4, g.nB), block, 0, st, a);
+  else hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);
   hipLaunchKernelGGL(k_pred_chroma, dim3((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, g.nB * 2), block, 0, st, a);
   size_t per_pic = (size_t)4 * g.BY * g.BX;
   int nblk = (int)((per_pic + 255) / 256);

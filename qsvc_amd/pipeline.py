@@ -31,6 +31,7 @@ class CompressParams:  # defaults of compress.py:57-106
     reversible: bool = False       # build extension: the reference hard-codes Creversible=no
     lossless: bool = False         # build extension: one layer, every coding pass (ignores the slopes)
     base_step: float = 1.0 / 256
+    cblk: int = 64                 # code-block size (Kakadu default Cblk={64,64}); 32 is a valid, faster alternative
 
     def resolve(self):
         d = schedule.default_block_size(self.pixels_in_x, self.pixels_in_y)
@@ -68,9 +69,9 @@ class Compressor:
     def j2k_params_for(self, subband_index):
         """subband_index into the slope table: 0 = L, k = H_{TRLs-k} (texture_compress.py:183-217)."""
         if self.p.lossless:
-            return j2k_params(reversible=True, levels=max(self.p.SRLs - 1, 0), layers=1)
+            return j2k_params(reversible=True, levels=max(self.p.SRLs - 1, 0), layers=1, cblk=self.p.cblk)
         return j2k_params(reversible=self.p.reversible, levels=max(self.p.SRLs - 1, 0), layers=self.p.nLayers,
-                          slopes=self.slopes[subband_index], base_step=self.p.base_step)
+                          slopes=self.slopes[subband_index], base_step=self.p.base_step, cblk=self.p.cblk)
 
     # texture_compress.py:183-217: high_t (pictures-1 each) then low_{TRLs-1}
     def texture_items(self, low_first=0):

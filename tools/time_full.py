@@ -7,9 +7,10 @@ W,H=1920,1080
 kind = sys.argv[1] if len(sys.argv)>1 else "pan_noise"
 mode = sys.argv[2] if len(sys.argv)>2 else "53"
 gops = int(sys.argv[3]) if len(sys.argv)>3 else 2
+cblk = int(sys.argv[4]) if len(sys.argv)>4 else 64
 e = hip.Engine(0)
 prm = CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=4, GOPs=gops, block_size=8, block_size_min=8, search_range=4, SRLs=5,
-                     lossless=(mode=="53"), reversible=False)
+                     lossless=(mode=="53"), reversible=False, cblk=cblk)
 comp = Compressor(e, prm)
 clip = make_clip(kind, comp.pictures, W, H, 43)
 comp.configure(); comp.load(clip)
