@@ -189,13 +189,13 @@ T1HD int t1_mag(uint64_t m, int k) { return (int)((m >> (16 * k)) & 0x7FFF); }
 T1HD int t1_neg(uint64_t m, int k) { return (int)((m >> (16 * k + 15)) & 1); }
 
 // sample (stripe-row r, column c, row-in-stripe k) has just become significant with sign `neg`:
-// publish it to every flag word whose neighbourhood contains it.  `own` is word (r, c) held in a register.
-// `nxt` is the already-fetched copy of word (r, c+1): it receives the same update (forwarding).
+// publish it to every flag word whose neighbourhood contains it.  The three words of the row that are in
+// registers -- `prv` (r, c-1), `own` (r, c), `nxt` (r, c+1) -- are updated in place (they are stored once, when
+// they leave the register window); only the words of the stripe rows above/below go through memory.
 template <class Store>
-T1HD void t1_set_sig(Store& S, int r, int c, uint32_t& own, uint32_t& nxt, int k, int neg) {
+T1HD void t1_set_sig(Store& S, int r, int c, uint32_t& prv, uint32_t& own, uint32_t& nxt, int k, int neg) {
   own |= (1u << (3 * (k + 1) + 1)) | ((uint32_t)neg << (T1_CHI_SHIFT + k + 1));
-  S.orr(r, c - 1, 1u << (3 * (k + 1) + 2));
-  S.orr(r, c + 1, 1u << (3 * (k + 1) + 0));
+  prv |= 1u << (3 * (k + 1) + 2);
   nxt |= 1u << (3 * (k + 1) + 0);
   if (k == 0) {  // also row 4 (index 5) of the stripe above
     S.orr(r - 1, c, (1u << 16) | ((uint32_t)neg << (T1_CHI_SHIFT + 5)));
@@ -249,9 +249,12 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
     const int r = s + 1;
     const bool row_on = lane_pass && 4 * s < h;
     // software pipeline: the flag word and magnitudes of column x+1 are fetched while column x is coded
-    uint32_t fpre = 0, fprv = 0;  // fprv: the previous column's word as it was left (apron word for x = 0)
+    // register window over the row's flag words: fprv = column x-1 (apron word for x = 0), f = column x,
+    // fnx = column x+1 (prefetched).  *_mem = the value memory holds, so each word is stored once, when it
+    // leaves the window, and only if it changed.
+    uint32_t fpre = 0, fprv = 0, fpre_mem = 0, fprv_mem = 0;
     uint64_t mpre = 0;
-    if (row_on && 0 < w) { fpre = S.ld(r, 1); mpre = S.mag(s, 0); }
+    if (row_on && 0 < w) { fpre = fpre_mem = S.ld(r, 1); mpre = S.mag(s, 0); }
     for (int x = 0; x < wmax; x++) {
       const bool on = row_on && x < w;
       const int c = x + 1;
@@ -259,10 +262,11 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
       uint32_t mlo = (uint32_t)mpre, mhi = (uint32_t)(mpre >> 32);
       T1_PIN32(f); T1_PIN32(mlo); T1_PIN32(mhi);
       const uint64_t m = (uint64_t)mlo | ((uint64_t)mhi << 32);
+      const uint32_t f_mem = fpre_mem;
       uint32_t fnx = 0;
       uint64_t mnx = 0;
       if (row_on && x + 1 < w) { fnx = S.ld(r, c + 1); mnx = S.mag(s, x + 1); }
-      const uint32_t f0 = f;
+      const uint32_t fnx_mem = fnx;
       do {  // one stripe column (break = nothing (more) to code here)
       if (!on) break;
       if (pass == 0) {
@@ -275,7 +279,7 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
           if (bit) {
             int neg = t1_neg(m, k);
             t1_code_sign(K, fprv, fnx, f, k, neg);
-            t1_set_sig(S, r, c, f, fnx, k, neg);
+            t1_set_sig(S, r, c, fprv, f, fnx, k, neg);
             if (want_dist) dist += t1_dist_sig(mag, p);
           }
           f |= 1u << (T1_PI_SHIFT + k);
@@ -309,7 +313,7 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
               K.sym(T1_CTX_UNI, fk & 1);
               int neg = t1_neg(m, fk);
               t1_code_sign(K, fprv, fnx, f, fk, neg);
-              t1_set_sig(S, r, c, f, fnx, fk, neg);
+              t1_set_sig(S, r, c, fprv, f, fnx, fk, neg);
               if (want_dist) dist += t1_dist_sig(t1_mag(m, fk), p);
               k = fk + 1;
             }
@@ -322,7 +326,7 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
             if (bit) {
               int neg = t1_neg(m, k);
               t1_code_sign(K, fprv, fnx, f, k, neg);
-              t1_set_sig(S, r, c, f, fnx, k, neg);
+              t1_set_sig(S, r, c, fprv, f, fnx, k, neg);
               if (want_dist) dist += t1_dist_sig(mag, p);
             }
           }
@@ -330,10 +334,11 @@ T1HD long long t1_pass(Sink& K, Store& S, const uint8_t* zc, int pass, int p, in
         f &= ~(0xFu << T1_PI_SHIFT);  // the "visited" marks last one bit-plane
       }
       } while (0);
-      if (f != f0) S.st(r, c, f);
-      fprv = f;
-      fpre = fnx; mpre = mnx;  // includes whatever this column forwarded into its right neighbour
+      if (row_on && x >= 1 && x - 1 < w && fprv != fprv_mem) S.st(r, c - 1, fprv);  // column x-1 is final for this pass
+      if (on) { fprv = f; fprv_mem = f_mem; }
+      fpre = fnx; fpre_mem = fnx_mem; mpre = mnx;  // includes whatever this column put into its right neighbour
     }
+    if (row_on && w == wmax && w > 0 && fprv != fprv_mem) S.st(r, w, fprv);  // the row's last column
     S.stripe_end(s);
   }
   S.pass_end(nstripes);

@@ -167,7 +167,7 @@ extern "C" int emul_t1_block(const int32_t* vals, int w, int h, int orient, uint
   T1Result r;
   int pl[T1_MAXPASS]; long long pd[T1_MAXPASS];
   r.pass_len = pl; r.pass_dist = pd;
-  t1_encode_lane(t, S, nb - 1, w, h, true, r);
+  t1_encode_lane(t, S, nb - 1, w + 7 > 64 ? 64 : w + 7, h + 5 > 64 ? 64 : h + 5, true, r);  // uniform bounds beyond the block, as in a wave
   if (r.overflow) return -2;
   memcpy(out, bufp + 1, r.len);
   *npasses = r.npasses; *nbps = r.nbps;
@@ -208,7 +208,7 @@ extern "C" int emul_t1_block_split(const int32_t* vals, int w, int h, int orient
     for (int s = 0; s < nstr; s++)
       for (int x = 0; x < w; x++) flags[(s + 1) * T1_FW + x + 1] = t1_initial_flag(M, s, x, p, nstr, w);
     T1ArrayStore S{flags.data(), mags.data(), 1};
-    t1_cm_plane(S, zclut, segs.data() + (size_t)p * T1_SEG_BYTES, p, w, h, orient, nb, w, h, true, &cnt[p * 3], &dist[p * 3]);
+    t1_cm_plane(S, zclut, segs.data() + (size_t)p * T1_SEG_BYTES, p, w, h, orient, nb, w + 7 > 64 ? 64 : w + 7, h + 5 > 64 ? 64 : h + 5, true, &cnt[p * 3], &dist[p * 3]);
   }
   uint32_t cx[19];
   std::vector<uint32_t> buf32((size_t)w * h + 16);
