@@ -7,14 +7,18 @@ HBM roofline and the CPU path timed beside it.
 Workload (BASELINE.json configs[2]): 1920x1080 4:2:0, one 16-picture GOP pair =
 17 pictures per GPU, TRLs=4 (3 MCTF levels: ME + predict + update, block 8, search range 4->8->16), then the
 JPEG 2000 stage (reversible 5/3, Clevels=4, 64x64 code-blocks, EBCOT Tier-1, Tier-2 with SOP) for every
-temporal subband picture.  One step = one whole encode of that sequence, from pictures resident in HBM to
-code-streams in host memory.  Synthetic input (seeded pan + noise), no reference numbers exist (vs_baseline null).
+temporal subband picture.  `--sessions S` (default 3) such sequences are encoded concurrently per GPU, one encoder context
+and host thread each: EBCOT Tier-1 is a long serial chain per code-block that leaves most of the chip idle, and
+independent sequences fill it.  One step = every session finishing one whole encode, from pictures
+resident in HBM to code-streams in host memory.  Synthetic input (seeded pan + noise), no reference numbers exist
+(vs_baseline null).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 Launched for N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; torch is
 used only for rendezvous/barrier/max-reduce over gloo (it never touches the GPU in these processes).
 """
 import argparse
+import copy
 import json
 import os
 import sys
@@ -63,34 +67,6 @@ def cpu_baseline():
             "mctf_s": round(t1 - t0, 3), "j2k_s": round(t2 - t1, 3), "codeblocks_per_s": round(ncb / (t2 - t1), 1)}
 
 
-def multi_session(nctx, prm, clip, steps=3):
-    """Informational (N=1): several independent encoder contexts in flight on the one GPU, one host thread each.
-    Tier-1 is a long serial chain per code-block that leaves most of the chip idle; a second and third sequence fill it."""
-    import copy
-    import threading
-    from qsvc_amd import hip
-    from qsvc_amd.pipeline import Compressor
-    comps = []
-    for _ in range(nctx):
-        c = Compressor(hip.Engine(0), copy.deepcopy(prm))
-        c.configure(); c.load(clip); c.analyze(); c.texture(copy=False); c.e.sync()
-        comps.append(c)
-
-    def work(c):
-        for _ in range(steps):
-            c.analyze(); c.texture(copy=False)
-        c.e.sync()
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(c,)) for c in comps]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    dt = time.perf_counter() - t0
-    for c in comps:
-        c.e.close()
-    return {"sessions": nctx, "steps_per_session": steps, "value": round(clip.shape[0] * nctx * steps / dt, 2), "unit": "frames/s",
-            "ms_per_step_amortised": round(dt / (nctx * steps) * 1e3, 3)}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +74,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clip", default="pan_noise")
-    ap.add_argument("--sessions", type=int, default=4, help="extra (N=1 only): throughput with this many encoder contexts in flight")
+    ap.add_argument("--sessions", type=int, default=3,
+                    help="17-picture sequences encoded concurrently per GPU (one encoder context + host thread each); "
+                         "a step = every session finishing one whole encode")
     args = ap.parse_args()
 
     # Native libraries (gloo, RCCL) print banners on fd 1; stdout must carry exactly ONE JSON line, so fd 1 points at
@@ -121,24 +99,29 @@ def main():
     from qsvc_amd.pipeline import CompressParams, Compressor
     from qsvc_amd.synth import make_clip
 
+    import threading
+    S = max(1, args.sessions)
     dev = os.environ.get("QSVC_BENCH_DEVICE")  # test hook: several ranks on one GPU (forces the host-staged exchange)
-    eng = hip.Engine(int(dev) if dev is not None else (local if world > 1 else 0))
-    exchange, exchange_kind = None, "none"
+    devno = int(dev) if dev is not None else (local if world > 1 else 0)
+    engs = [hip.Engine(devno) for _ in range(S)]
+    eng = engs[0]
+    real_exchange, exchange_kind = [None] * S, "none"
     if world > 1:
         import torch
-        # RCCL over xGMI; the id travels through gloo.  Every rank takes the same branch at every step, so a failure
-        # anywhere degrades ALL ranks to the host-staged transport (a transport fallback, never a compute fallback).
-        uid = [None]
+        # RCCL over xGMI, one communicator per session; the ids travel through gloo.  Every rank takes the same branch
+        # at every step, so a failure anywhere degrades ALL ranks to the host-staged transport (a transport fallback,
+        # never a compute fallback).
+        uids = [None]
         if rank == 0 and dev is None and os.environ.get("QSVC_EXCHANGE", "rccl") == "rccl":
             try:
-                uid = [hip.Engine.comm_unique_id()]
+                uids = [[hip.Engine.comm_unique_id() for _ in range(S)]]
             except Exception as ex:
                 log(f"[rank 0] RCCL unavailable ({ex})")
-        dist.broadcast_object_list(uid, src=0)
+        dist.broadcast_object_list(uids, src=0)
         ok = 0
-        if uid[0] is not None:
+        if uids[0] is not None:
             try:
-                exchange = sharding.RcclExchange(eng, rank, world, uid[0])
+                real_exchange = [sharding.RcclExchange(engs[k], rank, world, uids[0][k]) for k in range(S)]
                 ok = 1
             except Exception as ex:
                 log(f"[rank {rank}] qsvc_comm_init failed ({ex})")
@@ -147,40 +130,85 @@ def main():
         if flag.item() == 1:
             exchange_kind = "rccl"
         else:
-            exchange = sharding.HostExchange(dist, rank, world)
+            real_exchange = [sharding.HostExchange(dist, rank, world) for _ in range(S)]
             exchange_kind = "gloo-host"
 
     prm = CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=TRLS, GOPs=GOPS, block_size=BS, block_size_min=BS,
                          search_range=S0, SRLs=SRLS, lossless=True)
-    comp = Compressor(eng, prm, exchange)
+
+    class Lockstep:
+        """All sessions of this rank reach the level's exchange point together; ONE thread then runs the sessions'
+        exchanges one after the other, so every rank issues its collectives in the same order."""
+        def __init__(self):
+            self.args = [None] * S
+            self.bar = threading.Barrier(S, action=self._run)
+            self.err = None
+
+        def _run(self):
+            try:
+                for k in range(S):
+                    e, t, bs = self.args[k]
+                    real_exchange[k].exchange(e, t, bs)
+            except Exception as ex:  # noqa: BLE001
+                self.err = ex
+
+        def proxy(self, k):
+            outer = self
+
+            class P:
+                def exchange(self, e, t, bs):
+                    outer.args[k] = (e, t, bs)
+                    outer.bar.wait()
+                    if outer.err is not None:
+                        raise outer.err
+            return P()
+
+    lock = Lockstep() if world > 1 else None
+    comps = [Compressor(engs[k], copy.deepcopy(prm), lock.proxy(k) if lock else None) for k in range(S)]
+    comp = comps[0]
     P = comp.pictures
     # weak scaling: rank r holds pictures [16r, 16r+16] of one long synthetic sequence (boundary picture shared)
     G = 16
     seq_local = make_clip(args.clip, G * world + 1, W, H, 43)[G * rank:G * rank + P].copy()
-    comp.configure()
-    comp.load(seq_local)
+    for c in comps:
+        c.configure()
+        c.load(seq_local)
     low_first = 0 if rank == 0 else 1  # the shared boundary picture of low_T is coded by the left shard
+    nbytes_of = [0] * S
 
-    def step():
-        comp.analyze()
-        out = comp.texture(low_first, copy=False)  # code-streams stay in the engine's host buffer (no Python copies)
-        return sum(len(c) for v in out.values() for c in v)
+    def step(k):
+        comps[k].analyze()
+        out = comps[k].texture(low_first, copy=False)  # code-streams stay in the engine's host buffer (no Python copies)
+        nbytes_of[k] = sum(len(c) for v in out.values() for c in v)
+
+    def run_steps(n):
+        """n steps; a step = every session completing one whole encode."""
+        def work(k):
+            for _ in range(n):
+                step(k)
+            engs[k].sync()
+        if S == 1:
+            work(0)
+            return
+        th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+        [t.start() for t in th]
+        [t.join() for t in th]
 
     def barrier():
-        eng.sync()
+        for e in engs:
+            e.sync()
         if dist is not None:
             dist.barrier()
 
-    nbytes = 0
-    for _ in range(args.warmup):
-        nbytes = step()
-    eng.set_profiling(True)
+    run_steps(args.warmup)
+    for e in engs:
+        e.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nbytes = step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    nbytes = nbytes_of[0]
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64)
@@ -188,10 +216,18 @@ def main():
         dt = float(tt.item())
     timings = eng.timings()
     stats = eng.j2k_stats()
-    eng.set_profiling(False)
+    for e in engs:
+        e.set_profiling(False)
+    serial_ms = None
+    if world == 1:  # latency of ONE sequence alone on the chip (informational)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step(0)
+        engs[0].sync()
+        serial_ms = (time.perf_counter() - t1) / 2 * 1e3
 
     if rank == 0:
-        pics_total = G * world + 1
+        pics_total = (G * world + 1) * S   # unique pictures per step: S independent sequences of 16*N+1 pictures
         ms_step = dt / args.steps * 1e3
         fps = pics_total * args.steps / dt
         F = W * H * 3 // 2
@@ -248,14 +284,17 @@ def main():
             "config": {"workload": "1920x1080 4:2:0, 17 pictures per GPU (16-picture GOP window + shared boundary), TRLs=4 "
                                    "(ME+predict+update, block 8, search 4/8/16), JPEG 2000 5/3 reversible lossless, Clevels=4, "
                                    "64x64 code-blocks, SOP; clip=" + args.clip,
-                       "pictures_per_step_total": pics_total, "parallelism": f"gop-shard x{world}", "halo_exchange": exchange_kind},
-            "codeblocks_per_s": round(ncb_step * world * args.steps / dt, 1),
+                       "pictures_per_step_total": pics_total, "sequences_in_flight_per_gpu": S,
+                       "parallelism": f"gop-shard x{world}", "halo_exchange": exchange_kind},
+            "codeblocks_per_s": round(ncb_step * world * S * args.steps / dt, 1),
             "ebcot_codeblocks_per_s_kernel": round(ncb_step / (t1ms * 1e-3), 1) if t1ms else None,
             "codestream_bytes_per_step": int(nbytes), "mq_symbols_per_step": int(stats["symbols"]),
             "kernels": per, "roofline": roof,
         }
-        if world == 1 and args.sessions > 1:
-            line["multi_session"] = multi_session(args.sessions, prm, seq_local)
+        if serial_ms is not None:
+            line["single_sequence"] = {"ms_per_encode": round(serial_ms, 3), "frames_per_s": round(17 / (serial_ms * 1e-3), 2)}
+        line["kernels_note"] = ("per-kernel times are HIP-event durations on session 0's stream; with several sessions in "
+                                "flight kernels of different sessions overlap, so they do not sum to ms_per_step")
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()
@@ -265,7 +304,8 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
-    eng.close()
+    for e in engs:
+        e.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
