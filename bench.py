@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 W, H, TRLS, GOPS, BS, S0, SRLS = 1920, 1080, 4, 2, 8, 4, 5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = "r01_v1_pmc_hbm.json"
+PMC_FILE = "r01_v2_pmc_hbm.json"
 
 
 def log(*a):
@@ -263,7 +263,7 @@ def main():
             traffic = None
             try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-                kname = {"j2k_t1_mq": "k_t1_mq<4>", "j2k_t1_cm": "k_t1_cm<64>", "j2k_t1_encode": "k_t1_encode<8>"}.get(dom)
+                kname = {"j2k_t1_mq": "k_t1_mq<16>", "j2k_t1_cm": "k_t1_cm<64>", "j2k_t1_encode": "k_t1_encode<8>"}.get(dom)
                 if kname in pmc:
                     traffic = pmc[kname]["hbm_bytes_per_launch_raw"]
             except Exception:
