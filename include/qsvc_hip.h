@@ -149,6 +149,11 @@ int qsvc_j2k_encode_multi(qsvc_ctx* ctx, int nseq, const int* kinds, const int* 
 /* Same on a host plane (copied to the device first); one code-stream. */
 int qsvc_j2k_encode_plane(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, const qsvc_j2k_params* p, uint8_t* out,
                           size_t cap, size_t* len);
+/* `nplanes` host planes of 16-bit SIGNED samples (H x W each, back to back), one code-stream per plane: replaces the
+ * `kdu_compress ... Creversible=yes Sprecision=16 Ssigned=yes Clevels=0` call on every motion-field component
+ * (motion_compress_j2k.py:131-142).  prm->reversible must be 1 and prm->levels 0.  offs[nplanes+1]. */
+int qsvc_j2k_encode_planes_s16(qsvc_ctx* ctx, const int16_t* planes, int nplanes, int H, int W, const qsvc_j2k_params* prm,
+                               uint8_t* out, size_t cap, size_t* offs);
 /* Unit-testable transform: level shift + `levels` of forward DWT of a host 8-bit plane, Mallat layout.
  * out receives H*W int32 (reversible 5/3) or H*W float32 (irreversible 9/7, before quantisation). */
 int qsvc_j2k_dwt(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, int reversible, int levels, void* out);

@@ -25,6 +25,8 @@ def _lib():
     if not _ready:
         L.qo_j2k_encode_plane.restype = C.c_long
         L.qo_j2k_encode_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.qo_j2k_encode_plane_s16.restype = C.c_long
+        L.qo_j2k_encode_plane_s16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p]
         L.qo_j2k_t1_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
         L.qo_j2k_coefficients.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
         L.qo_j2k_dwt97_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -58,6 +60,23 @@ def encode_plane(plane: np.ndarray, reversible=False, levels=4, layers=1, cblk=6
         raise RuntimeError(f"qo_j2k_encode_plane failed: {n}")
     cs = out[:n].tobytes()
     return (cs, dict(codeblocks=int(st[0]), passes=int(st[1]), symbols=int(st[2]))) if want_stats else cs
+
+
+def encode_plane_s16(plane: np.ndarray, cblk=64, use_sop=True) -> bytes:
+    """16-bit signed plane, reversible, Clevels=0 (motion fields, motion_compress_j2k.py:131-142)."""
+    p = np.ascontiguousarray(plane, dtype=np.int16)
+    H, W = p.shape
+    out = np.empty(H * W * 4 + 4096, dtype=np.uint8)
+    prm = params(True, 0, 1, cblk, use_sop)
+    n = _lib().qo_j2k_encode_plane_s16(p.ctypes.data, H, W, C.byref(prm), out.ctypes.data, out.size, None)
+    if n < 0:
+        raise RuntimeError(f"qo_j2k_encode_plane_s16 failed: {n}")
+    return out[:n].tobytes()
+
+
+def decode_s16(codestream: bytes) -> np.ndarray:
+    """Pillow hands 16-bit signed single-component streams back as uint16 with a 32768 offset."""
+    return (decode(codestream).astype(np.int32) - 32768).astype(np.int16)
 
 
 def coefficients(plane, reversible, levels, base_step=1.0 / 256) -> np.ndarray:

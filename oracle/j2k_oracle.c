@@ -129,7 +129,11 @@ double qo_j2k_norm(int reversible, int orient, int dlev) {
 }
 
 /* subbands in code-stream order: LL_L, then HL,LH,HH for d = L .. 1.  returns count = 3L+1 */
+static int subbands_prec(int W, int H, int levels, int reversible, float base_step, int prec, subband *sb);
 int qo_j2k_subbands(int W, int H, int levels, int reversible, float base_step, subband *sb) {
+  return subbands_prec(W, H, levels, reversible, base_step, 8, sb);
+}
+static int subbands_prec(int W, int H, int levels, int reversible, float base_step, int prec, subband *sb) {
   int ws[MAX_LEVELS + 1], hs[MAX_LEVELS + 1];
   ws[0] = W; hs[0] = H;
   for (int d = 1; d <= levels; d++) { ws[d] = (ws[d - 1] + 1) >> 1; hs[d] = (hs[d - 1] + 1) >> 1; }
@@ -143,7 +147,7 @@ int qo_j2k_subbands(int W, int H, int levels, int reversible, float base_step, s
   }
   for (int i = 0; i < n; i++) {
     int gain = sb[i].orient == 0 ? 0 : (sb[i].orient == 3 ? 2 : 1); /* log2 nominal gain (E.1) */
-    int Rb = 8 + gain;
+    int Rb = prec + gain;
     if (reversible) {
       sb[i].eps = Rb; sb[i].mant = 0; sb[i].delta = 1.0f;
     } else {
@@ -567,18 +571,20 @@ static int passes_for_lambda(const t1result *r, double weight, double lambda) {
   return best;
 }
 
+/* Tier-1 + Tier-2 of a plane whose sign-magnitude coefficients (Mallat layout) are given.  prec/sgnd describe the
+ * samples for SIZ (Ssiz) and the dynamic range R_b. */
+static long encode_coefs(uint32_t *coef, int H, int W, int L, const qo_j2k_params *prm, int prec, int sgnd, uint8_t *out,
+                         size_t cap, uint64_t *stats);
+
 /* Encode one 8-bit unsigned plane to a raw JPEG 2000 code-stream.  Returns the length or <0. */
 long qo_j2k_encode_plane(const uint8_t *plane, int H, int W, const qo_j2k_params *prm, uint8_t *out, size_t cap,
                          uint64_t *stats /* nullable: [codeblocks, passes, symbols] */) {
-  int L = prm->levels, layers = prm->layers < 1 ? 1 : prm->layers;
-  if (L < 0 || L > MAX_LEVELS || layers > 16 || W < 1 || H < 1) return -1;
-  int cbw = prm->cblk_w ? prm->cblk_w : 64, cbh = prm->cblk_h ? prm->cblk_h : 64;
-  if (cbw > 64 || cbh > 64 || cbw < 4 || cbh < 4 || (cbw & (cbw - 1)) || (cbh & (cbh - 1))) return -1;
+  int L = prm->levels;
+  if (L < 0 || L > MAX_LEVELS || W < 1 || H < 1) return -1;
   while (L > 0 && ((W >> (L - 1)) < 1 || (H >> (L - 1)) < 1)) L--;
   size_t N = (size_t)W * H;
   subband sb[3 * MAX_LEVELS + 1];
   int nsb = qo_j2k_subbands(W, H, L, prm->reversible, prm->base_step > 0 ? prm->base_step : 1.0f / 256, sb);
-
   /* level shift + DWT + quantisation -> sign-magnitude coefficients */
   uint32_t *coef = (uint32_t *)malloc(sizeof(uint32_t) * N);
   if (prm->reversible) {
@@ -601,6 +607,38 @@ long qo_j2k_encode_plane(const uint8_t *plane, int H, int W, const qo_j2k_params
         }
     free(p);
   }
+  long r = encode_coefs(coef, H, W, L, prm, 8, 0, out, cap, stats);
+  free(coef);
+  return r;
+}
+
+/* Signed 16-bit samples, reversible, no DC shift (Ssigned=yes): the motion-field planes of
+ * motion_compress_j2k.py:131-142 (Sprecision=16, Clevels=0, Creversible=yes). */
+long qo_j2k_encode_plane_s16(const int16_t *plane, int H, int W, const qo_j2k_params *prm, uint8_t *out, size_t cap,
+                             uint64_t *stats) {
+  int L = prm->levels;
+  if (!prm->reversible || L < 0 || L > MAX_LEVELS || W < 1 || H < 1) return -1;
+  while (L > 0 && ((W >> (L - 1)) < 1 || (H >> (L - 1)) < 1)) L--;
+  size_t N = (size_t)W * H;
+  int32_t *p = (int32_t *)malloc(sizeof(int32_t) * N);
+  uint32_t *coef = (uint32_t *)malloc(sizeof(uint32_t) * N);
+  for (size_t i = 0; i < N; i++) p[i] = plane[i];
+  qo_j2k_fdwt53(p, W, H, W, L);
+  for (size_t i = 0; i < N; i++) coef[i] = p[i] < 0 ? (0x80000000u | (uint32_t)(-p[i])) : (uint32_t)p[i];
+  free(p);
+  long r = encode_coefs(coef, H, W, L, prm, 16, 1, out, cap, stats);
+  free(coef);
+  return r;
+}
+
+static long encode_coefs(uint32_t *coef, int H, int W, int L, const qo_j2k_params *prm, int prec, int sgnd, uint8_t *out,
+                         size_t cap, uint64_t *stats) {
+  int layers = prm->layers < 1 ? 1 : prm->layers;
+  if (layers > 16) return -1;
+  int cbw = prm->cblk_w ? prm->cblk_w : 64, cbh = prm->cblk_h ? prm->cblk_h : 64;
+  if (cbw > 64 || cbh > 64 || cbw < 4 || cbh < 4 || (cbw & (cbw - 1)) || (cbh & (cbh - 1))) return -1;
+  subband sb[3 * MAX_LEVELS + 1];
+  int nsb = subbands_prec(W, H, L, prm->reversible, prm->base_step > 0 ? prm->base_step : 1.0f / 256, prec, sb);
 
   /* code-blocks, in (subband, raster) order */
   int ncb = 0;
@@ -646,7 +684,7 @@ long qo_j2k_encode_plane(const uint8_t *plane, int H, int W, const qo_j2k_params
     ob_u16(&o, 0xFF51); ob_u16(&o, 41); ob_u16(&o, 0);     /* SIZ, Rsiz=0 */
     ob_u32(&o, W); ob_u32(&o, H); ob_u32(&o, 0); ob_u32(&o, 0);
     ob_u32(&o, W); ob_u32(&o, H); ob_u32(&o, 0); ob_u32(&o, 0);
-    ob_u16(&o, 1); ob_put(&o, 7); ob_put(&o, 1); ob_put(&o, 1);
+    ob_u16(&o, 1); ob_put(&o, (prec - 1) | (sgnd ? 0x80 : 0)); ob_put(&o, 1); ob_put(&o, 1);
     ob_u16(&o, 0xFF52); ob_u16(&o, 12);                    /* COD */
     ob_put(&o, prm->use_sop ? 0x02 : 0x00);
     ob_put(&o, 0); ob_u16(&o, layers); ob_put(&o, 0);      /* LRCP, layers, no MCT */
@@ -745,7 +783,7 @@ long qo_j2k_encode_plane(const uint8_t *plane, int H, int W, const qo_j2k_params
   if (stats) { stats[0] = ncb; stats[1] = tot_passes; stats[2] = tot_sym; }
 done:
   for (int i = 0; i < ncb; i++) free(cb[i].data);
-  free(cb); free(coef);
+  free(cb);
   return ret;
 }
 

@@ -212,6 +212,37 @@ def ref_analyze(low0, W, H, TRLs, bs, S=4, bs_min=None, always_B=0, update_facto
     return levels
 
 
+def ref_motion_residues(filtered: dict, BY: int, BX: int) -> dict:
+    """motion_filtered_t -> motion_residue_t by the reference's interlevel_/bidirectional_motion_decorrelate binaries
+    (oracle/_ref), called as motion_compress.py:146-186 does for block_size == block_size_min."""
+    d = tempfile.mkdtemp(prefix="qsvc_refm_")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MALLOC_")}
+    try:
+        its = sorted(filtered)
+        for t in its:
+            np.ascontiguousarray(filtered[t], dtype="<i2").tofile(os.path.join(d, f"motion_filtered_{t}"))
+        fields = filtered[its[0]].shape[0]
+        out = {}
+
+        def run(tool, *args):
+            subprocess.check_call([os.path.join(REF_DIR, tool)] + list(args), cwd=d, env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+        for t in its[:-1]:
+            run("interlevel_motion_decorrelate", f"--blocks_in_x={BX}", f"--blocks_in_y={BY}",
+                f"--fields_in_predicted={fields}", f"--predicted=motion_filtered_{t}",
+                f"--reference=motion_filtered_{t + 1}", f"--residue=motion_residue_{t}")
+            fields //= 2
+        t = its[-1]
+        run("bidirectional_motion_decorrelate", f"--blocks_in_x={BX}", f"--blocks_in_y={BY}", f"--fields={fields}",
+            f"--input=motion_filtered_{t}", f"--output=motion_residue_{t}")
+        for t in its:
+            out[t] = np.fromfile(os.path.join(d, f"motion_residue_{t}"), dtype="<i2").reshape(-1, 4, BY, BX)
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def ref_dwt(plane: np.ndarray, levels: int, inverse=False, filt="53") -> np.ndarray:
     p = np.ascontiguousarray(plane, dtype=np.int16)
     H, W = p.shape

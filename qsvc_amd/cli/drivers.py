@@ -178,8 +178,11 @@ def compress(argv=None):
         e.put_frames(hip.LOW, 0, low0)
         if a["TRLs"] > 1:  # compress.py:176-212
             _run_analyze(e, a, low0, keep=bool(a["keep_intermediates"]))
-            # motion_compress (compress.py:197-212) is a "next" row: the filtered motion fields are
-            # left in motion_filtered_t for it.
+            from .motion_tools import run_motion_compress  # compress.py:197-212
+            filt = {t: e.get_motion(hip.MOTION_FILTERED, t, P // 2, bs)
+                    for (t, P, S, bs) in schedule.level_schedule(a["GOPs"], a["TRLs"], a["block_size"], a["block_size_min"], a["search_range"])}
+            if a["block_size"] == a["block_size_min"]:
+                run_motion_compress(e, W, H, a["TRLs"], a["GOPs"], a["block_size"], a["block_size_min"], filtered=filt)
         _texture(e, a, device=True)
     except hip.QsvcError as ex:
         C.die(str(ex))

@@ -38,7 +38,7 @@ struct Subband {
 };
 
 struct PlanePlan {  // everything about one plane geometry
-  int W, H, L;
+  int W, H, L, prec;
   std::vector<Subband> sb;
   int ncb;
 };
@@ -50,10 +50,10 @@ double norm_of(bool rev, int orient, int dlev) {
 }
 
 // subbands in code-stream order: LL_L, then HL, LH, HH for d = L..1 (T.800 B.5, tile at the origin)
-void build_plan(PlanePlan& pp, int W, int H, int levels, bool rev, float base_step, int cbw, int cbh) {
+void build_plan(PlanePlan& pp, int W, int H, int levels, bool rev, float base_step, int cbw, int cbh, int prec) {
   int L = levels;
   while (L > 0 && ((W >> (L - 1)) < 1 || (H >> (L - 1)) < 1)) L--;
-  pp.W = W; pp.H = H; pp.L = L;
+  pp.W = W; pp.H = H; pp.L = L; pp.prec = prec;
   int ws[J2K_MAXLEV + 1], hs[J2K_MAXLEV + 1];
   ws[0] = W; hs[0] = H;
   for (int d = 1; d <= L; d++) { ws[d] = (ws[d - 1] + 1) >> 1; hs[d] = (hs[d - 1] + 1) >> 1; }
@@ -62,7 +62,7 @@ void build_plan(PlanePlan& pp, int W, int H, int levels, bool rev, float base_st
     Subband s;
     s.x0 = x0; s.y0 = y0; s.w = w; s.h = h; s.orient = orient; s.dlev = dlev;
     int gain = orient == 0 ? 0 : (orient == 3 ? 2 : 1);
-    int Rb = 8 + gain;
+    int Rb = prec + gain;
     if (rev) { s.eps = Rb; s.mant = 0; s.delta = 1.0f; }
     else {  // T.800 E.1.1: delta = 2^(Rb-eps) (1 + mant/2^11), target base_step*2^8/norm
       double target = (double)base_step * 256.0 / norm_of(false, orient, dlev ? dlev : 1);
@@ -226,7 +226,7 @@ static long write_codestream(const PlanePlan& pp, const qsvc_j2k_params& prm, in
   o.u16(0xFF4F);                                      // SOC
   o.u16(0xFF51); o.u16(41); o.u16(0);                 // SIZ
   o.u32(pp.W); o.u32(pp.H); o.u32(0); o.u32(0); o.u32(pp.W); o.u32(pp.H); o.u32(0); o.u32(0);
-  o.u16(1); o.put(7); o.put(1); o.put(1);
+  o.u16(1); o.put((pp.prec - 1) | (pp.prec == 16 ? 0x80 : 0)); o.put(1); o.put(1);  // Ssiz: 8-bit unsigned / 16-bit signed
   o.u16(0xFF52); o.u16(12);                           // COD
   o.put(prm.use_sop ? 0x02 : 0x00);
   o.put(0); o.u16(layers); o.put(0);
@@ -306,7 +306,7 @@ static long write_codestream(const PlanePlan& pp, const qsvc_j2k_params& prm, in
   return o.ovf ? -1 : (long)o.n;
 }
 
-struct PlaneSrc { const uint8_t* src; int stride, W, H; const qsvc_j2k_params* prm; };
+struct PlaneSrc { const uint8_t* src; int stride, W, H; const qsvc_j2k_params* prm; int s16; };
 
 // Encode a batch of device-resident planes.  All planes share the transform/quantiser/code-block parameters
 // of src[0].prm; the number of layers and the slopes may differ per plane (they only steer the host's PCRD).
@@ -334,19 +334,21 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
   std::vector<int> plan_of(np);
   for (int p = 0; p < np; p++) {
     int k = -1;
-    for (size_t q = 0; q < plans.size(); q++) if (plans[q].W == src[p].W && plans[q].H == src[p].H) { k = (int)q; break; }
-    if (k < 0) { plans.emplace_back(); build_plan(plans.back(), src[p].W, src[p].H, prm->levels, rev, base_step, cbw, cbh); k = (int)plans.size() - 1; }
+    const int prec = src[p].s16 ? 16 : 8;
+    for (size_t q = 0; q < plans.size(); q++) if (plans[q].W == src[p].W && plans[q].H == src[p].H && plans[q].prec == prec) { k = (int)q; break; }
+    if (k < 0) { plans.emplace_back(); build_plan(plans.back(), src[p].W, src[p].H, prm->levels, rev, base_step, cbw, cbh, prec); k = (int)plans.size() - 1; }
     plan_of[p] = k;
   }
-  for (auto& pl : plans)
-    for (auto& s : pl.sb) if (s.Mb > 15) return c->fail(QSVC_ERR_UNSUPPORTED, "subband needs %d magnitude bit-planes (> 15): raise base_step", s.Mb);
+  for (int p = 0; p < np; p++)
+    if (src[p].s16 && (!rev || plans[plan_of[p]].L != 0))
+      return c->fail(QSVC_ERR_UNSUPPORTED, "16-bit signed planes are coded reversibly with Clevels=0 only (motion fields)");
   int maxL = 0, maxW = 0, maxH = 0;
   S.planes.resize(np);
   size_t total = 0;
   std::vector<int> first_cb(np + 1);
   int ncb = 0;
   for (int p = 0; p < np; p++) {
-    S.planes[p].off = total; S.planes[p].src = src[p].src; S.planes[p].u8stride = src[p].stride; S.planes[p].W = src[p].W; S.planes[p].H = src[p].H;
+    S.planes[p].off = total; S.planes[p].src = src[p].src; S.planes[p].u8stride = src[p].stride; S.planes[p].W = src[p].W; S.planes[p].H = src[p].H; S.planes[p].s16 = src[p].s16;
     total += (size_t)src[p].W * src[p].H;
     maxW = std::max(maxW, src[p].W); maxH = std::max(maxH, src[p].H); maxL = std::max(maxL, plans[plan_of[p]].L);
     first_cb[p] = ncb; ncb += plans[plan_of[p]].ncb;
@@ -426,15 +428,16 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
       for (int p = 0; p < mx; p++) S.h_waves.push_back((g << 8) | p);
     }
     const int nwaves = (int)S.h_waves.size();
+    // the MQ stage reads joboff[b] of every block, also when no block of the batch has a bit-plane (all-zero planes)
+    if ((r = S.joboff_d.ensure(c, (size_t)ncb * 4))) return r;
+    HIPCHK(c, hipMemcpyAsync(S.joboff_d.p, S.h_joboff.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
     if (nwaves) {
       if ((r = S.waves_d.ensure(c, (size_t)nwaves * 4))) return r;
-      if ((r = S.joboff_d.ensure(c, (size_t)ncb * 4))) return r;
       if ((r = S.flags.ensure(c, (size_t)nwaves * T1_FLAGS_WORDS * 64 * 4))) return r;
       if ((r = S.segs_d.ensure(c, (njobs ? njobs : 1) * (size_t)T1_SEG_BYTES))) return r;
       if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
       if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
       HIPCHK(c, hipMemcpyAsync(S.waves_d.p, S.h_waves.data(), (size_t)nwaves * 4, hipMemcpyHostToDevice, c->st));
-      HIPCHK(c, hipMemcpyAsync(S.joboff_d.p, S.h_joboff.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
     }
     for (int stage = 0; stage < 3; stage++) {
       if (!nwaves && stage < 2) continue;
@@ -570,9 +573,9 @@ static int add_sequence(qsvc_ctx* c, int kind, int t, int first, int count, cons
   int cw = c->W / 2, ch = c->H / 2;
   for (int i = 0; i < count; i++) {  // order (picture, component), texture_compress_fb_j2k.py:255-257
     const uint8_t* f = (const uint8_t*)b->p + (size_t)(first + i) * c->F;
-    src.push_back({f, c->W, c->W, c->H, prm});
-    src.push_back({f + (size_t)c->W * c->H, cw, cw, ch, prm});
-    src.push_back({f + (size_t)c->W * c->H + (size_t)cw * ch, cw, cw, ch, prm});
+    src.push_back({f, c->W, c->W, c->H, prm, 0});
+    src.push_back({f + (size_t)c->W * c->H, cw, cw, ch, prm, 0});
+    src.push_back({f + (size_t)c->W * c->H + (size_t)cw * ch, cw, cw, ch, prm, 0});
   }
   return QSVC_OK;
 }
@@ -604,12 +607,26 @@ int qsvc_j2k_encode_plane(qsvc_ctx* c, const uint8_t* plane, int H, int W, const
   int r = c->j2k->up_d.ensure(c, (size_t)W * H);
   if (r) return r;
   HIPCHK(c, hipMemcpyAsync(c->j2k->up_d.p, plane, (size_t)W * H, hipMemcpyHostToDevice, c->st));
-  std::vector<PlaneSrc> src{{(const uint8_t*)c->j2k->up_d.p, W, W, H, prm}};
+  std::vector<PlaneSrc> src{{(const uint8_t*)c->j2k->up_d.p, W, W, H, prm, 0}};
   size_t offs[2];
   r = j2k_encode_planes(c, src, out, cap, offs);
   if (r) return r;
   *len = offs[1];
   return QSVC_OK;
+}
+
+int qsvc_j2k_encode_planes_s16(qsvc_ctx* c, const int16_t* planes, int nplanes, int H, int W, const qsvc_j2k_params* prm,
+                               uint8_t* out, size_t cap, size_t* offs) {
+  if (!c || !planes || !prm || !out || !offs || nplanes < 1 || W < 1 || H < 1 || W > 16384 || H > 16384) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  if (!c->j2k) c->j2k = new J2kState();
+  size_t bytes = (size_t)nplanes * W * H * 2;
+  int r = c->j2k->up_d.ensure(c, bytes);
+  if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(c->j2k->up_d.p, planes, bytes, hipMemcpyHostToDevice, c->st));
+  std::vector<PlaneSrc> src;
+  for (int p = 0; p < nplanes; p++) src.push_back({(const uint8_t*)c->j2k->up_d.p + (size_t)p * W * H * 2, W, W, H, prm, 1});
+  return j2k_encode_planes(c, src, out, cap, offs);
 }
 
 int qsvc_j2k_dwt(qsvc_ctx* c, const uint8_t* plane, int H, int W, int reversible, int levels, void* out) {
@@ -625,7 +642,7 @@ int qsvc_j2k_dwt(qsvc_ctx* c, const uint8_t* plane, int H, int W, int reversible
   if ((r = S.planes_d.ensure(c, sizeof(PlaneDesc)))) return r;
   int L = levels;
   while (L > 0 && ((W >> (L - 1)) < 1 || (H >> (L - 1)) < 1)) L--;
-  PlaneDesc pd{0, (const uint8_t*)S.up_d.p, W, W, H};
+  PlaneDesc pd{0, (const uint8_t*)S.up_d.p, W, W, H, 0};
   HIPCHK(c, hipMemcpyAsync(S.up_d.p, plane, N, hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipMemcpyAsync(S.planes_d.p, &pd, sizeof pd, hipMemcpyHostToDevice, c->st));
   launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, S.coefA.p, S.coefB.p, L, reversible != 0);

@@ -8,9 +8,10 @@ namespace qsvc {
 
 struct PlaneDesc {   // one image component plane of the batch
   size_t off;        // element offset of the plane in the coefficient buffers (stride = W)
-  const uint8_t* src; // source 8-bit samples (device)
-  int u8stride;      // source row stride in bytes
+  const uint8_t* src; // source samples (device): 8-bit unsigned (level shift -128) or 16-bit signed (no shift)
+  int u8stride;      // source row stride in samples
   int W, H;
+  int s16;           // 1: src holds int16 signed samples
 };
 struct CbDesc {      // one code-block
   int plane;

@@ -67,7 +67,10 @@ __global__ void __launch_bounds__(256) k_dwt_v(const PlaneDesc* planes, const vo
   if (REV) {
     const int32_t* s = (const int32_t*)srcv + pd.off;
     const uint8_t* u = pd.src;
-    auto X = [&](int yy) { return FROM_U8 ? (int)u[(size_t)yy * pd.u8stride + x] - 128 : s[(size_t)yy * pd.W + x]; };
+    auto X = [&](int yy) {
+      if (!FROM_U8) return s[(size_t)yy * pd.W + x];
+      return pd.s16 ? (int)((const int16_t*)u)[(size_t)yy * pd.u8stride + x] : (int)u[(size_t)yy * pd.u8stride + x] - 128;
+    };
     ((int32_t*)dstv)[o] = hr >= 2 ? dwt53_coef(X, y, hr) : X(y);
   } else {
     const float* s = (const float*)srcv + pd.off;
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(256) k_level_shift(const PlaneDesc* planes, vo
   PlaneDesc pd = planes[blockIdx.z];
   int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= pd.W || y >= pd.H) return;
-  int v = (int)pd.src[(size_t)y * pd.u8stride + x] - 128;
+  int v = pd.s16 ? (int)((const int16_t*)pd.src)[(size_t)y * pd.u8stride + x] : (int)pd.src[(size_t)y * pd.u8stride + x] - 128;
   if (REV) ((int32_t*)dstv)[pd.off + (size_t)y * pd.W + x] = v;
   else ((float*)dstv)[pd.off + (size_t)y * pd.W + x] = (float)v;
 }

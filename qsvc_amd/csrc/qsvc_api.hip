@@ -9,6 +9,7 @@
 
 #include <math.h>
 #include <stdarg.h>
+#include <algorithm>
 #include <stdio.h>
 
 using namespace qsvc;
@@ -214,7 +215,9 @@ static int level_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g) {
   if (t < 1 || t > QSVC_MAX_T) return c->fail(QSVC_ERR_INVALID, "temporal subband %d out of range", t);
   if (bs < 2 || bs > 256) return c->fail(QSVC_ERR_INVALID, "block_size %d", bs);
   if (P < 1) return c->fail(QSVC_ERR_INVALID, "pictures %d", P);
-  if (c->lv[t - 1].low_n < P) return c->fail(QSVC_ERR_STATE, "low_%d holds %d pictures, %d needed", t - 1, c->lv[t - 1].low_n, P);
+  // every B picture 2i+1 needs the even pictures 2i and 2i+2 (motion_estimate.cpp:792-820): 2*(P/2)+1 pictures in all
+  if (c->lv[t - 1].low_n < 2 * (P / 2) + 1 || c->lv[t - 1].low_n < P)
+    return c->fail(QSVC_ERR_STATE, "low_%d holds %d pictures, %d needed", t - 1, c->lv[t - 1].low_n, std::max(P, 2 * (P / 2) + 1));
   // rows/cols beyond BY*bs are never predicted by the reference and keep stale heap state there
   // (decorrelate.cpp:508-509,562-567; trunk/readme.txt:119-125) -- not reproduced on this path.
   if (c->H % bs || c->W % bs)

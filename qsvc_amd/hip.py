@@ -22,7 +22,7 @@ SYMBOLS = [
     "qsvc_get_frame_types", "qsvc_get_histograms", "qsvc_motion_estimate", "qsvc_decorrelate", "qsvc_update",
     "qsvc_analyze_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_dwt53_trunc",
-    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_dwt", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_j2k_dwt", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
 ]
 
 
@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     L.qsvc_j2k_encode_multi.argtypes = [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                         C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_encode_plane.argtypes = [vp, u8p, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.qsvc_j2k_encode_planes_s16.argtypes = [vp, i16p, i, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_dwt.argtypes = [vp, u8p, i, i, i, i, vp]
     L.qsvc_j2k_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qsvc_set_profiling.argtypes = [vp, i]
@@ -262,6 +263,17 @@ class Engine:
         n = C.c_size_t()
         self._chk(self.L.qsvc_j2k_encode_plane(self.h, p.ctypes.data, H, W, C.byref(params), out.ctypes.data, cap, C.byref(n)))
         return out[:n.value].tobytes()
+
+    def j2k_encode_planes_s16(self, planes: np.ndarray, params: J2kParams):
+        """planes: (n, H, W) int16 signed -> n lossless code-streams (Sprecision=16, Ssigned=yes, Clevels=0)."""
+        p = np.ascontiguousarray(planes, dtype=np.int16)
+        n, H, W = p.shape
+        cap = n * (H * W * 4 + 4096)
+        out = np.empty(cap, dtype=np.uint8)
+        offs = (C.c_size_t * (n + 1))()
+        self._chk(self.L.qsvc_j2k_encode_planes_s16(self.h, p.ctypes.data, n, H, W, C.byref(params), out.ctypes.data, cap, offs))
+        o = list(offs)
+        return [out[o[k]:o[k + 1]].tobytes() for k in range(n)]
 
     def j2k_dwt(self, plane: np.ndarray, reversible: bool, levels: int) -> np.ndarray:
         p = np.ascontiguousarray(plane, dtype=np.uint8)

@@ -63,6 +63,11 @@ def main():
                 out[f"{k}_{t}_sha"] = np.array(sha(lv[k]))
                 if full:
                     out[f"{k}_{t}"] = lv[k]
+        # motion-field residues (motion_compress.py:146-186) by the reference's own decorrelators; the cases all keep one
+        # block size over the levels, which is the configuration `compress` drives them in
+        filt = {t: lv["motion_filtered"] for t, lv in enumerate(levels, 1)}
+        for t, r in O.ref_motion_residues(filt, H // bs, W // bs).items():
+            out[f"motion_residue_{t}"] = r
         np.savez_compressed(os.path.join(HERE, f"mctf_{name}.npz"), **out)
         print(name, [lv["frame_types"] for lv in levels])
 
@@ -79,6 +84,21 @@ def main():
         kat[f"shaar_{h}x{w}_{lv}"] = O.ref_dwt(x, lv, inverse=True, filt="haar")
     np.savez_compressed(os.path.join(HERE, "dwt_kat.npz"), **kat)
     print("dwt_kat", len(kat))
+
+    # the two motion decorrelators on adversarial fields (odd negatives for the C division, int16 wrap, short reference)
+    rng = np.random.default_rng(13)
+    mk = {}
+    for i, (f1, f2, BY, BX) in enumerate([(4, 2, 3, 5), (5, 2, 2, 2), (2, 1, 4, 3), (1, 0, 2, 3)]):
+        a = rng.integers(-32768, 32768, size=(f1, 4, BY, BX)).astype(np.int16)
+        b = rng.integers(-32768, 32768, size=(f2, 4, BY, BX)).astype(np.int16)
+        mk[f"pred_{i}"], mk[f"ref_{i}"] = a, b
+        r = O.ref_motion_residues({1: a, 2: b}, BY, BX) if f2 else None
+        if r is not None:
+            mk[f"inter_{i}"], mk[f"bidir_{i}"] = r[1], r[2]
+        else:
+            mk[f"bidir_{i}"] = O.ref_motion_residues({1: a}, BY, BX)[1]
+    np.savez_compressed(os.path.join(HERE, "motion_kat.npz"), **mk)
+    print("motion_kat", len(mk))
 
     # header_size (trunk/src/header_size.c compiled into oracle/_ref) on deterministic marker streams
     import json, subprocess, tempfile

@@ -68,6 +68,44 @@ def test_compress_writes_the_reference_file_layout(oracle, tmp_path):
             for comp, pl in zip("YUV", planes):
                 cs = open(tmp_path / f"{name}_{comp}_{i:04d}.j2c", "rb").read()
                 np.testing.assert_array_equal(J.decode(cs), pl)
+    # motion coding (compress.py:197-212): residue files == the chain on the oracle's fields, every component stream decodes
+    # back to the demuxed residue, the .mjc index is the running sum of the bodies
+    from qsvc_amd import motion
+    from qsvc_amd.cli.texture_compress_fb_j2k import header_size
+    BY, BX = H // bs, W // bs
+    res = motion.residue_chain({t: lv["motion_filtered"] for t, lv in enumerate(want, 1)}, TRLs, bs, bs)
+    for t in range(1, TRLs):
+        np.testing.assert_array_equal(rd(tmp_path, f"motion_residue_{t}", np.int16), res[t].reshape(-1))
+        comps = motion.demux_components(res[t])
+        total, idx = 0, [int(x) for x in open(tmp_path / f"motion_residue_{t}.mjc").read().split()]
+        assert len(idx) == res[t].shape[0]
+        for n in range(res[t].shape[0]):
+            for c in range(4):
+                cs = open(tmp_path / f"motion_residue_{t}_comp{c}_{n:04d}.j2c", "rb").read()
+                assert cs == J.encode_plane_s16(comps[c, n])
+                np.testing.assert_array_equal(J.decode_s16(cs), comps[c, n])
+                total += len(cs) - header_size(cs)
+            assert idx[n] == total
+
+
+def test_motion_compress_tool_from_files(oracle, tmp_path):
+    """`mctf motion_compress` on motion_filtered_t files already in the directory (motion_compress.py as its own tool)."""
+    from qsvc_amd import motion
+    W, H, TRLs, bs = 128, 96, 4, 32
+    BY, BX = H // bs, W // bs
+    rng = np.random.default_rng(9)
+    filt, f = {}, 4
+    for t in range(1, TRLs):
+        filt[t] = rng.integers(-9, 10, size=(f, 4, BY, BX)).astype(np.int16)
+        filt[t].astype("<i2").tofile(tmp_path / f"motion_filtered_{t}")
+        f //= 2
+    run(tmp_path, "motion_compress", f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", "--GOPs=1",
+        f"--block_size={bs}", f"--block_size_min={bs}")
+    res = motion.residue_chain(filt, TRLs, bs, bs)
+    for t in range(1, TRLs):
+        np.testing.assert_array_equal(rd(tmp_path, f"motion_residue_{t}", np.int16), res[t].reshape(-1))
+        cs = open(tmp_path / f"motion_residue_{t}_comp3_0000.j2c", "rb").read()
+        np.testing.assert_array_equal(J.decode_s16(cs), motion.demux_components(res[t])[3, 0])
 
 
 def test_unsupported_requests_exit_nonzero(tmp_path):

@@ -114,3 +114,33 @@ def test_multi_sequence_batch_equals_single_calls(eng):
         assert got == eng.j2k_encode_frames(*it)
     hi = eng.get_frames(hip.HIGH, 2, 1, 1)[0]
     assert multi[1][3] == J.encode_plane(hi[:W * H].reshape(H, W), reversible=False, levels=3, layers=3, slopes=(47300, 46300, 45300))
+
+
+@pytest.mark.parametrize("n,H,W,amp", [(8, 9, 11, 40), (4, 135, 240, 300), (3, 17, 30, 16000), (5, 1, 1, 7), (2, 70, 66, 2000)])
+def test_motion_planes_s16_equal_restatement_and_decode(eng, n, H, W, amp):
+    """16-bit signed lossless planes (motion residues, motion_compress_j2k.py:131-142): HIP == restatement, decodes exactly."""
+    from qsvc_amd import hip
+    rng = np.random.default_rng(H * 1000 + W)
+    planes = rng.integers(-amp, amp + 1, size=(n, H, W)).astype(np.int16)
+    planes[0] = 0  # an all-zero residue plane (static scene): empty packets
+    got = eng.j2k_encode_planes_s16(planes, hip.j2k_params(reversible=True, levels=0, layers=1))
+    assert len(got) == n
+    for k in range(n):
+        assert got[k] == J.encode_plane_s16(planes[k]), k
+        np.testing.assert_array_equal(J.decode_s16(got[k]), planes[k])
+
+
+def test_motion_planes_s16_too_many_bitplanes_is_an_error(eng):
+    from qsvc_amd import hip
+    planes = np.full((1, 8, 8), -32768, dtype=np.int16)
+    with pytest.raises(hip.QsvcError):
+        eng.j2k_encode_planes_s16(planes, hip.j2k_params(reversible=True, levels=0, layers=1))
+
+
+def test_all_zero_planes_have_empty_packets(eng):
+    """No block of the batch has a bit-plane (a flat mid-grey plane): the Tier-1 job list is empty, the stream still decodes."""
+    from qsvc_amd import hip
+    pl = np.full((48, 80), 128, dtype=np.uint8)
+    cs = eng.j2k_encode_plane(pl, hip.j2k_params(reversible=True, levels=2))
+    assert cs == J.encode_plane(pl, reversible=True, levels=2)
+    np.testing.assert_array_equal(J.decode(cs), pl)

@@ -148,3 +148,23 @@ def test_halo_split_equals_whole_sequence(eng):
         np.testing.assert_array_equal(np.concatenate([left, right[1:]]), whole["low"])
     finally:
         e2.close()
+
+
+def test_degenerate_picture_counts(eng, oracle):
+    """pictures = 1 (no B picture: low_t is a copy), an even count (the last even picture is missing: refused, never
+    read out of bounds), and the minimum 3."""
+    from qsvc_amd import hip
+    W, H, bs, S = 64, 64, 16, 4
+    clip = make_clip("pan", 4, W, H, 2)
+    eng.seq_config(W, H)
+    eng.put_frames(hip.LOW, 0, clip[:1])
+    eng.analyze_step(1, 1, bs, S)
+    np.testing.assert_array_equal(eng.get_frames(hip.LOW, 1, 0, 1), clip[:1])
+    eng.put_frames(hip.LOW, 0, clip)            # 4 pictures: B picture 3 would need even picture 4
+    with pytest.raises(hip.QsvcError):
+        eng.motion_estimate(1, 4, bs, S)
+    eng.put_frames(hip.LOW, 0, clip[:3])
+    eng.analyze_step(1, 3, bs, S)
+    want = oracle.analyze_step(clip[:3], W, H, bs, S)
+    np.testing.assert_array_equal(eng.get_frames(hip.LOW, 1, 0, 2), want["low"])
+    np.testing.assert_array_equal(eng.get_frames(hip.HIGH, 1, 0, 1), want["high"])
