@@ -194,8 +194,8 @@ struct HostCb {  // host view of one coded block
 
 struct J2kState {
   DevBuf coefA, coefB, planes_d, cbs_d, nbps_d, mags, flags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
-  DevBuf waves_d, joboff_d, segs_d, cnt_d, dist_d;  // split Tier-1
-  std::vector<int> h_nbps, h_joboff, h_waves;
+  DevBuf waves_d, joboff_d, order_d, segs_d, cnt_d, dist_d;  // split Tier-1
+  std::vector<int> h_nbps, h_joboff, h_waves, h_order;
   std::vector<uint8_t> t2scratch;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
   std::vector<PlaneDesc> planes;
@@ -211,7 +211,7 @@ void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->coefB, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->flags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->waves_d, &s->joboff_d, &s->segs_d, &s->cnt_d, &s->dist_d};
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->waves_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   delete s;
@@ -428,6 +428,39 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
       for (int p = 0; p < mx; p++) S.h_waves.push_back((g << 8) | p);
     }
     const int nwaves = (int)S.h_waves.size();
+    // MQ slot table: slot k of the MQ launch codes block order[k] (ncb = idle lane).  The blocks with the longest expected
+    // chains (bit-planes x area) are set apart in waves of few lanes, whose lock-step costs less per decision; the others
+    // keep their natural order, 16 to a wave.  QSVC_MQ_NARROW="<fraction>,<lanes>" (default off = "0,16").
+    static const double narrow_frac = [] { const char* e = getenv("QSVC_MQ_NARROW"); return e ? atof(e) : 0.0; }();
+    static const int narrow_lanes = [] { const char* e = getenv("QSVC_MQ_NARROW"); const char* q = e ? strchr(e, ',') : nullptr; int v = q ? atoi(q + 1) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    const int MQW = 16;
+    int nslots = 0;
+    {
+      std::vector<int>& ord = S.h_order;
+      ord.clear();
+      int nn = (int)(narrow_frac * ncb);
+      if (nn > 0) {
+        int hist[15 * 64 + 2] = {0};
+        auto key = [&](int b) { int nb = S.h_nbps[b] > 15 ? 15 : S.h_nbps[b]; return 15 * 64 - nb * (((int)S.cbs[b].w * S.cbs[b].h + 63) >> 6); };
+        for (int b = 0; b < ncb; b++) hist[key(b) + 1]++;
+        for (int k = 1; k <= 15 * 64; k++) hist[k] += hist[k - 1];
+        std::vector<int> sorted(ncb);
+        for (int b = 0; b < ncb; b++) sorted[hist[key(b)]++] = b;
+        std::vector<char> taken(ncb, 0);
+        for (int i = 0; i < nn; i += narrow_lanes) {
+          for (int l = 0; l < MQW; l++) ord.push_back(l < narrow_lanes && i + l < nn ? sorted[i + l] : ncb);
+          for (int l = 0; l < narrow_lanes && i + l < nn; l++) taken[sorted[i + l]] = 1;
+        }
+        for (int b = 0; b < ncb; b++) if (!taken[b]) ord.push_back(b);
+      } else {
+        ord.resize(ncb);
+        for (int b = 0; b < ncb; b++) ord[b] = b;
+      }
+      while (ord.size() % MQW) ord.push_back(ncb);
+      nslots = (int)ord.size();
+    }
+    if ((r = S.order_d.ensure(c, (size_t)nslots * 4))) return r;
+    HIPCHK(c, hipMemcpyAsync(S.order_d.p, S.h_order.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, c->st));
     // the MQ stage reads joboff[b] of every block, also when no block of the batch has a bit-plane (all-zero planes)
     if ((r = S.joboff_d.ensure(c, (size_t)ncb * 4))) return r;
     HIPCHK(c, hipMemcpyAsync(S.joboff_d.p, S.h_joboff.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
@@ -443,7 +476,7 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
       if (!nwaves && stage < 2) continue;
       pf.begin(c, stage == 0 ? "j2k_t1_flags" : (stage == 1 ? "j2k_t1_cm" : "j2k_t1_mq"));
       launch_t1_split(c->st, (const int*)S.waves_d.p, nwaves, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p,
-                      (const uint32_t*)S.mags.p, (uint32_t*)S.flags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p,
+                      (const int*)S.order_d.p, nslots, (const uint32_t*)S.mags.p, (uint32_t*)S.flags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p,
                       (uint8_t*)S.outbuf.p, J2K_OUTCAP, (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, stage);
       pf.end(c);
     }

@@ -412,15 +412,18 @@ __global__ void __launch_bounds__(CML) k_t1_cm(const int* waves, const CbDesc* c
 
 template <int T1_MQ_LANES>
 __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
-                                                        const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf,
+                                                        const int* order, int nslots, const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf,
                                                         int outcap, CbOut* res, int* pass_len, long long* pass_dist) {
   __shared__ uint32_t s_cx[19 * T1_MQ_LANES];
   __shared__ uint32_t s_mq[64];
-  int lane = threadIdx.x, b = blockIdx.x * T1_MQ_LANES + lane;
+  __shared__ uint64_t s_mq2[94];
+  // order[]: the host's slot table (block index, or ncb for an idle lane)
+  int lane = threadIdx.x, slot = blockIdx.x * T1_MQ_LANES + lane, b = slot < nslots ? order[slot] : ncb;
   for (int i = lane; i < 47; i += T1_MQ_LANES) s_mq[i] = c_mqtab[i];
+  for (int i = lane; i < 94; i += T1_MQ_LANES) s_mq2[i] = mq2_pair(c_mqtab, i);
   __syncthreads();
   T1Lane t;
-  t.cx = s_cx + lane; t.cs = T1_MQ_LANES; t.mqtab = s_mq; t.zclut = nullptr;
+  t.cx = s_cx + lane; t.cs = T1_MQ_LANES; t.mqtab = s_mq; t.mq2 = s_mq2; t.zclut = nullptr;
   t.w = t.h = t.orient = 0; t.nbps = 0; t.out = outbuf; t.cap = 0;
   size_t job0 = 0;
   if (b < ncb) { t.nbps = nbps_in[b]; t.out = outbuf + (size_t)b * outcap; t.cap = outcap; job0 = (size_t)joboff[b]; }
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
   int bb = b < ncb ? b : 0;
   int* pl = pass_len + (size_t)bb * T1_MAXPASS;
   long long* pd = pass_dist ? pass_dist + (size_t)bb * T1_MAXPASS : nullptr;
-  t1_lane_init(t);
+  mq2_lane_init(t);
   int np = 0;
   for (int p = top; p >= 0; p--) {
     const bool active = p < t.nbps, first = p == t.nbps - 1;
@@ -451,22 +454,16 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
         asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w)::"memory");
         uint4 nxt = make_uint4(0, 0, 0, 0);
         if (i + 16 < n) nxt = sg[(i >> 4) + 1];  // next 16 decisions in flight while these are coded
-        uint32_t wds[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          if (i + j < n) {
-            const int v = (wds[j >> 2] >> (8 * (j & 3))) & 0xFF;
-            mq_encode(t, v & 31, v >> 5);
-          }
-        }
+        mq2_chunk16(t, cur.x, cur.y, cur.z, cur.w, n - i);
         cur = nxt;
       }
+      t.nsym += (uint32_t)n;
       if (lane_pass) { pl[np] = t.n + 4; if (pd) pd[np] = dist[job * 3 + pass]; np++; }
     }
   }
   T1Result r;
   r.pass_len = pl; r.pass_dist = pd;
-  t1_lane_finish(t, np, r);
+  t1_lane_finish<true>(t, np, r);
   if (b < ncb) {
     CbOut o;
     o.len = r.len; o.npasses = r.npasses; o.nbps = r.nbps; o.overflow = r.overflow; o.nsym = r.nsym;
@@ -475,7 +472,7 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
 }
 
 void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff,
-                     const uint32_t* mags, uint32_t* flags, uint8_t* segs, int* cnt, long long* dist, uint8_t* outbuf, int outcap,
+                     const int* order, int nslots, const uint32_t* mags, uint32_t* flags, uint8_t* segs, int* cnt, long long* dist, uint8_t* outbuf, int outcap,
                      CbOut* res, int* pass_len, long long* pass_dist, int want_dist, int stage) {
   if (stage == 0) {
     hipLaunchKernelGGL(k_t1_flags_init, dim3((T1_FLAGS_WORDS * 64 + 255) / 256, nwaves), dim3(256), 0, st, waves, cbs, ncb, nbps, mags, flags);
@@ -487,7 +484,7 @@ void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc*
   } else {
     static const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 16; return (v == 4 || v == 8 || v == 32 || v == 64) ? v : 16; }();
     long long* pdp = want_dist ? pass_dist : nullptr;
-#define MQ_LAUNCH(N) hipLaunchKernelGGL(k_t1_mq<N>, dim3((ncb + N - 1) / N), dim3(N), 0, st, cbs, ncb, nbps, joboff, segs, cnt, dist, outbuf, outcap, res, pass_len, pdp)
+#define MQ_LAUNCH(N) hipLaunchKernelGGL(k_t1_mq<N>, dim3((nslots + N - 1) / N), dim3(N), 0, st, cbs, ncb, nbps, joboff, order, nslots, segs, cnt, dist, outbuf, outcap, res, pass_len, pdp)
     switch (ml) { case 4: MQ_LAUNCH(4); break; case 8: MQ_LAUNCH(8); break; case 32: MQ_LAUNCH(32); break; case 64: MQ_LAUNCH(64); break; default: MQ_LAUNCH(16); }
 #undef MQ_LAUNCH
   }

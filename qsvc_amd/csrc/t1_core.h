@@ -100,6 +100,7 @@ struct T1Lane {
   uint32_t* cx;           // this lane's context states, one packed word each: the state's table entry
                           // (qe | nmps<<16 | nlps<<22 | switch<<28) | mps<<29; context c at cx[c*cs]
   const uint32_t* mqtab;  // [47]
+  const uint64_t* mq2;    // [94] successor pairs of the second coder form (mq2_*), or nullptr
   const uint8_t* zclut;   // [3][512] zero-coding LUT (class 0: LL/LH, 1: HL, 2: HH)
   uint8_t* out;           // 4-byte aligned; out[0] is a scratch byte; the segment is out[1..]
   int cs;
@@ -183,6 +184,94 @@ T1HD int mq_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment lengt
   if (t.B != 0xFF) mq_emit(t);
   if ((t.n & 3) && (t.n & ~3) + 4 <= t.cap) *(uint32_t*)(t.out + (t.n & ~3)) = t.ob;  // the partial last word
   return t.n - 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second coder form (the split MQ kernel): straight-line, 16 decisions per call.
+// A context word describes itself: qe | 8*(2*state + mps) << 16.  mq2[2*state + mps] holds the two possible successors
+// (low half: after an MPS renormalisation; high half: after an LPS, MPS flipped where SWITCH is set), so a decision needs
+// one context read and one table read, both issued ahead of their use: the context of decision j+1 is fetched while
+// decision j is coded and replaced by j's result when both use the same context.
+// With addc = "C += Qe", seta = "A = Qe" (T.800 C.2.4/C.2.5): seta == (ismps == (A - Qe < Qe)) and addc == !seta, because
+// A - Qe < Qe implies A - Qe < 0x8000.
+T1HD uint32_t mq2_word(const uint32_t* mqtab, int state, int mps) {
+  return (mqtab[state] & 0xFFFF) | (uint32_t)(8 * (2 * state + mps)) << 16;
+}
+T1HD uint64_t mq2_pair(const uint32_t* mqtab, int idx) {  // idx = 2*state + mps
+  const uint32_t e = mqtab[idx >> 1];
+  const int mps = idx & 1, sw = (int)((e >> 28) & 1);
+  return (uint64_t)mq2_word(mqtab, (int)((e >> 16) & 63), mps) | (uint64_t)mq2_word(mqtab, (int)((e >> 22) & 63), mps ^ sw) << 32;
+}
+T1HD void mq2_lane_init(T1Lane& t) {  // as t1_lane_init, context words in the second form
+  for (int c = 0; c < 19; c++) t.cx[c * t.cs] = mq2_word(t.mqtab, 0, 0);
+  t.cx[0 * t.cs] = mq2_word(t.mqtab, 4, 0); t.cx[T1_CTX_RUN * t.cs] = mq2_word(t.mqtab, 3, 0);
+  t.cx[T1_CTX_UNI * t.cs] = mq2_word(t.mqtab, 46, 0);
+  t.A = 0x8000; t.C = 0; t.CT = 12; t.B = 0; t.n = 0; t.ob = 0; t.nsym = 0;
+}
+T1HD int mq2_clz(uint32_t v) {  // v != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_clz(v);
+#else
+  return __builtin_clz(v);
+#endif
+}
+// BYTEOUT with a plain byte store per byte (no word packing: nothing but the store depends on the lane's byte count).
+T1HD void mq2_emit(T1Lane& t) {
+  t.out[t.n < t.cap ? t.n : t.cap - 1] = (uint8_t)t.B;  // past the capacity only `n` keeps counting (-> overflow)
+  t.n++;
+}
+T1HD void mq2_byteout(T1Lane& t) {
+  uint32_t carry = (t.C >> 27) & (uint32_t)(t.B != 0xFF);
+  t.B += (int)carry;
+  const bool ff = t.B == 0xFF;
+  if (carry && ff) t.C &= 0x7FFFFFF;
+  mq2_emit(t);
+  t.B = ff ? (int)((t.C >> 20) & 0xFF) : (int)((t.C >> 19) & 0xFF);
+  t.C &= ff ? 0xFFFFFu : 0x7FFFFu;
+  t.CT = ff ? 7 : 8;
+}
+T1HD int mq2_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment length
+  uint32_t tempc = t.C + t.A;
+  t.C |= 0xFFFF;
+  if (t.C >= tempc) t.C -= 0x8000;
+  t.C <<= t.CT; mq2_byteout(t);
+  t.C <<= t.CT; mq2_byteout(t);
+  if (t.B != 0xFF) mq2_emit(t);
+  return t.n - 1;
+}
+// decisions: bytes cx | d << 5, little-endian in w0..w3; only the first nvalid (<= 16, may be <= 0) are coded.
+T1HD void mq2_chunk16(T1Lane& t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int nvalid) {
+  const uint32_t w[4] = {w0, w1, w2, w3};
+  uint32_t A = t.A;
+  uint32_t e = t.cx[(int)(w0 & 31) * t.cs];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint32_t v = w[j >> 2] >> (8 * (j & 3));
+    const int cx = (int)(v & 31);
+    uint32_t epre = 0;
+    int cx1 = -1;
+    if (j < 15) { cx1 = (int)((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 31); epre = t.cx[cx1 * t.cs]; }
+    const uint64_t succ = *(const uint64_t*)((const char*)t.mq2 + (e >> 16));
+    const bool valid = j < nvalid;
+    const uint32_t qe = valid ? (e & 0xFFFF) : 0u;
+    const bool ismps = !valid || ((v >> 5) & 1) == ((e >> 19) & 1);
+    A -= qe;
+    const bool lt = A < qe;
+    const bool ren = !ismps || A < 0x8000u;
+    const bool seta = ismps == lt;
+    t.C += seta ? 0u : qe;
+    A = seta ? qe : A;
+    const uint32_t en = ren ? (ismps ? (uint32_t)succ : (uint32_t)(succ >> 32)) : e;
+    t.cx[cx * t.cs] = en;
+    int sh = mq2_clz(A) - 16;  // 0 unless renormalising: A is in [0x8000, 0xFFFF] otherwise
+    A <<= sh;
+    if (sh >= t.CT) {
+      do { t.C <<= t.CT; sh -= t.CT; mq2_byteout(t); } while (sh >= t.CT);
+    }
+    t.C <<= sh; t.CT -= sh;
+    e = cx1 == cx ? en : epre;
+  }
+  t.A = A;
 }
 
 T1HD int t1_mag(uint64_t m, int k) { return (int)((m >> (16 * k)) & 0x7FFF); }
@@ -355,10 +444,11 @@ T1HD void t1_lane_init(T1Lane& t) {  // context reset (T.800 Table D.7) + INITEN
   t.cx[0 * t.cs] = t.mqtab[4]; t.cx[T1_CTX_RUN * t.cs] = t.mqtab[3]; t.cx[T1_CTX_UNI * t.cs] = t.mqtab[46];
   t.A = 0x8000; t.C = 0; t.CT = 12; t.B = 0; t.n = 0; t.ob = 0; t.nsym = 0;
 }
+template <bool MQ2 = false>
 T1HD void t1_lane_finish(T1Lane& t, int np, T1Result& res) {
   res.npasses = np;
   res.nbps = t.nbps;
-  res.len = t.nbps ? mq_flush(t) : 0;
+  res.len = t.nbps ? (MQ2 ? mq2_flush(t) : mq_flush(t)) : 0;
   res.overflow = ((t.n + 3) & ~3) > t.cap;
   res.nsym = t.nsym;
   for (int i = 0; i < np; i++) if (res.pass_len[i] > res.len) res.pass_len[i] = res.len;
@@ -460,18 +550,23 @@ T1HD void t1_cm_plane(Store& S, const uint8_t* zclut, uint8_t* seg, int p, int w
 // Cnt(p, pass) -> decisions in that pass.  Sequential per lane; different lanes run different lengths.
 template <class SegF, class CntF, class DistF>
 T1HD void t1_mq_block(T1Lane& t, const SegF& Seg, const CntF& Cnt, const DistF& Dist, T1Result& res) {
-  t1_lane_init(t);
+  mq2_lane_init(t);
   int np = 0;
   for (int p = t.nbps - 1; p >= 0; p--)
     for (int pass = (p == t.nbps - 1 ? 2 : 0); pass < 3; pass++) {
       const uint8_t* sg = Seg(p) + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
       int n = Cnt(p, pass);
-      for (int i = 0; i < n; i++) { int v = sg[i]; mq_encode(t, v & 31, v >> 5); }
+      for (int i = 0; i < n; i += 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 16 && i + k < n; k++) w[k >> 2] |= (uint32_t)sg[i + k] << (8 * (k & 3));
+        mq2_chunk16(t, w[0], w[1], w[2], w[3], n - i);
+      }
+      t.nsym += (uint32_t)n;
       res.pass_len[np] = t.n + 4;
       if (res.pass_dist) res.pass_dist[np] = Dist(p, pass);
       np++;
     }
-  t1_lane_finish(t, np, res);
+  t1_lane_finish<true>(t, np, res);
 }
 
 // Host/array store: lane stride ls (1 on the host harness).

@@ -213,8 +213,10 @@ extern "C" int emul_t1_block_split(const int32_t* vals, int w, int h, int orient
   uint32_t cx[19];
   std::vector<uint32_t> buf32((size_t)w * h + 16);
   uint8_t* bufp = (uint8_t*)buf32.data();
+  static uint64_t mq2[94];
+  for (int i = 0; i < 94; i++) mq2[i] = mq2_pair(mqtab, i);
   T1Lane t;
-  t.cx = cx; t.mqtab = mqtab; t.zclut = zclut; t.out = bufp;
+  t.cx = cx; t.mqtab = mqtab; t.mq2 = mq2; t.zclut = zclut; t.out = bufp;
   t.cs = 1; t.cap = (int)buf32.size() * 4; t.w = w; t.h = h; t.orient = orient; t.nbps = nb;
   T1Result r;
   int pl[T1_MAXPASS]; long long pd[T1_MAXPASS];
