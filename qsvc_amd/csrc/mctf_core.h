@@ -159,6 +159,26 @@ QHD int predict_chroma_full(const uint8_t* u0, const uint8_t* u1, const BorderGe
   int by = y / bs, bx = x / bs;
   return (chroma_up_b(u0, g, y + mv.py(by, bx), x + mv.px(by, bx)) + chroma_up_b(u1, g, y + mv.ny(by, bx), x + mv.nx(by, bx))) >> 1;
 }
+// Q7 -- pictures the block grid does not tile.  predict() writes only rows < BY*bs and columns < BX*bs of its three
+// full-resolution planes (decorrelate.cpp:86-108); the planes are allocated once and never cleared, so the margin keeps what
+// the previous picture left there: zero for luma (nothing else writes it), and for chroma whatever the in-place 1-level
+// analysis of the previous picture (decorrelate.cpp:860-861) put at those Mallat positions, clipped to 0..255 with the
+// rest of the plane (decorrelate.cpp:841-848) before the next analysis reads it.  MarginGeom indexes that margin compactly:
+// first the bottom band (rows >= Hb, all columns), then the right band (rows < Hb, columns >= Wb).
+struct MarginGeom {
+  int H, W, Hb, Wb;
+  QHDM size_t count() const { return (size_t)(H - Hb) * W + (size_t)Hb * (W - Wb); }
+  QHDM bool inside(int y, int x) const { return y < Hb && x < Wb; }  // written by predict()
+  QHDM size_t index(int y, int x) const {
+    return y >= Hb ? (size_t)(y - Hb) * W + x : (size_t)(H - Hb) * W + (size_t)y * (W - Wb) + (x - Wb);
+  }
+  QHDM void coords(size_t k, int& y, int& x) const {
+    size_t nb = (size_t)(H - Hb) * W;
+    if (k < nb) { y = Hb + (int)(k / W); x = (int)(k % W); }
+    else { k -= nb; y = (int)(k / (W - Wb)); x = Wb + (int)(k % (W - Wb)); }
+  }
+};
+
 // Chroma /2 (decorrelate.cpp:860-861): LL sample (j,i) of a 1-level analysis (rows, then columns) of
 // the full-resolution plane P(y,x).
 template <class Plane>

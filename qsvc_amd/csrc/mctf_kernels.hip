@@ -95,18 +95,23 @@ __global__ void __launch_bounds__(256) k_pred_luma8(PredArgs a) {
     const uint8_t* od = frame_y(a.frames, g, 2 * i + 1) + (size_t)y * g.W + x;
     const int by = y / g.bs, bx = x / g.bs;
     const size_t fld = (size_t)g.BY * g.BX;
-    const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)by * g.BX + bx;
+    const bool predicted = by < g.BY && bx < g.BX;  // Q7: the margin of the luma prediction plane stays zero
+    const int16_t* m = a.mv + (size_t)i * 4 * fld + (predicted ? (size_t)by * g.BX + bx : 0);
     const int x0 = x + m[0], y0 = y + m[fld], x1 = x + m[2 * fld], y1 = y + m[3 * fld];
     const int n = g.W - x < 8 ? g.W - x : 8;
     uint8_t p0[8], p1[8], o[8];
-    if (n == 8 && y0 >= 0 && y0 < g.H && x0 >= 0 && x0 + 8 <= g.W) {
+    if (!predicted) {
+      for (int k = 0; k < 8; k++) p0[k] = 0;
+    } else if (n == 8 && y0 >= 0 && y0 < g.H && x0 >= 0 && x0 + 8 <= g.W) {
       uint64_t v = ld8u(r0 + (size_t)y0 * g.W + x0);
       __builtin_memcpy(p0, &v, 8);
     } else {
       BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
       for (int k = 0; k < 8; k++) p0[k] = (uint8_t)luma_b(r0, bg, y0, x0 + k);
     }
-    if (n == 8 && y1 >= 0 && y1 < g.H && x1 >= 0 && x1 + 8 <= g.W) {
+    if (!predicted) {
+      for (int k = 0; k < 8; k++) p1[k] = 0;
+    } else if (n == 8 && y1 >= 0 && y1 < g.H && x1 >= 0 && x1 + 8 <= g.W) {
       uint64_t v = ld8u(r1 + (size_t)y1 * g.W + x1);
       __builtin_memcpy(p1, &v, 8);
     } else {
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(256) k_pred_chroma(PredArgs a) {
   for (int k = tid; k < PC_FH * PC_FW; k += 256) {
     int yy = yb + k / PC_FW, xx = xb + k % PC_FW;
     int v = 0;
-    if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) v = predict_chroma_full(u0, u1, bg, mv, g.bs, yy, xx);
+    if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) v = pred_chroma_sample(a, u0, u1, bg, mv, i, c, yy, xx);
     sP[k / PC_FW][k % PC_FW] = (int16_t)v;
   }
   __syncthreads();
@@ -206,6 +211,11 @@ __global__ void __launch_bounds__(256) k_pred_chroma(PredArgs a) {
     if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;
   }
 }
+// Q7: the chroma margin state picture i leaves behind (one launch per picture, in order)
+__global__ void __launch_bounds__(256) k_pred_margin(PredArgs a, int i) {
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < margin_geom(a.g).count()) pred_margin_thread(a, k, i, 1 + (int)blockIdx.y);
+}
 // histogram of the motion components + 128 (decorrelate.cpp:805-812)
 __global__ void __launch_bounds__(256) k_mv_hist(const int16_t* mv, size_t per_pic, unsigned* hist) {
   __shared__ unsigned h[256];
@@ -222,6 +232,11 @@ void launch_predict(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
   hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
   dim3 block(64, 4);
+  if (a.margin) {
+    size_t cnt = margin_geom(g).count();
+    for (int i = 0; i + 1 < g.nB; i++)  // the last picture's state has no reader
+      hipLaunchKernelGGL(k_pred_margin, dim3((unsigned)((cnt + 255) / 256), 2), dim3(256), 0, st, a, i);
+  }
   if (g.bs % 8 == 0) hipLaunchKernelGGL(k_pred_luma8, dim3((g.W + 511) / 512, (g.H + 3) / 4, g.nB), block, 0, st, a);
   else hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);
   hipLaunchKernelGGL(k_pred_chroma, dim3((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, g.nB * 2), block, 0, st, a);

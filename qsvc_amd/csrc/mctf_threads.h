@@ -97,13 +97,18 @@ struct PredArgs {
   uint8_t* high;          // [nB][F]  residue + 128
   uint8_t* pred_dump;     // [nB][F] or nullptr (prediction_<even_fn> debug picture)
   unsigned* hist;         // [nB][3][256]
+  int16_t* margin;        // Q7: [nB][2][MarginGeom::count()] chroma margin state AFTER each picture; nullptr when the
+                          // block grid tiles the picture
 };
+QHD MarginGeom margin_geom(const LevelGeom& g) { return {g.H, g.W, g.BY * g.bs, g.BX * g.bs}; }
 // luma: returns the two histogram bins through odd_bin / res_bin
 QHD void pred_luma_thread(const PredArgs& a, int x, int y, int i, int& odd_bin, int& res_bin) {
   const LevelGeom& g = a.g;
   BorderGeom bg = make_border(g.H, g.W, 4 * g.S);  // decorrelate.cpp:539
   MvField mv = {a.mv + (size_t)i * 4 * g.BY * g.BX, g.BY, g.BX};
-  int p = predict_luma(frame_y(a.frames, g, 2 * i), frame_y(a.frames, g, 2 * i + 2), bg, mv, g.bs, y, x);
+  int p = 0;  // Q7: the unpredicted margin of the luma plane stays zero
+  if (y < g.BY * g.bs && x < g.BX * g.bs)
+    p = predict_luma(frame_y(a.frames, g, 2 * i), frame_y(a.frames, g, 2 * i + 2), bg, mv, g.bs, y, x);
   int o = frame_y(a.frames, g, 2 * i + 1)[(size_t)y * g.W + x];
   int val = iclamp(o - p, -128, 127);  // decorrelate.cpp:920-929
   size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
@@ -111,13 +116,35 @@ QHD void pred_luma_thread(const PredArgs& a, int x, int y, int i, int& odd_bin, 
   if (a.pred_dump) a.pred_dump[off] = (uint8_t)p;
   odd_bin = o; res_bin = val + 128;
 }
+// one sample of picture i's full-resolution chroma prediction plane as the chroma/2 analysis sees it (after the clip)
+QHD int pred_chroma_sample(const PredArgs& a, const uint8_t* u0, const uint8_t* u1, const BorderGeom& bg, const MvField& mv,
+                           int i, int c, int yy, int xx) {
+  if (!a.margin) return predict_chroma_full(u0, u1, bg, mv, a.g.bs, yy, xx);
+  MarginGeom mg = margin_geom(a.g);
+  if (mg.inside(yy, xx)) return predict_chroma_full(u0, u1, bg, mv, a.g.bs, yy, xx);
+  if (i == 0) return 0;  // fresh planes
+  return iclamp(a.margin[((size_t)(i - 1) * 2 + (c - 1)) * mg.count() + mg.index(yy, xx)], 0, 255);
+}
+// Q7: margin position k of picture i's analysed plane = the state picture i+1 starts from.  Pictures in order.
+QHD void pred_margin_thread(const PredArgs& a, size_t k, int i, int c /*1|2*/) {
+  const LevelGeom& g = a.g;
+  BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+  MvField mv = {a.mv + (size_t)i * 4 * g.BY * g.BX, g.BY, g.BX};
+  const uint8_t* u0 = frame_c(a.frames, g, 2 * i, c);
+  const uint8_t* u1 = frame_c(a.frames, g, 2 * i + 2, c);
+  MarginGeom mg = margin_geom(g);
+  int y, x;
+  mg.coords(k, y, x);
+  auto P = [&](int yy, int xx) { return pred_chroma_sample(a, u0, u1, bg, mv, i, c, yy, xx); };
+  a.margin[((size_t)i * 2 + (c - 1)) * mg.count() + k] = (int16_t)analyze2d_coef(P, y, x, g.H, g.W);
+}
 QHD void pred_chroma_thread(const PredArgs& a, int ci, int cj, int i, int c /*1|2*/) {
   const LevelGeom& g = a.g;
   BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
   MvField mv = {a.mv + (size_t)i * 4 * g.BY * g.BX, g.BY, g.BX};
   const uint8_t* u0 = frame_c(a.frames, g, 2 * i, c);
   const uint8_t* u1 = frame_c(a.frames, g, 2 * i + 2, c);
-  auto P = [&](int yy, int xx) { return predict_chroma_full(u0, u1, bg, mv, g.bs, yy, xx); };
+  auto P = [&](int yy, int xx) { return pred_chroma_sample(a, u0, u1, bg, mv, i, c, yy, xx); };
   int ll = analyze_ll(P, cj, ci, g.H, g.W);  // chroma /2 of the full-resolution prediction
   int cw = g.W / 2;
   int o = frame_c(a.frames, g, 2 * i + 1, c)[(size_t)cj * cw + ci];

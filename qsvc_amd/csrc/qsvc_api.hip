@@ -98,6 +98,7 @@ void qsvc_destroy(qsvc_ctx* c) {
   for (auto& b : c->snap) b.release();
   c->mvtmp[0].release(); c->mvtmp[1].release();
   for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); }
+  c->margin.release();
   if (c->comm) qsvc_comm_destroy(c);
   c->scal.release(); c->tmp16[0].release(); c->tmp16[1].release();
   j2k_release(c);
@@ -218,10 +219,9 @@ static int level_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g) {
   // every B picture 2i+1 needs the even pictures 2i and 2i+2 (motion_estimate.cpp:792-820): 2*(P/2)+1 pictures in all
   if (c->lv[t - 1].low_n < 2 * (P / 2) + 1 || c->lv[t - 1].low_n < P)
     return c->fail(QSVC_ERR_STATE, "low_%d holds %d pictures, %d needed", t - 1, c->lv[t - 1].low_n, std::max(P, 2 * (P / 2) + 1));
-  // rows/cols beyond BY*bs are never predicted by the reference and keep stale heap state there
-  // (decorrelate.cpp:508-509,562-567; trunk/readme.txt:119-125) -- not reproduced on this path.
-  if (c->H % bs || c->W % bs)
-    return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d is not a multiple of block_size %d", c->W, c->H, bs);
+  // rows/cols beyond BY*bs are never predicted by the reference (decorrelate.cpp:508-509,562-567; trunk/readme.txt:119-125):
+  // Q7, reproduced by the margin state of PredArgs (mctf_threads.h)
+  if (c->H < bs || c->W < bs) return c->fail(QSVC_ERR_INVALID, "picture %dx%d smaller than block_size %d", c->W, c->H, bs);
   g->W = c->W; g->H = c->H; g->bs = bs; g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
   return QSVC_OK;
 }
@@ -308,6 +308,12 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   PredArgs a;
   a.g = g; a.frames = (const uint8_t*)c->lv[t - 1].low.p; a.mv = (const int16_t*)lv.mv_raw.p;
   a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = (unsigned*)lv.hist.p;
+  a.margin = nullptr;
+  lv.ragged = (g.H % bs || g.W % bs);
+  if (lv.ragged) {  // Q7: the chroma margins carry state from picture to picture
+    if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
+    a.margin = (int16_t*)c->margin.p;
+  }
   Prof pf;
   pf.begin(c, "predict");
   launch_predict(c->st, a);
@@ -395,7 +401,14 @@ size_t qsvc_halo_bytes(qsvc_ctx* c, int bs) {
   return c->F + (size_t)4 * (c->H / bs) * (c->W / bs) * sizeof(int16_t) + 16;
 }
 // pack our boundary B picture of level t into the context's send buffer `side`
+// The stale-margin recurrence of a ragged picture (Q7) runs through every picture of the level in order: a shard cannot
+// start it in the middle, so the open-GOP split is refused there.
+static int halo_ragged(qsvc_ctx* c, int t) {
+  return c->lv[t].ragged ? c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d is not a multiple of the block size: its prediction margins depend "
+                                   "on every earlier picture of the level, the sequence cannot be split across GPUs", c->W, c->H) : QSVC_OK;
+}
 static int halo_pack(qsvc_ctx* c, int t, int side) {
+  if (int rr = halo_ragged(c, t)) return rr;
   Level& lv = c->lv[t];
   int nB = lv.high_n;
   if (nB < 1 || lv.mv_filt_n < nB || (int)lv.types.size() < nB) return c->fail(QSVC_ERR_STATE, "nothing to export for t=%d", t);

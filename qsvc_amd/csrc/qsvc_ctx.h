@@ -30,6 +30,7 @@ struct Level {  // the device-resident "files" of temporal subband t
   DevBuf hist;                   // [nB][3][256] u32
   std::string types;             // frame_types_t
   const void* halo[2] = {nullptr, nullptr};
+  bool ragged = false;           // Q7: decorrelate ran on a picture the block grid does not tile
 };
 
 struct Seg {
@@ -52,6 +53,7 @@ struct qsvc_ctx {
   int keep_pred = 0;
   std::vector<Level> lv;
   std::vector<DevBuf> snap;  // ME pyramid snapshots per DWT level
+  DevBuf margin;             // Q7 chroma margin state of the level being decorrelated
   DevBuf mvtmp[2], scal, tmp16[2];
   DevBuf halo_tx[2], halo_rx[2];  // boundary records: [0] left neighbour, [1] right neighbour
   uint8_t halo_tb[2][16];

@@ -87,11 +87,17 @@ int emul_motion_estimate(const uint8_t* low, int P, int W, int H, int bs, int S,
 int emul_predict(const uint8_t* low, int P, int W, int H, int bs, int S, const int16_t* mv, uint8_t* high, uint8_t* pred,
                  unsigned* hist /*[nB][3][256]*/) {
   LevelGeom g = make_geom(P, W, H, bs, S);
-  if (H % bs || W % bs || (W & 1) || (H & 1)) return -2;
-  PredArgs a = {g, low, mv, high, pred, hist};
+  if ((W & 1) || (H & 1)) return -2;
+  std::vector<int16_t> margin;
+  MarginGeom mg = margin_geom(g);
+  if (H % bs || W % bs) margin.assign((size_t)(g.nB ? g.nB : 1) * 2 * mg.count(), 0);  // Q7
+  PredArgs a = {g, low, mv, high, pred, hist, margin.empty() ? nullptr : margin.data()};
   memset(hist, 0, sizeof(unsigned) * g.nB * 3 * 256);
   size_t fld = (size_t)g.BY * g.BX;
   for (int i = 0; i < g.nB; i++) {
+    if (a.margin)  // one launch per picture, in order: picture i reads the state picture i-1 left
+      for (int c = 1; c < 3; c++)
+        for (size_t k = 0; k < mg.count(); k++) pred_margin_thread(a, k, i, c);
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) {
         int ob, rb;
@@ -110,7 +116,7 @@ int emul_update(const uint8_t* low, int P, int W, int H, int bs, const uint8_t* 
                 float uf, int reach, const uint8_t* halo_l, int halo_l_type, const uint8_t* halo_r, int halo_r_type,
                 uint8_t* low_out) {
   LevelGeom g = make_geom(P, W, H, bs, 0);
-  if (H % bs || W % bs || (W & 1) || (H & 1)) return -2;
+  if ((W & 1) || (H & 1)) return -2;
   UpdArgs a;
   a.g = g; a.frames = low; a.high = high; a.mv = mv; a.types = (const uint8_t*)types; a.low = low_out; a.uf = uf; a.reach = reach;
   a.halo_high[0] = halo_l; a.halo_mv[0] = halo_l ? (const int16_t*)(halo_l + g.F) : nullptr; a.halo_type[0] = halo_l ? halo_l_type : 0;

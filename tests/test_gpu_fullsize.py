@@ -54,6 +54,25 @@ def test_config3_1080p_gop16_three_levels(eng, oracle):
     assert all(out[k] == out2[k] for k in out)
 
 
+def test_1080p_default_block_size_is_ragged(eng, oracle):
+    """The reference's default block size at 1080p is 64 (compress.py:139-142) and 1080 = 16*64 + 56: the bottom 56 rows
+    are never predicted (Q7).  Two B pictures == oracle, bytes for bytes, including the second picture's stale chroma margin."""
+    from qsvc_amd import hip
+    W, H, bs = 1920, 1080, 64
+    clip = make_clip("pan_noise", 5, W, H, 43)
+    eng.seq_config(W, H, keep_prediction=True)
+    eng.put_frames(hip.LOW, 0, clip)
+    eng.analyze_step(1, 5, bs, 4)
+    want = oracle.analyze_step(clip, W, H, bs, 4, want_prediction=True)
+    np.testing.assert_array_equal(eng.get_motion(hip.MOTION_RAW, 1, 2, bs), want["motion"])
+    np.testing.assert_array_equal(eng.get_frames(hip.PRED, 1, 0, 2), want["prediction"])
+    np.testing.assert_array_equal(eng.get_frames(hip.HIGH, 1, 0, 2), want["high"])
+    np.testing.assert_array_equal(eng.get_frames(hip.LOW, 1, 0, 3), want["low"])
+    assert bytes(eng.get_frame_types(1, 2)) == bytes(want["frame_types"])
+    with pytest.raises(hip.QsvcError):  # the margin recurrence cannot be cut at a GPU boundary
+        eng.halo_export(1, 1, bs)
+
+
 def test_config4_4k_gop32_97(eng, oracle):
     """3840x2160, 33 pictures, TRLs=5 (search 4..32), block 16, 9/7 irreversible, 5 spatial levels."""
     from qsvc_amd import hip

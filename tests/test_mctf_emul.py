@@ -1,0 +1,64 @@
+"""The kernels' per-thread code (qsvc_amd/csrc/mctf_threads.h), driven by host loops (tests/emul), against the goldens the
+reference's own tools produced -- indexing and arithmetic of the HIP path checked where there is no GPU.  Includes the
+pictures the block grid does not tile (Q7: stale prediction margins) which the GPU tests repeat on the device."""
+import numpy as np
+import pytest
+
+from helpers import golden_input, load_golden, sha
+
+CASES = ["tiny_pan", "tiny_sat", "tiny_binary", "q7_200x120"]
+
+
+@pytest.fixture(scope="module")
+def E():
+    from emul import emul
+    return emul
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_thread_code_reproduces_golden_chain(E, name):
+    z, m = load_golden(name)
+    low = golden_input(z, m)
+    W, H, bs, S = m["W"], m["H"], m["bs"], m["S"]
+    for t in range(1, m["TRLs"]):
+        r, mv = E.motion_estimate(low, W, H, bs, S)
+        assert r == 0
+        np.testing.assert_array_equal(mv, z[f"motion_{t}"], err_msg=f"motion_{t}")
+        r, high, pred, hist = E.predict(low, W, H, bs, S, mv)
+        assert r == 0
+        types = z[f"frame_types_{t}"].tobytes()
+        filt = z[f"motion_filtered_{t}"]
+        for i, ty in enumerate(types):
+            if ty == ord("I"):
+                high[i] = low[2 * i + 1]
+        assert sha(pred) == str(z[f"prediction_{t}_sha"]), f"prediction_{t}"
+        assert sha(high) == str(z[f"high_{t}_sha"]), f"high_{t}"
+        r, lo = E.update(low, W, H, bs, high, filt, types)
+        assert r == 0
+        assert sha(lo) == str(z[f"low_{t}_sha"]), f"low_{t}"
+        low, S = lo, min(2 * S, 128)
+
+
+RAGGED = [("pan_noise", 18, 9, 72, 56, 16, 4), ("edge", 19, 9, 120, 68, 32, 4), ("scene_cut", 20, 7, 240, 136, 16, 4),
+          ("saturating", 21, 5, 80, 48, 32, 8)]
+
+
+@pytest.mark.parametrize("kind,seed,frames,W,H,bs,S", RAGGED)
+def test_ragged_pictures_equal_restatement(E, oracle, kind, seed, frames, W, H, bs, S):
+    """Q7 beyond the golden: more pictures (deeper margin recurrence), both margins, margins wider than a block."""
+    from qsvc_amd.synth import make_clip
+    low = make_clip(kind, frames, W, H, seed)
+    want = oracle.analyze_step(low, W, H, bs, S, want_prediction=True)
+    r, mv = E.motion_estimate(low, W, H, bs, S)
+    assert r == 0
+    np.testing.assert_array_equal(mv, want["motion"])
+    r, high, pred, hist = E.predict(low, W, H, bs, S, mv)
+    assert r == 0
+    np.testing.assert_array_equal(pred, want["prediction"])
+    for i, ty in enumerate(want["frame_types"]):
+        if ty == ord("I"):
+            high[i] = low[2 * i + 1]
+    np.testing.assert_array_equal(high, want["high"])
+    r, lo = E.update(low, W, H, bs, high, want["motion_filtered"], want["frame_types"])
+    assert r == 0
+    np.testing.assert_array_equal(lo, want["low"])

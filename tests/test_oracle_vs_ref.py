@@ -14,6 +14,9 @@ CASES = [
     ("noise", 15, 3, 96, 64, 16, 4),
     ("pan", 16, 3, 98, 70, 16, 8),     # odd intermediate sizes: literal analyse/synthesise replay (Q5)
     ("edge", 17, 5, 360, 200, 8, 16),  # Q1 row aliasing reachable
+    ("pan_noise", 18, 9, 72, 56, 16, 4),   # Q7: both margins unpredicted, four B pictures deep in the stale-state recurrence
+    ("edge", 19, 9, 120, 68, 32, 4),       # Q7: margins wider than the chroma/2 filter support
+    ("scene_cut", 20, 7, 1920 // 8, 1080 // 8 + 1, 64 // 8 * 2, 4),  # 240x136 bs 16: bottom margin only (1080p/bs 64 in small)
 ]
 
 
