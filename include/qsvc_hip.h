@@ -96,6 +96,17 @@ int qsvc_update(qsvc_ctx* ctx, int t, int pictures, int block_size, float update
 int qsvc_analyze_step(qsvc_ctx* ctx, int t, int pictures, int block_size, int search_range, int always_B,
                       float update_factor);
 
+/* ---- inverse temporal level (synthesize_step.py:96-151) ---------- */
+/* Inputs resident for subband t: low_t (pictures/2+1), high_t, frame_types_t and the decoded motion_t, put as
+ * QSVC_MOTION_FILTERED.  "merge" (split.cpp without ANALYZE) is the layout: both stages write low_{t-1} in place.
+ * replaces `un_update` (update.cpp without ANALYZE, :100-104,:466-478): low_t -> the even pictures of low_{t-1}. */
+int qsvc_un_update(qsvc_ctx* ctx, int t, int pictures, int block_size, float update_factor);
+/* replaces `correlate` (decorrelate.cpp without ANALYZE, :1029-1068): even pictures of low_{t-1}, high_t ->
+ * the odd pictures of low_{t-1} ('I': the stored picture; 'B': clip(residue + prediction)). */
+int qsvc_correlate(qsvc_ctx* ctx, int t, int pictures, int block_size, int search_range);
+/* replaces `synthesize_step` (synthesize_step.py): the two stages above. */
+int qsvc_synthesize_step(qsvc_ctx* ctx, int t, int pictures, int block_size, int search_range, float update_factor);
+
 /* ---- open-GOP boundary exchange (multi-GPU) -------------------------- */
 /* GOPs are open: the last even picture of one GPU's shard is the first of the next one's, and its
  * update needs the neighbour's boundary B picture (update.cpp:605-614,649-653).  A halo record =

@@ -368,8 +368,12 @@ static void chroma_up(int16_t *px, int stride, const uint8_t *src, int H, int W)
  *   prediction[P/2] frames I420 u8, nullable  (out; the prediction_<even_fn> debug dump)
  *   hists     [P/2][3][256] int, nullable     (out; odd luma, residue+128 luma, mv+128)
  */
-int qo_decorrelate(const uint8_t *low, int P, int W, int H, int bs, int S, int always_B, const int16_t *mv_in,
-                   uint8_t *high, char *types, int16_t *mv_out, uint8_t *prediction, int *hists) {
+/* Shared by decorrelate and correlate (the reference compiles both from decorrelate.cpp, #if defined ANALYZE).
+ * ev(k) = even picture k, od(i) = odd picture i (analysis only).  synth: high/types are INPUTS and odd_out is written
+ * (decorrelate.cpp:1029-1068). */
+static int decor_run(int synth, const uint8_t *ev_base, size_t ev_step, const uint8_t *od_base, size_t od_step, int P,
+                     int W, int H, int bs, int S, int always_B, const int16_t *mv_in, uint8_t *high, char *types,
+                     int16_t *mv_out, uint8_t *prediction, int *hists, uint8_t *odd_out) {
   if (bs <= 0 || S <= 0 || W < 4 || H < 4) return QO_EINVAL;
   int BY = H / bs, BX = W / bs, nB = P / 2, b = 4 * S;
   int cw = W / 2, ch = H / 2;
@@ -383,15 +387,15 @@ int qo_decorrelate(const uint8_t *low, int P, int W, int H, int bs, int S, int a
   int16_t *pred[3];
   for (int c = 0; c < 3; c++) pred[c] = (int16_t *)calloc((size_t)H * W, sizeof(int16_t));
   int a = 0;
-  const uint8_t *f0 = low;
+  const uint8_t *f0 = ev_base;
   bplane_load_u8(&ref[a][0], f0, H, W);
   chroma_up(ref[a][1].px, ref[a][1].stride, f0 + (size_t)W * H, H, W);
   chroma_up(ref[a][2].px, ref[a][2].stride, f0 + (size_t)W * H + (size_t)cw * ch, H, W);
   for (int c = 0; c < 3; c++) bplane_fill_border(&ref[a][c]);
 
   for (int i = 0; i < nB; i++) {
-    const uint8_t *odd = low + (size_t)(2 * i + 1) * F;
-    const uint8_t *ev = low + (size_t)(2 * i + 2) * F;
+    const uint8_t *odd = synth ? NULL : od_base + (size_t)i * od_step;
+    const uint8_t *ev = ev_base + (size_t)(i + 1) * ev_step;
     int n = 1 - a;
     bplane_load_u8(&ref[n][0], ev, H, W);
     chroma_up(ref[n][1].px, ref[n][1].stride, ev + (size_t)W * H, H, W);
@@ -402,7 +406,7 @@ int qo_decorrelate(const uint8_t *low, int P, int W, int H, int bs, int S, int a
     const int16_t *mvx1 = mv_in + ((size_t)i * 4 + 2) * fld, *mvy1 = mv_in + ((size_t)i * 4 + 3) * fld;
     int hmv[256], hodd[256], hres[256];
     memset(hmv, 0, sizeof hmv); memset(hodd, 0, sizeof hodd); memset(hres, 0, sizeof hres);
-    if (!always_B)
+    if (!always_B && !synth)
       for (size_t k = 0; k < fld; k++) { /* decorrelate.cpp:805-812 */
         hmv[(mvy0[k] + 128) & 255]++; hmv[(mvx0[k] + 128) & 255]++;
         hmv[(mvy1[k] + 128) & 255]++; hmv[(mvx1[k] + 128) & 255]++;
@@ -432,8 +436,25 @@ int qo_decorrelate(const uint8_t *low, int P, int W, int H, int bs, int S, int a
         for (int y = 0; y < ch; y++)
           for (int x = 0; x < cw; x++) o[(size_t)y * cw + x] = (uint8_t)pred[c][(size_t)y * W + x];
     }
-    /* residue (decorrelate.cpp:920-929) + luma histograms (:945-950) */
     uint8_t *hi = high + (size_t)i * F;
+    if (synth) { /* decorrelate.cpp:1029-1068: 'I' -> the stored picture, 'B' -> clip(residue + prediction) */
+      uint8_t *o = odd_out + (size_t)i * F;
+      const uint8_t *h = hi;
+      for (int c = 0; c < 3; c++) {
+        int hh = c ? ch : H, ww = c ? cw : W;
+        for (int y = 0; y < hh; y++)
+          for (int x = 0; x < ww; x++) {
+            int val = h[(size_t)y * ww + x] - 128;
+            if (types[i] == 'I') val += 128;
+            else { val += pred[c][(size_t)y * W + x]; if (val < 0) val = 0; else if (val > 255) val = 255; }
+            o[(size_t)y * ww + x] = (uint8_t)val;
+          }
+        o += (size_t)hh * ww; h += (size_t)hh * ww;
+      }
+      a = n;
+      continue;
+    }
+    /* residue (decorrelate.cpp:920-929) + luma histograms (:945-950) */
     {
       const uint8_t *o = odd; uint8_t *h = hi;
       for (int c = 0; c < 3; c++) {
@@ -469,13 +490,26 @@ int qo_decorrelate(const uint8_t *low, int P, int W, int H, int bs, int S, int a
   return QO_OK;
 }
 
+int qo_decorrelate(const uint8_t *low, int P, int W, int H, int bs, int S, int always_B, const int16_t *mv_in,
+                   uint8_t *high, char *types, int16_t *mv_out, uint8_t *prediction, int *hists) {
+  size_t F = frame_bytes(W, H);
+  return decor_run(0, low, 2 * F, low + F, 2 * F, P, W, H, bs, S, always_B, mv_in, high, types, mv_out, prediction, hists, 0);
+}
+/* correlate (decorrelate.cpp without ANALYZE; synthesize_step.py:117-136): even [P/2+1] frames (what un_update wrote),
+ * high/types/mv as decoded -> odd_out [P/2] frames. */
+int qo_correlate(const uint8_t *even, int P, int W, int H, int bs, int S, const int16_t *mv, const uint8_t *high,
+                 const char *types, uint8_t *odd_out, uint8_t *prediction) {
+  return decor_run(1, even, frame_bytes(W, H), 0, 0, P, W, H, bs, S, 1, mv, (uint8_t *)high, (char *)types, 0, prediction, 0,
+                   odd_out);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* update (update.cpp:50-148, main :446-679).                                                 */
 
 static int clipi(int x, int dim) { return x < 0 ? 0 : (x >= dim ? dim - 1 : x); } /* update.cpp:50-54 */
 
 static void upd_apply(int16_t *E, const int16_t *res, const int16_t *mvx, const int16_t *mvy, int H, int W, int bs,
-                      int BY, int BX, float uf) {
+                      int BY, int BX, float uf, int undo) {
   for (int by = 0; by < BY; by++)
     for (int bx = 0; bx < BX; bx++) {
       int dy = mvy[(size_t)by * BX + bx], dx = mvx[(size_t)by * BX + bx];
@@ -483,16 +517,18 @@ static void upd_apply(int16_t *E, const int16_t *res, const int16_t *mvx, const 
         for (int x = 0; x < bs; x++) {
           int16_t *t = &E[(size_t)clipi(by * bs + y + dy, H) * W + clipi(bx * bs + x + dx, W)];
           float aux = (float)*t;
-          aux += res[(size_t)(by * bs + y) * W + bx * bs + x] * uf;
+          if (undo) aux -= res[(size_t)(by * bs + y) * W + bx * bs + x] * uf; /* update.cpp:100-104 */
+          else aux += res[(size_t)(by * bs + y) * W + bx * bs + x] * uf;
           if (aux > 255) aux = 255; else if (aux < 0) aux = 0;
           *t = (int16_t)aux;
         }
     }
 }
 
-/* low_out: [P/2+1] frames.  high/mv/types are the decorrelate outputs (motion_filtered). */
-int qo_update(const uint8_t *low, int P, int W, int H, int bs, const uint8_t *high, const int16_t *mv,
-              const char *types, float uf, uint8_t *low_out) {
+/* update / un_update share update.cpp (#ifdef ANALYZE at :100-104,:466-478,:625-641): src picture k at
+ * src + k*src_step.  low_out: [P/2+1] frames.  high/mv/types are the decorrelate outputs (motion_filtered). */
+static int upd_run(int undo, const uint8_t *low, size_t src_step, int P, int W, int H, int bs, const uint8_t *high,
+                   const int16_t *mv, const char *types, float uf, uint8_t *low_out) {
   if (bs <= 0 || W < 4 || H < 4) return QO_EINVAL;
   int BY = H / bs, BX = W / bs, nB = P / 2, cw = W / 2, ch = H / 2;
   size_t F = frame_bytes(W, H), fld = (size_t)BY * BX, N = (size_t)H * W;
@@ -529,14 +565,14 @@ int qo_update(const uint8_t *low, int P, int W, int H, int bs, const uint8_t *hi
       for (int y = 0; y < ch; y++)
         for (int x = 0; x < cw; x++) res[c][(size_t)y * W + x] = (int16_t)(hc[(size_t)y * cw + x] - 128);
     }
-    LOAD_EVEN(E[1 - a], low + (size_t)(2 * i + 2) * F);
+    LOAD_EVEN(E[1 - a], low + (size_t)(i + 1) * src_step);
     if (types[i] == 'B') {
       const int16_t *m = mv + (size_t)i * 4 * fld;
       /* update.cpp:85-146: per source pixel PREV target then NEXT target; the two targets are
        * different pictures, so per picture the order is simply (c, by, bx, y, x). */
       for (int c = 0; c < 3; c++) {
-        upd_apply(E[a][c], res[c], m + 0 * fld, m + 1 * fld, H, W, bs, BY, BX, uf);
-        upd_apply(E[1 - a][c], res[c], m + 2 * fld, m + 3 * fld, H, W, bs, BY, BX, uf);
+        upd_apply(E[a][c], res[c], m + 0 * fld, m + 1 * fld, H, W, bs, BY, BX, uf, undo);
+        upd_apply(E[1 - a][c], res[c], m + 2 * fld, m + 3 * fld, H, W, bs, BY, BX, uf, undo);
       }
     }
     STORE_LOW(E[a], low_out + (size_t)i * F);
@@ -546,6 +582,16 @@ int qo_update(const uint8_t *low, int P, int W, int H, int bs, const uint8_t *hi
   for (int i = 0; i < 2; i++) for (int c = 0; c < 3; c++) free(E[i][c]);
   for (int c = 0; c < 3; c++) free(res[c]);
   return QO_OK;
+}
+
+int qo_update(const uint8_t *low, int P, int W, int H, int bs, const uint8_t *high, const int16_t *mv,
+              const char *types, float uf, uint8_t *low_out) {
+  return upd_run(0, low, 2 * frame_bytes(W, H), P, W, H, bs, high, mv, types, uf, low_out);
+}
+/* un_update (synthesize_step.py:96-113): low_t [P/2+1] frames -> even_t [P/2+1] frames. */
+int qo_un_update(const uint8_t *low_t, int P, int W, int H, int bs, const uint8_t *high, const int16_t *mv,
+                 const char *types, float uf, uint8_t *even_out) {
+  return upd_run(1, low_t, frame_bytes(W, H), P, W, H, bs, high, mv, types, uf, even_out);
 }
 
 /* One whole temporal level = split + motion_estimate + decorrelate + update

@@ -50,6 +50,8 @@ def lib() -> C.CDLL:
         L.qo_decorrelate.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p, _u8p,
                                      C.c_char_p, _i16p, C.c_void_p, C.c_void_p]
         L.qo_update.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _i16p, C.c_char_p, C.c_float, _u8p]
+        L.qo_un_update.argtypes = L.qo_update.argtypes
+        L.qo_correlate.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p, _u8p, C.c_char_p, _u8p, C.c_void_p]
         L.qo_entropy.argtypes = [_i32p, C.c_int]
         L.qo_entropy.restype = C.c_float
         L.qo_frame_type.argtypes = [_i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -117,6 +119,34 @@ def update(low, W, H, bs, high, mv, types: bytes, update_factor=0.25) -> np.ndar
                         update_factor, out)
     assert r == 0
     return out
+
+
+def un_update(low_t, P, W, H, bs, high, mv, types: bytes, update_factor=0.25) -> np.ndarray:
+    """low_t [P/2+1] -> even_t [P/2+1] (update.cpp without ANALYZE)."""
+    low_t = np.ascontiguousarray(low_t, dtype=np.uint8)
+    out = np.zeros((P // 2 + 1, frame_bytes(W, H)), dtype=np.uint8)
+    assert lib().qo_un_update(low_t, P, W, H, bs, np.ascontiguousarray(high), np.ascontiguousarray(mv), types, update_factor, out) == 0
+    return out
+
+
+def correlate(even, P, W, H, bs, S, high, mv, types: bytes) -> np.ndarray:
+    """even_t [P/2+1], high_t [P/2] -> odd_t [P/2] (decorrelate.cpp without ANALYZE)."""
+    even = np.ascontiguousarray(even, dtype=np.uint8)
+    out = np.zeros((P // 2, frame_bytes(W, H)), dtype=np.uint8)
+    assert lib().qo_correlate(even, P, W, H, bs, S, np.ascontiguousarray(mv), np.ascontiguousarray(high), types, out, None) == 0
+    return out
+
+
+def synthesize_step(low_t, high, mv, types: bytes, W, H, bs, S, update_factor=0.25):
+    """One inverse temporal level (synthesize_step.py:96-151): un_update, correlate, merge -> low_{t-1}."""
+    nB = high.shape[0]
+    P = 2 * nB + 1
+    even = un_update(low_t, P, W, H, bs, high, mv, types, update_factor)
+    odd = correlate(even, P, W, H, bs, S, high, mv, types)
+    out = np.empty((P, frame_bytes(W, H)), dtype=np.uint8)
+    out[0::2] = even
+    out[1::2] = odd
+    return dict(even=even, odd=odd, low=out)
 
 
 def analyze_step(low, W, H, bs, S, always_B=0, update_factor=0.25, want_prediction=False):
@@ -210,6 +240,37 @@ def ref_analyze(low0, W, H, TRLs, bs, S=4, bs_min=None, always_B=0, update_facto
         S = min(2 * S, 128)
         bs = max(bs // 2, bs_min)
     return levels
+
+
+def ref_synthesize_step(low_t, high, mv, types: bytes, W, H, bs, S, update_factor=0.25, t=1):
+    """The reference's un_update / correlate / merge binaries (oracle/_ref) as synthesize_step.py:96-151 chains them."""
+    nB = high.shape[0]
+    P = 2 * nB + 1
+    d = tempfile.mkdtemp(prefix="qsvc_refs_")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MALLOC_")}
+    try:
+        np.ascontiguousarray(low_t, dtype=np.uint8).tofile(os.path.join(d, f"low_{t}"))
+        np.ascontiguousarray(high, dtype=np.uint8).tofile(os.path.join(d, f"high_{t}"))
+        np.ascontiguousarray(mv, dtype="<i2").tofile(os.path.join(d, f"motion_{t}"))
+        open(os.path.join(d, f"frame_types_{t}"), "wb").write(types)
+
+        def run(tool, *args):
+            subprocess.check_call([os.path.join(REF_DIR, tool)] + [str(a) for a in args], cwd=d, env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+        run("un_update", f"--block_size={bs}", f"--even_fn=even_{t}", f"--frame_types_fn=frame_types_{t}", f"--high_fn=high_{t}",
+            f"--low_fn=low_{t}", f"--motion_fn=motion_{t}", f"--pictures={P}", f"--pixels_in_x={W}", f"--pixels_in_y={H}",
+            "--subpixel_accuracy=0", f"--update_factor={update_factor}")
+        run("correlate", "--block_overlaping=0", f"--block_size={bs}", f"--even_fn=even_{t}", f"--frame_types_fn=frame_types_{t}",
+            f"--high_fn=high_{t}", f"--motion_in_fn=motion_{t}", f"--odd_fn=odd_{t}", f"--pictures={P}", f"--pixels_in_x={W}",
+            f"--pixels_in_y={H}", f"--search_range={S}", "--subpixel_accuracy=0")
+        run("merge", f"--even=even_{t}", f"--low=low_{t - 1}", f"--odd=odd_{t}", f"--pictures={P}", f"--pixels_in_x={W}",
+            f"--pixels_in_y={H}")
+        F = frame_bytes(W, H)
+        rd = lambda n: np.fromfile(os.path.join(d, n), dtype=np.uint8)
+        return dict(even=rd(f"even_{t}").reshape(nB + 1, F), odd=rd(f"odd_{t}").reshape(nB, F), low=rd(f"low_{t - 1}").reshape(P, F))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def ref_motion_residues(filtered: dict, BY: int, BX: int) -> dict:

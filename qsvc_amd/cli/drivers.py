@@ -5,6 +5,8 @@ cwd files of the script it replaces, but the stages it would spawn as processes 
   analyze ............. trunk/src/analyze.py:30-153
   analyze_step ........ trunk/src/analyze_step.py:30-232
   texture_compress .... trunk/src/texture_compress.py:30-217
+  synthesize_step ..... trunk/src/synthesize_step.py:30-151
+  synthesize .......... trunk/src/synthesize.py:30-170
 """
 from __future__ import annotations
 
@@ -58,6 +60,90 @@ def analyze_step(argv=None):
         e.put_frames(hip.LOW, t - 1, low_prev)
         e.analyze_step(t, low_prev.shape[0], bs, a["search_range"], a["always_B"], a["update_factor"])
         _write_level(e, t, low_prev.shape[0], bs, W, H, low_prev)
+    except hip.QsvcError as ex:
+        C.die(str(ex))
+    finally:
+        e.close()
+
+
+def _load_subband(e, t, nB, bs, W, H, with_low):
+    """The cwd files one inverse level reads (synthesize_step.py:96-136): low_t, high_t, motion_t, frame_types_t."""
+    from .. import hip
+    if with_low:
+        e.put_frames(hip.LOW, t, C.read_frames(f"low_{t}", W, H, nB + 1))
+    e.put_frames(hip.HIGH, t, C.read_frames(f"high_{t}", W, H, nB))
+    e.put_motion(hip.MOTION_FILTERED, t, C.read_motion(f"motion_{t}", nB, H // bs, W // bs), bs)
+    try:
+        types = open(f"frame_types_{t}", "rb").read(nB)
+    except OSError:
+        C.die(f"unable to read \"frame_types_{t}\" ... aborting!")
+    e.put_frame_types(t, types.ljust(nB, b"I"))
+
+
+def _write_synth_level(e, t, P):
+    from .. import hip
+    low = e.get_frames(hip.LOW, t - 1, 0, P)
+    C.write_frames(f"even_{t}", low[0::2])
+    C.write_frames(f"odd_{t}", low[1::2])
+    C.write_frames(f"low_{t - 1}", low)
+
+
+def synthesize_step(argv=None):
+    a = C.parse("Performs a step of the temporal synthesis.", {
+        "block_overlaping": (0, int), "block_size": (16, int), "pictures": (33, int), "pixels_in_x": (352, int),
+        "pixels_in_y": (288, int), "search_range": (4, int), "subpixel_accuracy": (0, int), "temporal_subband": (0, int),
+        "update_factor": (1.0 / 4, float)}, argv)
+    _refuse_deferred(a)
+    from .. import hip
+    W, H, t, bs = a["pixels_in_x"], a["pixels_in_y"], a["temporal_subband"], a["block_size"]
+    nB = a["pictures"] // 2
+    e = C.engine()
+    try:
+        e.seq_config(W, H)
+        _load_subband(e, t, nB, bs, W, H, with_low=True)
+        e.synthesize_step(t, 2 * nB + 1, bs, a["search_range"], a["update_factor"])
+        _write_synth_level(e, t, 2 * nB + 1)
+    except hip.QsvcError as ex:
+        C.die(str(ex))
+    finally:
+        e.close()
+
+
+def synthesize(argv=None):
+    """synthesize.py:103-170: from the coarsest subband down; the per-level lists (block size, picture size) of the
+    reference's spatially scalable decoder are accepted, a change of picture size between levels is not."""
+    a = C.parse("Performs the temporal synthesis of a picture sequence.", {
+        "GOPs": (1, int), "TRLs": (4, int), "block_size": ("16,16,16,16", str), "pixels_in_x": ("352,352,352,352,352", str),
+        "pixels_in_y": ("288,288,288,288,288", str), "subpixel_accuracy": ("0,0,0,0", str), "border_size": (0, int),
+        "block_overlaping": (0, int), "search_range": (4, int), "update_factor": (1.0 / 4, float)}, argv)
+    if a["block_overlaping"] or a["border_size"] or any(int(x) for x in a["subpixel_accuracy"].split(",")):
+        C.die("block_overlaping / subpixel_accuracy / border_size other than 0 are not implemented on this path (SURVEY.md N4)")
+    from .. import hip
+    TRLs = a["TRLs"]
+    if TRLs < 2:
+        return
+
+    def per_level(text, idx):  # the reference indexes its comma lists; a single value stands for every level
+        parts = text.split(",")
+        return int(parts[idx] if len(parts) > 1 else parts[0])
+
+    sizes = {(per_level(a["pixels_in_x"], TRLs - t), per_level(a["pixels_in_y"], TRLs - t)) for t in range(1, TRLs)}
+    if len(sizes) != 1:
+        C.die("a different picture size per temporal subband (spatial scalability) is not implemented on this path")
+    W, H = sizes.pop()
+    P0 = schedule.pictures(a["GOPs"], TRLs)
+    e = C.engine()
+    try:
+        e.seq_config(W, H)
+        for t in range(TRLs - 1, 0, -1):
+            P, S = P0, a["search_range"]
+            for _ in range(1, t):  # synthesize.py:118-124,160-168
+                S = min(S * 2, 128)
+                P = (P + 1) // 2
+            bs = per_level(a["block_size"], (TRLs - 1) - t)
+            _load_subband(e, t, P // 2, bs, W, H, with_low=(t == TRLs - 1))
+            e.synthesize_step(t, P, bs, S, a["update_factor"])
+            _write_synth_level(e, t, 2 * (P // 2) + 1)
     except hip.QsvcError as ex:
         C.die(str(ex))
     finally:

@@ -118,6 +118,16 @@ __global__ void __launch_bounds__(256) k_pred_luma8(PredArgs a) {
       BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
       for (int k = 0; k < 8; k++) p1[k] = (uint8_t)luma_b(r1, bg, y1, x1 + k);
     }
+    const size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
+    if (a.odd_out) {  // correlate: high is the input, the odd picture the output
+      const int ty = a.types[i];
+      uint8_t* dst = a.odd_out + (size_t)(2 * i + 1) * g.F + (size_t)y * g.W + x;
+      for (int k = 0; k < n; k++) {
+        int p = ((int)p0[k] + (int)p1[k]) >> 1;
+        dst[k] = (uint8_t)correlate_sample(a.high[off + k], p, ty);
+        if (a.pred_dump) a.pred_dump[off + k] = (uint8_t)p;
+      }
+    } else {
     if (n == 8) { uint64_t v = ld8u(od); __builtin_memcpy(o, &v, 8); }
     else for (int k = 0; k < n; k++) o[k] = od[k];
     uint8_t hi[8], pr[8];
@@ -128,7 +138,6 @@ __global__ void __launch_bounds__(256) k_pred_luma8(PredArgs a) {
       hi[k] = (uint8_t)(val + 128); pr[k] = (uint8_t)p;
       if (k < n) { atomicAdd(&h[0][o[k]], 1u); atomicAdd(&h[1][val + 128], 1u); }
     }
-    const size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
     if (n == 8) {
       uint64_t v;
       __builtin_memcpy(&v, hi, 8); __builtin_memcpy(a.high + off, &v, 8);
@@ -136,7 +145,9 @@ __global__ void __launch_bounds__(256) k_pred_luma8(PredArgs a) {
     } else {
       for (int k = 0; k < n; k++) { a.high[off + k] = hi[k]; if (a.pred_dump) a.pred_dump[off + k] = pr[k]; }
     }
+    }
   }
+  if (a.odd_out) return;  // correlate: no histograms (uniform over the launch)
   __syncthreads();
   unsigned* gh = a.hist + (size_t)i * 3 * 256;
   if (h[0][tid]) atomicAdd(&gh[tid], h[0][tid]);
@@ -152,9 +163,9 @@ __global__ void __launch_bounds__(256) k_pred_luma(PredArgs a) {
   if (x < a.g.W && y < a.g.H) {
     int ob, rb;
     pred_luma_thread(a, x, y, i, ob, rb);
-    atomicAdd(&h[0][ob], 1u);
-    atomicAdd(&h[1][rb], 1u);
+    if (!a.odd_out) { atomicAdd(&h[0][ob], 1u); atomicAdd(&h[1][rb], 1u); }
   }
+  if (a.odd_out) return;  // correlate: no histograms (uniform over the launch)
   __syncthreads();
   unsigned* gh = a.hist + (size_t)i * 3 * 256;
   if (h[0][tid]) atomicAdd(&gh[tid], h[0][tid]);
@@ -204,10 +215,15 @@ __global__ void __launch_bounds__(256) k_pred_chroma(PredArgs a) {
     const int lx = tid & (PC_TW - 1);
     auto col = [&](int yy) { return (int)sL[yy - yb][lx]; };
     int ll = (int16_t)a53_low(col, cj, g.H);
-    int o = frame_c(a.frames, g, 2 * i + 1, c)[(size_t)cj * cw + ci];
-    int val = iclamp(o - ll, -128, 127);
-    size_t off = (size_t)i * g.F + (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh + (size_t)cj * cw + ci;
-    a.high[off] = (uint8_t)(val + 128);
+    size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh + (size_t)cj * cw + ci;
+    size_t off = (size_t)i * g.F + coff;
+    if (a.odd_out) {
+      a.odd_out[(size_t)(2 * i + 1) * g.F + coff] = (uint8_t)correlate_sample(a.high[off], ll, a.types[i]);
+    } else {
+      int o = frame_c(a.frames, g, 2 * i + 1, c)[(size_t)cj * cw + ci];
+      int val = iclamp(o - ll, -128, 127);
+      a.high[off] = (uint8_t)(val + 128);
+    }
     if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;
   }
 }
@@ -230,7 +246,7 @@ __global__ void __launch_bounds__(256) k_mv_hist(const int16_t* mv, size_t per_p
 }
 void launch_predict(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
-  hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
+  if (!a.odd_out) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
   dim3 block(64, 4);
   if (a.margin) {
     size_t cnt = margin_geom(g).count();
@@ -240,6 +256,7 @@ void launch_predict(hipStream_t st, const PredArgs& a) {
   if (g.bs % 8 == 0) hipLaunchKernelGGL(k_pred_luma8, dim3((g.W + 511) / 512, (g.H + 3) / 4, g.nB), block, 0, st, a);
   else hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);
   hipLaunchKernelGGL(k_pred_chroma, dim3((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, g.nB * 2), block, 0, st, a);
+  if (a.odd_out) return;
   size_t per_pic = (size_t)4 * g.BY * g.BX;
   int nblk = (int)((per_pic + 255) / 256);
   if (nblk > 64) nblk = 64;
@@ -264,14 +281,14 @@ __global__ void __launch_bounds__(256) k_upd_chroma(UpdArgs a) {
   const int i0 = blockIdx.x * PC_TW, j0 = blockIdx.y * PC_TH;
   const int cw = g.W / 2, chh = g.H / 2;
   const int xb = 2 * i0 - 2, yb = 2 * j0 - 2;
-  const uint8_t* u = frame_c(a.frames, g, 2 * j, c);
+  const uint8_t* u = frame_c(a.frames, g, a.src_mul * j, c);
   const size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh;
   UpdSide s[2];
   upd_sides(a, j, s);
   const int ci = i0 + (tid & (PC_TW - 1)), cj = j0 + tid / PC_TW;
   const bool untouched = (!s[0].high && !s[1].high) || yb >= chh + a.reach || xb >= cw + a.reach;  // wave-uniform
   if (untouched) {
-    if (ci < cw && cj < chh) a.low[(size_t)j * g.F + coff + (size_t)cj * cw + ci] = u[(size_t)cj * cw + ci];
+    if (ci < cw && cj < chh) a.low[(size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci] = u[(size_t)cj * cw + ci];
     return;
   }
   for (int k = tid; k < PC_FH * PC_FW; k += 256) {
@@ -303,7 +320,7 @@ __global__ void __launch_bounds__(256) k_upd_chroma(UpdArgs a) {
   if (ci < cw && cj < chh) {
     const int lx = tid & (PC_TW - 1);
     auto col = [&](int yy) { return (int)sL[yy - yb][lx]; };
-    a.low[(size_t)j * g.F + coff + (size_t)cj * cw + ci] = (uint8_t)(int16_t)a53_low(col, cj, g.H);
+    a.low[(size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci] = (uint8_t)(int16_t)a53_low(col, cj, g.H);
   }
 }
 void launch_update(hipStream_t st, const UpdArgs& a) {

@@ -99,7 +99,13 @@ struct PredArgs {
   unsigned* hist;         // [nB][3][256]
   int16_t* margin;        // Q7: [nB][2][MarginGeom::count()] chroma margin state AFTER each picture; nullptr when the
                           // block grid tiles the picture
+  // correlate (decorrelate.cpp without ANALYZE, :1029-1068): `high` and `types` are inputs and the odd picture 2i+1 of
+  // `odd_out` (= the frames buffer itself: un_update put the even pictures at 2i) is written instead.
+  uint8_t* odd_out;       // nullptr = analysis
+  const uint8_t* types;   // [nB] 'I' / 'B' (synthesis only)
 };
+// what correlate stores for one sample: the picture itself for 'I', clip(residue + prediction) for 'B'
+QHD int correlate_sample(int h, int p, int type) { return type == 'I' ? h : iclamp(h - 128 + p, 0, 255); }
 QHD MarginGeom margin_geom(const LevelGeom& g) { return {g.H, g.W, g.BY * g.bs, g.BX * g.bs}; }
 // luma: returns the two histogram bins through odd_bin / res_bin
 QHD void pred_luma_thread(const PredArgs& a, int x, int y, int i, int& odd_bin, int& res_bin) {
@@ -109,9 +115,15 @@ QHD void pred_luma_thread(const PredArgs& a, int x, int y, int i, int& odd_bin, 
   int p = 0;  // Q7: the unpredicted margin of the luma plane stays zero
   if (y < g.BY * g.bs && x < g.BX * g.bs)
     p = predict_luma(frame_y(a.frames, g, 2 * i), frame_y(a.frames, g, 2 * i + 2), bg, mv, g.bs, y, x);
+  size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
+  if (a.odd_out) {
+    a.odd_out[(size_t)(2 * i + 1) * g.F + (size_t)y * g.W + x] = (uint8_t)correlate_sample(a.high[off], p, a.types[i]);
+    if (a.pred_dump) a.pred_dump[off] = (uint8_t)p;
+    odd_bin = res_bin = 0;
+    return;
+  }
   int o = frame_y(a.frames, g, 2 * i + 1)[(size_t)y * g.W + x];
   int val = iclamp(o - p, -128, 127);  // decorrelate.cpp:920-929
-  size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
   a.high[off] = (uint8_t)(val + 128);
   if (a.pred_dump) a.pred_dump[off] = (uint8_t)p;
   odd_bin = o; res_bin = val + 128;
@@ -147,9 +159,15 @@ QHD void pred_chroma_thread(const PredArgs& a, int ci, int cj, int i, int c /*1|
   auto P = [&](int yy, int xx) { return pred_chroma_sample(a, u0, u1, bg, mv, i, c, yy, xx); };
   int ll = analyze_ll(P, cj, ci, g.H, g.W);  // chroma /2 of the full-resolution prediction
   int cw = g.W / 2;
+  size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * (g.H / 2) + (size_t)cj * cw + ci;
+  size_t off = (size_t)i * g.F + coff;
+  if (a.odd_out) {
+    a.odd_out[(size_t)(2 * i + 1) * g.F + coff] = (uint8_t)correlate_sample(a.high[off], ll, a.types[i]);
+    if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;
+    return;
+  }
   int o = frame_c(a.frames, g, 2 * i + 1, c)[(size_t)cj * cw + ci];
   int val = iclamp(o - ll, -128, 127);
-  size_t off = (size_t)i * g.F + (size_t)g.W * g.H + (size_t)(c - 1) * cw * (g.H / 2) + (size_t)cj * cw + ci;
   a.high[off] = (uint8_t)(val + 128);
   if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;  // texture::write: plain short -> u8 (Q4)
 }
@@ -167,8 +185,11 @@ struct UpdArgs {
   const int16_t* halo_mv[2];
   int halo_type[2];        // 0 = no halo, else 'I' / 'B'
   uint8_t* low;            // [nB+1][F]
-  float uf;                // update_factor
+  float uf;                // update_factor; un_update (update.cpp:100-104 without ANALYZE) passes -update_factor:
+                           // a - r*uf and a + r*(-uf) are the same float
   int reach;               // >= max |mv component| over every field used
+  int src_mul, dst_mul;    // even picture j is frames[src_mul*j] and goes to low[dst_mul*j]: (2,1) update low_{t-1} -> low_t,
+                           // (1,2) un_update low_t -> the even pictures of low_{t-1}
 };
 struct UpdSide {  // one contribution to even picture j
   const uint8_t* high;  // frame base of the B picture, or nullptr
@@ -203,14 +224,14 @@ QHD void upd_luma_thread(const UpdArgs& a, int x, int y, int j) {
   const LevelGeom& g = a.g;
   UpdSide s[2];
   upd_sides(a, j, s);
-  int v = frame_y(a.frames, g, 2 * j)[(size_t)y * g.W + x];
+  int v = frame_y(a.frames, g, a.src_mul * j)[(size_t)y * g.W + x];
   for (int k = 0; k < 2; k++)
     if (s[k].high) {
       const uint8_t* h = s[k].high;
       auto R = [&](int sy, int sx) { return (int)h[(size_t)sy * g.W + sx] - 128; };  // update.cpp:512-520
       v = update_gather(v, R, s[k].mvx, s[k].mvy, g.BY, g.BX, g.bs, g.H, g.W, g.H, g.W, a.reach, y, x, a.uf);
     }
-  a.low[(size_t)j * g.F + (size_t)y * g.W + x] = (uint8_t)v;
+  a.low[(size_t)(a.dst_mul * j) * g.F + (size_t)y * g.W + x] = (uint8_t)v;
 }
 // chroma: low sample (cj,ci) = LL of the 1-level analysis of the updated full-resolution plane
 // (update.cpp:632-643).  Only targets within `reach` of the top-left quadrant can change (Q3); for
@@ -218,8 +239,8 @@ QHD void upd_luma_thread(const UpdArgs& a, int x, int y, int j) {
 QHD void upd_chroma_thread(const UpdArgs& a, int ci, int cj, int j, int c /*1|2*/) {
   const LevelGeom& g = a.g;
   int cw = g.W / 2, chh = g.H / 2;
-  const uint8_t* u = frame_c(a.frames, g, 2 * j, c);
-  size_t off = (size_t)j * g.F + (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh + (size_t)cj * cw + ci;
+  const uint8_t* u = frame_c(a.frames, g, a.src_mul * j, c);
+  size_t off = (size_t)(a.dst_mul * j) * g.F + (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh + (size_t)cj * cw + ci;
   UpdSide s[2];
   upd_sides(a, j, s);
   bool untouched = (!s[0].high && !s[1].high) || 2 * cj - 2 >= chh + a.reach || 2 * ci - 2 >= cw + a.reach;

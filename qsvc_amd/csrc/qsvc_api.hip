@@ -308,7 +308,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   PredArgs a;
   a.g = g; a.frames = (const uint8_t*)c->lv[t - 1].low.p; a.mv = (const int16_t*)lv.mv_raw.p;
   a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = (unsigned*)lv.hist.p;
-  a.margin = nullptr;
+  a.margin = nullptr; a.odd_out = nullptr; a.types = nullptr;
   lv.ragged = (g.H % bs || g.W % bs);
   if (lv.ragged) {  // Q7: the chroma margins carry state from picture to picture
     if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
@@ -373,7 +373,7 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   UpdArgs a;
   a.g = g; a.frames = (const uint8_t*)c->lv[t - 1].low.p; a.high = (const uint8_t*)lv.high.p;
   a.mv = (const int16_t*)lv.mv_filt.p; a.types = (const uint8_t*)c->tmp16[0].p; a.low = (uint8_t*)lv.low.p;
-  a.uf = uf; a.reach = reach;
+  a.uf = uf; a.reach = reach; a.src_mul = 2; a.dst_mul = 1;
   for (int s = 0; s < 2; s++) {
     a.halo_high[s] = (const uint8_t*)lv.halo[s];
     a.halo_mv[s] = lv.halo[s] ? (const int16_t*)((const uint8_t*)lv.halo[s] + g.F) : nullptr;
@@ -393,6 +393,97 @@ int qsvc_analyze_step(qsvc_ctx* c, int t, int P, int bs, int S, int always_B, fl
   if (r) return r;
   if ((r = qsvc_decorrelate(c, t, P, bs, S, always_B))) return r;
   return qsvc_update(c, t, P, bs, uf);
+}
+
+// ---- inverse temporal level (synthesize_step.py:96-151): un_update, correlate; "merge" is the layout itself --------
+// low_t (P/2+1 pictures), high_t, motion_filtered_t (the decoded motion_t) and frame_types_t must be resident.
+static int synth_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g, bool need_low) {
+  if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+  if (t < 1 || t > QSVC_MAX_T) return c->fail(QSVC_ERR_INVALID, "temporal subband %d out of range", t);
+  if (bs < 2 || bs > 256) return c->fail(QSVC_ERR_INVALID, "block_size %d", bs);
+  if (P < 1) return c->fail(QSVC_ERR_INVALID, "pictures %d", P);
+  if (c->H < bs || c->W < bs) return c->fail(QSVC_ERR_INVALID, "picture %dx%d smaller than block_size %d", c->W, c->H, bs);
+  g->W = c->W; g->H = c->H; g->bs = bs; g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
+  Level& lv = c->lv[t];
+  if (need_low && lv.low_n < g->nB + 1) return c->fail(QSVC_ERR_STATE, "low_%d holds %d pictures, %d needed", t, lv.low_n, g->nB + 1);
+  if (lv.high_n < g->nB || lv.mv_filt_n < g->nB || (int)lv.types.size() < g->nB || (g->nB && lv.mv_bs != bs))
+    return c->fail(QSVC_ERR_STATE, "high_%d / motion_%d / frame_types_%d missing", t, t, t);
+  return QSVC_OK;
+}
+static int types_to_device(qsvc_ctx* c, const Level& lv, int nB) {
+  int r = c->tmp16[0].ensure(c, (size_t)nB + 16);
+  if (r) return r;
+  if (nB) HIPCHK(c, hipMemcpyAsync(c->tmp16[0].p, lv.types.data(), nB, hipMemcpyHostToDevice, c->st));
+  return QSVC_OK;
+}
+
+int qsvc_un_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
+  if (!c) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  LevelGeom g;
+  int r = synth_geom(c, t, P, bs, 0, &g, true);
+  if (r) return r;
+  Level& lv = c->lv[t];
+  Level& out = c->lv[t - 1];
+  const int Pout = 2 * g.nB + 1;
+  if ((r = out.low.ensure(c, (size_t)Pout * g.F))) return r;
+  out.low_n = Pout;
+  if ((r = c->scal.ensure(c, 256))) return r;
+  size_t fld = (size_t)g.BY * g.BX;
+  HIPCHK(c, hipMemsetAsync(c->scal.p, 0, 16, c->st));
+  if (g.nB) launch_mv_maxabs(c->st, (const int16_t*)lv.mv_filt.p, (size_t)g.nB * 4 * fld, (int*)c->scal.p);
+  int reach = 0;
+  HIPCHK(c, hipMemcpyAsync(&reach, c->scal.p, sizeof(int), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  if ((r = types_to_device(c, lv, g.nB))) return r;
+  UpdArgs a;
+  a.g = g; a.frames = (const uint8_t*)lv.low.p; a.high = (const uint8_t*)lv.high.p;
+  a.mv = (const int16_t*)lv.mv_filt.p; a.types = (const uint8_t*)c->tmp16[0].p; a.low = (uint8_t*)out.low.p;
+  a.uf = -uf; a.reach = reach; a.src_mul = 1; a.dst_mul = 2;
+  for (int s = 0; s < 2; s++) { a.halo_high[s] = nullptr; a.halo_mv[s] = nullptr; a.halo_type[s] = 0; }
+  Prof pf;
+  pf.begin(c, "un_update");
+  launch_update(c->st, a);
+  pf.end(c);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return QSVC_OK;
+}
+
+int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
+  if (!c) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  LevelGeom g;
+  int r = synth_geom(c, t, P, bs, S, &g, false);
+  if (r) return r;
+  if (S < 1 || S > 128) return c->fail(QSVC_ERR_INVALID, "search_range %d", S);
+  Level& lv = c->lv[t];
+  Level& out = c->lv[t - 1];
+  if (out.low_n < 2 * g.nB + 1) return c->fail(QSVC_ERR_STATE, "even_%d missing (run un_update first)", t);
+  if (g.nB == 0) return QSVC_OK;
+  if (c->keep_pred) { if ((r = lv.pred.ensure(c, (size_t)g.nB * g.F))) return r; lv.pred_n = g.nB; }
+  if ((r = types_to_device(c, lv, g.nB))) return r;
+  PredArgs a;
+  a.g = g; a.frames = (const uint8_t*)out.low.p; a.mv = (const int16_t*)lv.mv_filt.p;
+  a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = nullptr;
+  a.margin = nullptr; a.odd_out = (uint8_t*)out.low.p; a.types = (const uint8_t*)c->tmp16[0].p;
+  if (g.H % bs || g.W % bs) {  // Q7 applies to the decoder's prediction planes as well
+    if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
+    a.margin = (int16_t*)c->margin.p;
+  }
+  Prof pf;
+  pf.begin(c, "correlate");
+  launch_predict(c->st, a);
+  pf.end(c);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  return QSVC_OK;
+}
+
+int qsvc_synthesize_step(qsvc_ctx* c, int t, int P, int bs, int S, float uf) {
+  int r = qsvc_un_update(c, t, P, bs, uf);
+  if (r) return r;
+  return qsvc_correlate(c, t, P, bs, S);
 }
 
 // ---- halo ---------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ SYMBOLS = [
     "qsvc_init", "qsvc_destroy", "qsvc_last_error", "qsvc_stream", "qsvc_sync", "qsvc_seq_config",
     "qsvc_put_frames", "qsvc_get_frames", "qsvc_put_motion", "qsvc_get_motion", "qsvc_put_frame_types",
     "qsvc_get_frame_types", "qsvc_get_histograms", "qsvc_motion_estimate", "qsvc_decorrelate", "qsvc_update",
-    "qsvc_analyze_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
+    "qsvc_analyze_step", "qsvc_un_update", "qsvc_correlate", "qsvc_synthesize_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_dwt53_trunc",
     "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_j2k_dwt", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
 ]
@@ -66,6 +66,9 @@ def load_library() -> C.CDLL:
     L.qsvc_decorrelate.argtypes = [vp, i, i, i, i, i]
     L.qsvc_update.argtypes = [vp, i, i, i, C.c_float]
     L.qsvc_analyze_step.argtypes = [vp, i, i, i, i, i, C.c_float]
+    L.qsvc_un_update.argtypes = [vp, i, i, i, C.c_float]
+    L.qsvc_correlate.argtypes = [vp, i, i, i, i]
+    L.qsvc_synthesize_step.argtypes = [vp, i, i, i, i, C.c_float]
     L.qsvc_halo_bytes.argtypes = [vp, i]; L.qsvc_halo_bytes.restype = C.c_size_t
     L.qsvc_halo_export_host.argtypes = [vp, i, i, vp]
     L.qsvc_halo_import_host.argtypes = [vp, i, i, vp]
@@ -176,6 +179,16 @@ class Engine:
 
     def analyze_step(self, t, pictures, block_size, search_range, always_B=0, update_factor=0.25):
         self._chk(self.L.qsvc_analyze_step(self.h, t, pictures, block_size, search_range, always_B, update_factor))
+
+    # ---- inverse temporal level (synthesize_step.py): low_t, high_t, motion (FILTERED), frame types -> low_{t-1}
+    def un_update(self, t, pictures, block_size, update_factor=0.25):
+        self._chk(self.L.qsvc_un_update(self.h, t, pictures, block_size, update_factor))
+
+    def correlate(self, t, pictures, block_size, search_range):
+        self._chk(self.L.qsvc_correlate(self.h, t, pictures, block_size, search_range))
+
+    def synthesize_step(self, t, pictures, block_size, search_range, update_factor=0.25):
+        self._chk(self.L.qsvc_synthesize_step(self.h, t, pictures, block_size, search_range, update_factor))
 
     def sync(self):
         self._chk(self.L.qsvc_sync(self.h))

@@ -91,7 +91,7 @@ int emul_predict(const uint8_t* low, int P, int W, int H, int bs, int S, const i
   std::vector<int16_t> margin;
   MarginGeom mg = margin_geom(g);
   if (H % bs || W % bs) margin.assign((size_t)(g.nB ? g.nB : 1) * 2 * mg.count(), 0);  // Q7
-  PredArgs a = {g, low, mv, high, pred, hist, margin.empty() ? nullptr : margin.data()};
+  PredArgs a = {g, low, mv, high, pred, hist, margin.empty() ? nullptr : margin.data(), nullptr, nullptr};
   memset(hist, 0, sizeof(unsigned) * g.nB * 3 * 256);
   size_t fld = (size_t)g.BY * g.BX;
   for (int i = 0; i < g.nB; i++) {
@@ -119,12 +119,44 @@ int emul_update(const uint8_t* low, int P, int W, int H, int bs, const uint8_t* 
   if ((W & 1) || (H & 1)) return -2;
   UpdArgs a;
   a.g = g; a.frames = low; a.high = high; a.mv = mv; a.types = (const uint8_t*)types; a.low = low_out; a.uf = uf; a.reach = reach;
+  a.src_mul = 2; a.dst_mul = 1;
   a.halo_high[0] = halo_l; a.halo_mv[0] = halo_l ? (const int16_t*)(halo_l + g.F) : nullptr; a.halo_type[0] = halo_l ? halo_l_type : 0;
   a.halo_high[1] = halo_r; a.halo_mv[1] = halo_r ? (const int16_t*)(halo_r + g.F) : nullptr; a.halo_type[1] = halo_r ? halo_r_type : 0;
   for (int j = 0; j <= g.nB; j++) {
     for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) upd_luma_thread(a, x, y, j);
     for (int c = 1; c < 3; c++)
       for (int y = 0; y < H / 2; y++) for (int x = 0; x < W / 2; x++) upd_chroma_thread(a, x, y, j, c);
+  }
+  return 0;
+}
+
+// inverse level: low_t [nB+1] -> frames [2nB+1] (even pictures by un_update, odd pictures by correlate, in place)
+int emul_synthesize_step(const uint8_t* low_t, int P, int W, int H, int bs, int S, const uint8_t* high, const int16_t* mv,
+                         const char* types, float uf, int reach, uint8_t* frames) {
+  LevelGeom g = make_geom(P, W, H, bs, S);
+  if ((W & 1) || (H & 1)) return -2;
+  UpdArgs u;
+  u.g = g; u.frames = low_t; u.high = high; u.mv = mv; u.types = (const uint8_t*)types; u.low = frames; u.uf = -uf; u.reach = reach;
+  u.src_mul = 1; u.dst_mul = 2;
+  for (int s = 0; s < 2; s++) { u.halo_high[s] = nullptr; u.halo_mv[s] = nullptr; u.halo_type[s] = 0; }
+  for (int j = 0; j <= g.nB; j++) {
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) upd_luma_thread(u, x, y, j);
+    for (int c = 1; c < 3; c++)
+      for (int y = 0; y < H / 2; y++) for (int x = 0; x < W / 2; x++) upd_chroma_thread(u, x, y, j, c);
+  }
+  std::vector<int16_t> margin;
+  MarginGeom mg = margin_geom(g);
+  if (H % bs || W % bs) margin.assign((size_t)(g.nB ? g.nB : 1) * 2 * mg.count(), 0);
+  PredArgs a = {g, frames, mv, (uint8_t*)high, nullptr, nullptr, margin.empty() ? nullptr : margin.data(), frames, (const uint8_t*)types};
+  for (int i = 0; i < g.nB; i++) {
+    if (a.margin)
+      for (int c = 1; c < 3; c++)
+        for (size_t k = 0; k < mg.count(); k++) pred_margin_thread(a, k, i, c);
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) { int ob, rb; pred_luma_thread(a, x, y, i, ob, rb); }
+    for (int c = 1; c < 3; c++)
+      for (int y = 0; y < H / 2; y++)
+        for (int x = 0; x < W / 2; x++) pred_chroma_thread(a, x, y, i, c);
   }
   return 0;
 }

@@ -30,6 +30,8 @@ def lib():
         L.emul_t1_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.emul_t1_block_split.argtypes = L.emul_t1_block.argtypes
         L.emul_border_luma.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _i16p]
+        L.emul_synthesize_step.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _i16p, C.c_char_p, C.c_float,
+                                           C.c_int, _u8p]
         _LIB = L
     return _LIB
 
@@ -67,6 +69,16 @@ def update(low, W, H, bs, high, mv, types, uf=0.25, halo_l=None, halo_r=None):
         hr = np.ascontiguousarray(halo_r[0]); tr = halo_r[1]; reach = max(reach, halo_r[2])
     r = lib().emul_update(low, low.shape[0], W, H, bs, np.ascontiguousarray(high), np.ascontiguousarray(mv), types, uf, reach,
                           hl.ctypes.data if hl is not None else None, tl, hr.ctypes.data if hr is not None else None, tr, out)
+    return r, out
+
+
+def synthesize_step(low_t, W, H, bs, S, high, mv, types, uf=0.25):
+    low_t = np.ascontiguousarray(low_t)
+    nB = high.shape[0]
+    out = np.zeros((2 * nB + 1, fb(W, H)), dtype=np.uint8)
+    reach = int(np.abs(mv).max()) if mv.size else 0
+    r = lib().emul_synthesize_step(low_t, 2 * nB + 1, W, H, bs, S, np.ascontiguousarray(high), np.ascontiguousarray(mv), types, uf,
+                                   reach, out)
     return r, out
 
 

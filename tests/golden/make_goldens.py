@@ -68,6 +68,17 @@ def main():
         filt = {t: lv["motion_filtered"] for t, lv in enumerate(levels, 1)}
         for t, r in O.ref_motion_residues(filt, H // bs, W // bs).items():
             out[f"motion_residue_{t}"] = r
+        # inverse chain (synthesize.py): the reference's un_update / correlate / merge from the coarsest level down, every
+        # level fed with the level above's RECONSTRUCTED low pictures
+        low = levels[-1]["low"]
+        S_t = [S * 2 ** k for k in range(len(levels))]
+        for t in range(len(levels), 0, -1):
+            lv = levels[t - 1]
+            r = O.ref_synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], W, H, bs, min(S_t[t - 1], 128), t=t)
+            low = r["low"]
+            out[f"synth_low_{t - 1}_sha"] = np.array(sha(low))
+            if full:
+                out[f"synth_low_{t - 1}"] = low
         np.savez_compressed(os.path.join(HERE, f"mctf_{name}.npz"), **out)
         print(name, [lv["frame_types"] for lv in levels])
 

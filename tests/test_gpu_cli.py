@@ -108,6 +108,36 @@ def test_motion_compress_tool_from_files(oracle, tmp_path):
         np.testing.assert_array_equal(J.decode_s16(cs), motion.demux_components(res[t])[3, 0])
 
 
+def test_synthesize_chain_tools(oracle, tmp_path):
+    """analyze, then `mctf synthesize` (synthesize.py) over the files it left: every low_{t-1} == the oracle's inverse chain;
+    the stage tools un_update / correlate / merge alone give the same level."""
+    W, H, TRLs, bs = 128, 96, 3, 16
+    P = 2 ** (TRLs - 1) + 1
+    clip = make_clip("pan_noise", P, W, H, 6)
+    clip.tofile(tmp_path / "low_0")
+    run(tmp_path, "analyze", f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", "--GOPs=1", f"--block_size={bs}",
+        f"--block_size_min={bs}", "--update_factor=0.25")
+    want = oracle.analyze(clip, W, H, TRLs, bs, 4, update_factor=0.25)
+    for t in range(1, TRLs):  # the decoder reads motion_t: the filtered field (motion_expand's output in the reference)
+        os.replace(tmp_path / f"motion_filtered_{t}", tmp_path / f"motion_{t}")
+    os.remove(tmp_path / "low_0"); os.remove(tmp_path / "low_1")
+    run(tmp_path, "synthesize", f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", "--GOPs=1", f"--block_size={bs}",
+        "--update_factor=0.25")
+    low, S_t = want[-1]["low"], [4, 8]
+    for t in range(TRLs - 1, 0, -1):
+        lv = want[t - 1]
+        low = oracle.synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], W, H, bs, S_t[t - 1])["low"]
+        np.testing.assert_array_equal(rd(tmp_path, f"low_{t - 1}"), low.reshape(-1), err_msg=f"low_{t - 1}")
+    # stage tools on level 2 (its inputs are untouched files)
+    geo = [f"--pixels_in_x={W}", f"--pixels_in_y={H}", "--pictures=3"]
+    run(tmp_path, "un_update", f"--block_size={bs}", "--even_fn=e2", "--frame_types_fn=frame_types_2", "--high_fn=high_2",
+        "--low_fn=low_2", "--motion_fn=motion_2", "--update_factor=0.25", *geo)
+    run(tmp_path, "correlate", f"--block_size={bs}", "--even_fn=e2", "--frame_types_fn=frame_types_2", "--high_fn=high_2",
+        "--motion_in_fn=motion_2", "--odd_fn=o2", "--search_range=8", *geo)
+    run(tmp_path, "merge", "--even=e2", "--low=l1", "--odd=o2", *geo)
+    np.testing.assert_array_equal(rd(tmp_path, "l1"), rd(tmp_path, "low_1"))
+
+
 def test_unsupported_requests_exit_nonzero(tmp_path):
     make_clip("pan", 5, 64, 64, 1).tofile(tmp_path / "low_0")
     r = subprocess.run([MCTF, "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=3", "--block_overlaping=2"],

@@ -48,6 +48,61 @@ def test_hip_matches_reference_goldens(eng, name):
     check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "frame_types", "high", "low", "prediction"))
 
 
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_hip_inverse_chain_matches_reference_goldens(eng, name):
+    """un_update + correlate (+ merge = the layout) down from the coarsest level, on the device-resident analysis outputs:
+    every reconstructed low_{t-1} == what the reference's own inverse tools produced (digests in the goldens)."""
+    from helpers import sha
+    from qsvc_amd import hip
+    z, m = load_golden(name)
+    clip = golden_input(z, m)
+    W, H, bs, TRLs = m["W"], m["H"], m["bs"], m["TRLs"]
+    run_levels(eng, clip, W, H, TRLs, bs, m["S"])
+    P_t, S_t, P, S = [], [], clip.shape[0], m["S"]
+    for t in range(1, TRLs):
+        P_t.append(P); S_t.append(S)
+        P, S = (P + 1) // 2, min(2 * S, 128)
+    for t in range(TRLs - 1, 0, -1):
+        eng.synthesize_step(t, P_t[t - 1], bs, S_t[t - 1])
+        low = eng.get_frames(hip.LOW, t - 1, 0, P_t[t - 1])
+        assert sha(low) == str(z[f"synth_low_{t - 1}_sha"]), f"synth_low_{t - 1}"
+        if f"synth_low_{t - 1}" in z.files:
+            np.testing.assert_array_equal(low, z[f"synth_low_{t - 1}"])
+
+
+SYNTH = [("pan_noise", 31, 9, 256, 160, 3, 16, 4), ("binary", 32, 5, 128, 96, 2, 16, 4), ("saturating", 33, 9, 192, 128, 3, 8, 4),
+         ("edge", 34, 9, 120, 68, 2, 32, 4), ("pan_noise", 35, 9, 200, 120, 3, 64, 4)]
+
+
+@pytest.mark.parametrize("kind,seed,frames,W,H,TRLs,bs,S", SYNTH)
+def test_hip_inverse_level_matches_oracle_from_host_inputs(eng, oracle, kind, seed, frames, W, H, TRLs, bs, S):
+    """The decoder's situation: subband pictures, motion and frame types arrive from the host (put_*), one level back."""
+    from qsvc_amd import hip
+    clip = make_clip(kind, frames, W, H, seed)
+    a = oracle.analyze_step(clip, W, H, bs, S)
+    want = oracle.synthesize_step(a["low"], a["high"], a["motion_filtered"], a["frame_types"], W, H, bs, S)
+    nB = frames // 2
+    eng.seq_config(W, H, True)
+    eng.put_frames(hip.LOW, 1, a["low"])
+    eng.put_frames(hip.HIGH, 1, a["high"])
+    eng.put_motion(hip.MOTION_FILTERED, 1, a["motion_filtered"], bs)
+    eng.put_frame_types(1, a["frame_types"])
+    eng.un_update(1, frames, bs)
+    np.testing.assert_array_equal(eng.get_frames(hip.LOW, 0, 0, frames)[0::2], want["even"])
+    eng.correlate(1, frames, bs, S)
+    got = eng.get_frames(hip.LOW, 0, 0, frames)
+    np.testing.assert_array_equal(got[0::2], want["even"])
+    np.testing.assert_array_equal(got[1::2], want["odd"])
+
+
+def test_inverse_level_needs_its_inputs(eng):
+    from qsvc_amd import hip
+    eng.seq_config(64, 64)
+    eng.put_frames(hip.LOW, 2, np.zeros((2, 64 * 64 * 3 // 2), dtype=np.uint8))
+    with pytest.raises(hip.QsvcError):
+        eng.un_update(2, 5, 16)  # needs 3 low pictures, high_2, motion_2, frame_types_2
+
+
 @pytest.mark.parametrize("name", ["odd_350x286"])
 def test_unsupported_geometries_fail_loudly(eng, name):
     from qsvc_amd import hip

@@ -62,3 +62,20 @@ def test_ragged_pictures_equal_restatement(E, oracle, kind, seed, frames, W, H, 
     r, lo = E.update(low, W, H, bs, high, want["motion_filtered"], want["frame_types"])
     assert r == 0
     np.testing.assert_array_equal(lo, want["low"])
+
+
+SYNTH = [("pan_noise", 12, 5, 128, 96, 16, 4), ("saturating", 14, 5, 128, 128, 8, 4), ("binary", 48, 5, 64, 64, 16, 4),
+         ("pan_noise", 18, 9, 72, 56, 16, 4), ("edge", 17, 5, 120, 72, 8, 16)]
+
+
+@pytest.mark.parametrize("kind,seed,frames,W,H,bs,S", SYNTH)
+def test_inverse_level_thread_code_equals_restatement(E, oracle, kind, seed, frames, W, H, bs, S):
+    """un_update + correlate + merge (synthesize_step.py) through the kernels' thread code, incl. 'I' pictures and Q7."""
+    from qsvc_amd.synth import make_clip
+    clip = make_clip(kind, frames, W, H, seed)
+    a = oracle.analyze_step(clip, W, H, bs, S)
+    want = oracle.synthesize_step(a["low"], a["high"], a["motion_filtered"], a["frame_types"], W, H, bs, S)
+    r, got = E.synthesize_step(a["low"], W, H, bs, S, a["high"], a["motion_filtered"], a["frame_types"])
+    assert r == 0
+    np.testing.assert_array_equal(got[0::2], want["even"])
+    np.testing.assert_array_equal(got[1::2], want["odd"])

@@ -3,7 +3,7 @@ compiled tools (tests/golden/make_goldens.py).  CPU only."""
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, check_levels_against_golden, golden_cases, golden_input, load_golden
+from helpers import GOLDEN, check_levels_against_golden, golden_cases, golden_input, load_golden, sha
 
 
 @pytest.mark.parametrize("name", golden_cases())
@@ -17,6 +17,14 @@ def test_mctf_restatement_matches_reference_goldens(oracle, name):
         levels.append(lv)
         low, S = lv["low"], min(2 * S, 128)
     check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "frame_types", "high", "low", "prediction"))
+    # inverse chain (un_update, correlate, merge of the reference; synthesize.py), each level fed with the reconstruction
+    S_t = [min(m["S"] * 2 ** k, 128) for k in range(len(levels))]
+    for t in range(len(levels), 0, -1):
+        lv = levels[t - 1]
+        low = oracle.synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], m["W"], m["H"], bs, S_t[t - 1])["low"]
+        assert sha(low) == str(z[f"synth_low_{t - 1}_sha"]), f"synth_low_{t - 1}"
+        if f"synth_low_{t - 1}" in z.files:
+            np.testing.assert_array_equal(low, z[f"synth_low_{t - 1}"])
 
 
 def test_dwt_known_answers(oracle):

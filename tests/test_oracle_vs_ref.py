@@ -32,6 +32,19 @@ def test_restatement_equals_compiled_reference(oracle, kind, seed, frames, W, H,
     assert a["frame_types"] == b["frame_types"]
 
 
+@pytest.mark.parametrize("kind,seed,frames,W,H,bs,S", [c for c in CASES if c[0] != "pan" or c[2] == 5] + [("binary", 48, 5, 64, 64, 16, 4)])
+def test_inverse_restatement_equals_compiled_reference(oracle, kind, seed, frames, W, H, bs, S):
+    """un_update / correlate / merge of oracle/_ref against qo_un_update / qo_correlate on the analysis outputs."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    clip = make_clip(kind, frames, W, H, seed)
+    a = oracle.analyze_step(clip, W, H, bs, S)
+    got = oracle.synthesize_step(a["low"], a["high"], a["motion_filtered"], a["frame_types"], W, H, bs, S)
+    want = oracle.ref_synthesize_step(a["low"], a["high"], a["motion_filtered"], a["frame_types"], W, H, bs, S)
+    for k in ("even", "odd", "low"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+
 def test_dwt_restatement_equals_reference_templates(oracle):
     if not oracle.have_ref():
         pytest.skip("oracle/_ref not built")
