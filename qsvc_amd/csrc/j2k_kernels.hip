@@ -184,8 +184,73 @@ __global__ void __launch_bounds__(256) k_t1_pack(const CbDesc* cbs, int ncb, con
     if (nb > cb.Mb || nb > 15) atomicOr(err, 1);  // magnitude does not fit M_b / the 15-bit lane format
   }
 }
+// The same for the 64-lane layout of the split Tier-1, one workgroup per (stripe, group of 64 blocks): coefficient rows are
+// read coalesced along x, the packed words go through an LDS transpose and leave as full 256-byte runs along the lane
+// index (the per-block form above scatters 4-byte stores 256 bytes apart: 12x write amplification in HBM).
+// maxmag[b] collects the block's largest magnitude (atomicMax; zeroed by the launcher), k_t1_nbps turns it into nbps.
+#define PK_ROW 65
+template <bool REV>
+__global__ void __launch_bounds__(256) k_t1_pack64(const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coefv,
+                                                    uint32_t* mags, int* maxmag) {
+  __shared__ uint32_t sT[128 * PK_ROW];  // [(x*2 + k)][lane]
+  __shared__ int smax[64];
+  const int s = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int x = tid & 63, lq = tid >> 6;
+  if (tid < 64) smax[tid] = 0;
+  __syncthreads();
+  for (int l = lq; l < 64; l += 4) {
+    const int b = g * 64 + l;
+    uint64_t word = 0;
+    int mymax = 0;
+    if (b < ncb) {
+      const CbDesc cb = cbs[b];
+      if (x < cb.w && 4 * s < cb.h) {
+        const PlaneDesc pd = planes[cb.plane];
+        for (int k = 0; k < 4; k++) {
+          int y = 4 * s + k;
+          if (y >= cb.h) break;
+          size_t i = pd.off + (size_t)(cb.y0 + y) * pd.W + cb.x0 + x;
+          int mag, neg;
+          if (REV) {
+            int v = ((const int32_t*)coefv)[i];
+            neg = v < 0; mag = neg ? -v : v;
+          } else {
+            float v = ((const float*)coefv)[i];
+            mag = (int)floorf(__fdiv_rn(fabsf(v), cb.delta));  // dead-zone quantiser, T.800 E.1
+            neg = v < 0.0f && mag;
+          }
+          mymax = mag > mymax ? mag : mymax;
+          word |= (uint64_t)((mag & 0x7FFF) | (neg << 15)) << (16 * k);
+        }
+      }
+    }
+    sT[(x * 2 + 0) * PK_ROW + l] = (uint32_t)word;
+    sT[(x * 2 + 1) * PK_ROW + l] = (uint32_t)(word >> 32);
+    if (mymax) atomicMax(&smax[l], mymax);
+  }
+  __syncthreads();
+  uint32_t* mg = mags + (size_t)g * T1_MAGS_WORDS * 64 + (size_t)s * 128 * 64;
+  for (int i = tid; i < 128 * 64; i += 256) mg[i] = sT[(i >> 6) * PK_ROW + (i & 63)];
+  if (tid < 64 && g * 64 + tid < ncb && smax[tid]) atomicMax(&maxmag[g * 64 + tid], smax[tid]);
+}
+__global__ void __launch_bounds__(256) k_t1_nbps(const CbDesc* cbs, int ncb, int* nbps, int* err) {
+  int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= ncb) return;
+  int m = nbps[b], nb = 0;
+  while (nb < 31 && (m >> nb)) nb++;
+  nbps[b] = nb;
+  if (nb > cbs[b].Mb || nb > 15) atomicOr(err, 1);  // magnitude does not fit M_b / the 15-bit lane format
+}
 void launch_t1_pack(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef, uint32_t* mags,
                     int* nbps, int* err, bool reversible, int lanes) {
+  if (lanes == 64) {
+    hipMemsetAsync(nbps, 0, (size_t)ncb * 4, st);
+    dim3 grid(16, (ncb + 63) / 64);
+    if (reversible) hipLaunchKernelGGL(k_t1_pack64<true>, grid, dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps);
+    else hipLaunchKernelGGL(k_t1_pack64<false>, grid, dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps);
+    hipLaunchKernelGGL(k_t1_nbps, dim3((ncb + 255) / 256), dim3(256), 0, st, cbs, ncb, nbps, err);
+    return;
+  }
   if (reversible) hipLaunchKernelGGL(k_t1_pack<true>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err, lanes);
   else hipLaunchKernelGGL(k_t1_pack<false>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err, lanes);
 }
