@@ -194,8 +194,8 @@ struct HostCb {  // host view of one coded block
 
 struct J2kState {
   DevBuf coefA, coefB, planes_d, cbs_d, nbps_d, mags, flags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
-  DevBuf waves_d, joboff_d, order_d, segs_d, cnt_d, dist_d;  // split Tier-1
-  std::vector<int> h_nbps, h_joboff, h_waves, h_order;
+  DevBuf waves_d, joboff_d, order_d, jobs_d, segs_d, cnt_d, dist_d;  // split Tier-1
+  std::vector<int> h_nbps, h_joboff, h_waves, h_order, h_jobs;
   std::vector<uint8_t> t2scratch;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
   std::vector<PlaneDesc> planes;
@@ -211,7 +211,7 @@ void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->coefB, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->flags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->waves_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d};
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->waves_d, &s->joboff_d, &s->order_d, &s->jobs_d, &s->segs_d, &s->cnt_d, &s->dist_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   delete s;
@@ -374,6 +374,9 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
   // Tier-1 form: "split" (default) = bit-plane-parallel context modelling + MQ kernel; "fused" = one kernel,
   // `lanes` code-blocks per wave through an LDS window.
   static const bool split = [] { const char* e = getenv("QSVC_T1_MODE"); return !(e && !strcmp(e, "fused")); }();
+  // context modelling of the split form: "cm2" (default) = sample-parallel, one wave per (block, bit-plane), no flag words in
+  // HBM (t1_cm2.h); "split" = the lane-per-block form over flag words (k_t1_flags_init + k_t1_cm)
+  static const bool cm2 = [] { const char* e = getenv("QSVC_T1_MODE"); return !(e && (!strcmp(e, "fused") || !strcmp(e, "split"))); }();
   static const int lanes_env = [] { const char* e = getenv("QSVC_T1_LANES"); int v = e ? atoi(e) : 8; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 8; }();
   const int lanes = split ? 64 : lanes_env;
   const int ngroups = (ncb + lanes - 1) / lanes;
@@ -400,8 +403,10 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
   launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, S.coefA.p, S.coefB.p, maxL, rev);
   pf.end(c);
   pf.begin(c, "j2k_t1_pack");
-  launch_t1_pack(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (uint32_t*)S.mags.p, (int*)S.nbps_d.p,
-                 (int*)S.err_d.p, rev, lanes);
+  if (cm2) launch_t1_pack_blk(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (unsigned long long*)S.mags.p,
+                              (int*)S.nbps_d.p, (int*)S.err_d.p, rev);
+  else launch_t1_pack(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (uint32_t*)S.mags.p, (int*)S.nbps_d.p,
+                      (int*)S.err_d.p, rev, lanes);
   pf.end(c);
   if (!split) {
     if ((r = S.flags.ensure(c, (size_t)ngroups * lanes * T1_FLAGS_WORDS * 4))) return r;
@@ -466,13 +471,26 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
     HIPCHK(c, hipMemcpyAsync(S.joboff_d.p, S.h_joboff.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
     if (nwaves) {
       if ((r = S.waves_d.ensure(c, (size_t)nwaves * 4))) return r;
-      if ((r = S.flags.ensure(c, (size_t)nwaves * T1_FLAGS_WORDS * 64 * 4))) return r;
+      if (!cm2) if ((r = S.flags.ensure(c, (size_t)nwaves * T1_FLAGS_WORDS * 64 * 4))) return r;
       if ((r = S.segs_d.ensure(c, (njobs ? njobs : 1) * (size_t)T1_SEG_BYTES))) return r;
       if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
       if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
       HIPCHK(c, hipMemcpyAsync(S.waves_d.p, S.h_waves.data(), (size_t)nwaves * 4, hipMemcpyHostToDevice, c->st));
     }
-    for (int stage = 0; stage < 3; stage++) {
+    if (cm2 && njobs) {  // job list: (block << 4 | plane) at joboff[block] + plane
+      S.h_jobs.resize(njobs);
+      for (int b = 0; b < ncb; b++) {
+        int nb = S.h_nbps[b] > 15 ? 15 : S.h_nbps[b];
+        for (int p = 0; p < nb; p++) S.h_jobs[S.h_joboff[b] + p] = (b << 4) | p;
+      }
+      if ((r = S.jobs_d.ensure(c, njobs * 4))) return r;
+      HIPCHK(c, hipMemcpyAsync(S.jobs_d.p, S.h_jobs.data(), njobs * 4, hipMemcpyHostToDevice, c->st));
+      pf.begin(c, "j2k_t1_cm");
+      launch_t1_cm2(c->st, (const int*)S.jobs_d.p, (int)njobs, (const CbDesc*)S.cbs_d.p, (const int*)S.nbps_d.p,
+                    (const unsigned long long*)S.mags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p, want_dist ? 1 : 0);
+      pf.end(c);
+    }
+    for (int stage = cm2 ? 2 : 0; stage < 3; stage++) {
       if (!nwaves && stage < 2) continue;
       pf.begin(c, stage == 0 ? "j2k_t1_flags" : (stage == 1 ? "j2k_t1_cm" : "j2k_t1_mq"));
       launch_t1_split(c->st, (const int*)S.waves_d.p, nwaves, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p,

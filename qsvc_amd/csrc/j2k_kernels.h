@@ -40,6 +40,10 @@ void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc*
                      const int* order, int nslots,
                      const uint32_t* mags, uint32_t* flags, uint8_t* segs, int* cnt, long long* dist, uint8_t* outbuf, int outcap,
                      CbOut* res, int* pass_len, long long* pass_dist, int want_dist, int stage);
+void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef,
+                        unsigned long long* mags, int* nbps, int* err, bool reversible);
+void launch_t1_cm2(hipStream_t st, const int* jobs, int njobs, const CbDesc* cbs, const int* nbps, const unsigned long long* mags,
+                   uint8_t* segs, int* cnt, long long* dist, int want_dist);
 void launch_gather(hipStream_t st, const uint8_t* outbuf, int outcap, const unsigned long long* offs, const int* lens, int ncb,
                    uint8_t* dst);
 }  // namespace qsvc

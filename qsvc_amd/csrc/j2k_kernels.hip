@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "j2k_kernels.h"
+#include "t1_cm2.h"
 
 namespace qsvc {
 
@@ -553,6 +554,143 @@ void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc*
     switch (ml) { case 4: MQ_LAUNCH(4); break; case 8: MQ_LAUNCH(8); break; case 32: MQ_LAUNCH(32); break; case 64: MQ_LAUNCH(64); break; default: MQ_LAUNCH(16); }
 #undef MQ_LAUNCH
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sample-parallel context modelling (t1_cm2.h): ONE WAVE per (code-block, bit-plane) job.  The block's magnitudes are read
+// once (block-contiguous layout, 512-byte rows), the per-column state words live in LDS, the decisions of a pass are laid
+// out in LDS in scan order by a prefix sum over the lanes' counts and leave as 16-byte stores.  No flag words in HBM.
+template <bool REV>
+__global__ void __launch_bounds__(256) k_t1_pack_blk(const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coefv,
+                                                      unsigned long long* mags, int* nbps_out, int* err) {
+  int b = blockIdx.x;
+  if (b >= ncb) return;
+  CbDesc cb = cbs[b];
+  PlaneDesc pd = planes[cb.plane];
+  unsigned long long* mg = mags + (size_t)b * 1024;
+  __shared__ int smax[256];
+  int x = threadIdx.x & 63, sq = threadIdx.x >> 6;
+  int mymax = 0;
+  for (int s = sq; s < 16; s += 4) {
+    uint64_t word = 0;
+    if (x < cb.w) {
+      for (int k = 0; k < 4; k++) {
+        int y = 4 * s + k;
+        if (y >= cb.h) break;
+        size_t i = pd.off + (size_t)(cb.y0 + y) * pd.W + cb.x0 + x;
+        int mag, neg;
+        if (REV) {
+          int v = ((const int32_t*)coefv)[i];
+          neg = v < 0; mag = neg ? -v : v;
+        } else {
+          float v = ((const float*)coefv)[i];
+          mag = (int)floorf(__fdiv_rn(fabsf(v), cb.delta));  // dead-zone quantiser, T.800 E.1
+          neg = v < 0.0f && mag;
+        }
+        mymax = mag > mymax ? mag : mymax;
+        word |= (uint64_t)((mag & 0x7FFF) | (neg << 15)) << (16 * k);
+      }
+    }
+    mg[s * 64 + x] = word;
+  }
+  smax[threadIdx.x] = mymax;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) smax[threadIdx.x] = smax[threadIdx.x] > smax[threadIdx.x + o] ? smax[threadIdx.x] : smax[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int m = smax[0], nb = 0;
+    while (nb < 31 && (m >> nb)) nb++;
+    nbps_out[b] = nb;
+    if (nb > cb.Mb || nb > 15) atomicOr(err, 1);
+  }
+}
+void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef,
+                        unsigned long long* mags, int* nbps, int* err, bool reversible) {
+  if (reversible) hipLaunchKernelGGL(k_t1_pack_blk<true>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err);
+  else hipLaunchKernelGGL(k_t1_pack_blk<false>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err);
+}
+
+#define CM2_OUT_BYTES 10240  // the largest pass segment (clean-up: 10 decisions per stripe column at most)
+__global__ void __launch_bounds__(64) k_t1_cm2(const int* jobs, int njobs, const CbDesc* cbs, const int* nbps_in,
+                                                const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist,
+                                                int want_dist) {
+  __shared__ uint32_t s_cw[18][66];
+  __shared__ uint32_t s_sp[64];
+  __shared__ uint8_t s_zc[512];
+  __shared__ __attribute__((aligned(16))) uint8_t s_out[CM2_OUT_BYTES];
+  const int job = blockIdx.x, lane = threadIdx.x;
+  if (job >= njobs) return;
+  const int jb = jobs[job], b = jb >> 4, p = jb & 15;
+  const CbDesc cb = cbs[b];
+  const int w = cb.w, h = cb.h, nstr = (h + 3) >> 2, nb = nbps_in[b];
+  const unsigned long long* mg = mags + (size_t)b * 1024;
+  // tables + column words (lane = column x, all stripes: 512-byte rows of magnitudes)
+  s_sp[lane] = CM2_SPREAD_INIT((uint32_t)lane);
+  {
+    const int oc = cb.orient == 1 ? 1 : (cb.orient == 3 ? 3 : 0);
+    for (int i = lane; i < 512; i += 64) s_zc[i] = (uint8_t)t1_zc_from_nb(i, oc);
+  }
+  for (int i = lane; i < 18 * 66; i += 64) (&s_cw[0][0])[i] = 0;
+  __syncthreads();
+  for (int s = 0; s < nstr; s++) {
+    const int rows = h - 4 * s > 4 ? 4 : h - 4 * s;
+    if (lane < w) s_cw[s + 1][lane + 1] = cm2_colword(mg[s * 64 + lane], p, rows, true);
+  }
+  __syncthreads();
+  // membership: lane = stripe, two columns behind the stripe above; a step's stores follow all of its loads
+  {
+    const int steps = w + 2 * (nstr - 1);
+    for (int t = 0; t < steps; t++) {
+      const int x = t - 2 * lane;
+      const bool on = lane < nstr && x >= 0 && x < w;
+      uint32_t res = 0;
+      if (on) res = cm2_member(&s_cw[lane][x], &s_cw[lane + 1][x], &s_cw[lane + 2][x]);
+      __syncthreads();
+      if (on) s_cw[lane + 1][x + 1] |= res;
+      __syncthreads();
+    }
+  }
+  Cm2Ctx cx;
+  cx.zc = s_zc; cx.sp = s_sp; cx.p = p; cx.want_dist = want_dist != 0;
+  const bool first = p == nb - 1;
+  for (int pass = 0; pass < 3; pass++) {
+    if (first && pass < 2) { if (lane == 0) { cnt[(size_t)job * 3 + pass] = 0; if (want_dist) dist[(size_t)job * 3 + pass] = 0; } continue; }
+    // count
+    Cm2CountSink C;
+    C.n = 0;
+    long long dd = 0;
+    for (int i = lane * 16; i < lane * 16 + 16; i++) {
+      const int s = i >> 6, x = i & 63;
+      if (s < nstr && x < w) cm2_column(C, cx, pass, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x], 0ull, dd);
+    }
+    // exclusive prefix sum over the 64 lanes
+    int incl = C.n;
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const int total = __shfl(incl, 63, 64);
+    Cm2ByteSink B;
+    B.out = s_out + (incl - C.n); B.n = 0;
+    dd = 0;
+    for (int i = lane * 16; i < lane * 16 + 16; i++) {
+      const int s = i >> 6, x = i & 63;
+      if (s < nstr && x < w)
+        cm2_column(B, cx, pass, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x], want_dist ? mg[i] : 0ull, dd);
+    }
+    __syncthreads();
+    uint8_t* seg = segs + (size_t)job * T1_SEG_BYTES + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
+    for (int o = lane * 16; o < total; o += 64 * 16) *(uint4*)(seg + o) = *(const uint4*)(s_out + o);
+    if (want_dist) {
+      for (int o = 32; o >= 1; o >>= 1) dd += __shfl_xor(dd, o, 64);
+      if (lane == 0) dist[(size_t)job * 3 + pass] = dd;
+    }
+    if (lane == 0) cnt[(size_t)job * 3 + pass] = total;
+    __syncthreads();  // s_out is reused by the next pass
+  }
+}
+void launch_t1_cm2(hipStream_t st, const int* jobs, int njobs, const CbDesc* cbs, const int* nbps, const unsigned long long* mags,
+                   uint8_t* segs, int* cnt, long long* dist, int want_dist) {
+  if (njobs > 0) hipLaunchKernelGGL(k_t1_cm2, dim3(njobs), dim3(64), 0, st, jobs, njobs, cbs, nbps, mags, segs, cnt, dist, want_dist);
 }
 
 // gather: segment of block b (bytes 1..len of its lane buffer) -> dst + offs[b]

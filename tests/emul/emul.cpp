@@ -171,6 +171,7 @@ int emul_border_luma(const uint8_t* luma, int H, int W, int b, int16_t* out /*(H
 
 // ---- EBCOT Tier-1: one block through the lane code with lane stride 1 -------------------------
 #include "../../qsvc_amd/csrc/t1_core.h"
+#include "../../qsvc_amd/csrc/t1_cm2.h"
 extern "C" int emul_t1_block(const int32_t* vals, int w, int h, int orient, uint8_t* out, int* npasses, int* nbps,
                              int* pass_len, long long* pass_dist) {
   static const uint32_t mqtab[47] = T1_MQ_TABLE_INIT;
@@ -255,6 +256,104 @@ extern "C" int emul_t1_block_split(const int32_t* vals, int w, int h, int orient
   for (int i = 0; i < 94; i++) mq2[i] = mq2_pair(mqtab, i);
   T1Lane t;
   t.cx = cx; t.mqtab = mqtab; t.mq2 = mq2; t.zclut = zclut; t.out = bufp;
+  t.cs = 1; t.cap = (int)buf32.size() * 4; t.w = w; t.h = h; t.orient = orient; t.nbps = nb;
+  T1Result r;
+  int pl[T1_MAXPASS]; long long pd[T1_MAXPASS];
+  r.pass_len = pl; r.pass_dist = pd;
+  auto Seg = [&](int p) { return (const uint8_t*)segs.data() + (size_t)p * T1_SEG_BYTES; };
+  auto Cnt = [&](int p, int pass) { return cnt[p * 3 + pass]; };
+  auto Dist = [&](int p, int pass) { return dist[p * 3 + pass]; };
+  t1_mq_block(t, Seg, Cnt, Dist, r);
+  if (r.overflow) return -2;
+  memcpy(out, bufp + 1, r.len);
+  *npasses = r.npasses; *nbps = r.nbps;
+  for (int i = 0; i < r.npasses; i++) { pass_len[i] = pl[i]; if (pass_dist) pass_dist[i] = pd[i]; }
+  return r.len;
+}
+
+// ---- sample-parallel context modelling (t1_cm2.h) driven like the kernel: one "wave" per (block, plane); membership by 16
+// stripe lanes, each two columns behind the stripe above; then 64 "threads" x 16 stripe columns count, scan and emit ----
+extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, uint8_t* out, int* npasses, int* nbps,
+                                 int* pass_len, long long* pass_dist) {
+  static const uint32_t mqtab[47] = T1_MQ_TABLE_INIT;
+  static uint8_t zclut[3 * 512];
+  static uint32_t sp[64];
+  static bool init = false;
+  if (!init) {
+    for (int c = 0; c < 3; c++)
+      for (int nb = 0; nb < 512; nb++) zclut[c * 512 + nb] = (uint8_t)t1_zc_from_nb(nb, c == 0 ? 0 : (c == 1 ? 1 : 3));
+    for (uint32_t v = 0; v < 64; v++) sp[v] = CM2_SPREAD_INIT(v);
+    init = true;
+  }
+  std::vector<uint64_t> mags(16 * 64, 0);
+  int maxm = 0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int v = vals[y * w + x];
+      int m = v < 0 ? -v : v;
+      if (m > 0x7FFF) return -1;
+      if (m > maxm) maxm = m;
+      mags[(y >> 2) * 64 + x] |= (uint64_t)(m | (v < 0 ? 0x8000 : 0)) << (16 * (y & 3));
+    }
+  int nb = 0;
+  while (maxm >> nb) nb++;
+  const int nstr = (h + 3) >> 2;
+  std::vector<uint8_t> segs((size_t)(nb ? nb : 1) * T1_SEG_BYTES);
+  std::vector<int> cnt((size_t)(nb ? nb : 1) * 3, 0);
+  std::vector<long long> dist((size_t)(nb ? nb : 1) * 3, 0);
+  for (int p = 0; p < nb; p++) {
+    uint32_t cw[18][66];  // one-cell apron of zeros
+    memset(cw, 0, sizeof cw);
+    for (int s = 0; s < nstr; s++)
+      for (int x = 0; x < w; x++) cw[s + 1][x + 1] = cm2_colword(mags[s * 64 + x], p, h - 4 * s > 4 ? 4 : h - 4 * s, true);
+    for (int t = 0; t < w + 2 * (nstr - 1); t++) {       // membership: stripe lane s works on column t - 2s
+      uint32_t res[16]; bool on[16];
+      for (int s = 0; s < nstr; s++) {
+        int x = t - 2 * s;
+        on[s] = x >= 0 && x < w;
+        if (on[s]) res[s] = cm2_member(&cw[s][x], &cw[s + 1][x], &cw[s + 2][x]);
+      }
+      for (int s = 0; s < nstr; s++) if (on[s]) cw[s + 1][t - 2 * s + 1] |= res[s];  // all lanes store after all computed
+    }
+    Cm2Ctx cx{zclut + 512 * (orient == 1 ? 1 : (orient == 3 ? 2 : 0)), sp, p, true};
+    const bool active = true, first = p == nb - 1;
+    (void)active;
+    for (int pass = 0; pass < 3; pass++) {
+      if (first && pass < 2) { cnt[p * 3 + pass] = 0; continue; }
+      int counts[64], offs[65];
+      for (int th = 0; th < 64; th++) {
+        Cm2CountSink C{0};
+        long long dd = 0;
+        for (int i = th * 16; i < th * 16 + 16; i++) {
+          int s = i >> 6, x = i & 63;
+          if (s >= nstr || x >= w) continue;
+          cm2_column(C, cx, pass, &cw[s][x], &cw[s + 1][x], &cw[s + 2][x], mags[s * 64 + x], dd);
+        }
+        counts[th] = C.n;
+      }
+      offs[0] = 0;
+      for (int th = 0; th < 64; th++) offs[th + 1] = offs[th] + counts[th];
+      uint8_t* seg = segs.data() + (size_t)p * T1_SEG_BYTES + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
+      long long dsum = 0;
+      for (int th = 0; th < 64; th++) {
+        Cm2ByteSink B{seg + offs[th], 0};
+        for (int i = th * 16; i < th * 16 + 16; i++) {
+          int s = i >> 6, x = i & 63;
+          if (s >= nstr || x >= w) continue;
+          cm2_column(B, cx, pass, &cw[s][x], &cw[s + 1][x], &cw[s + 2][x], mags[s * 64 + x], dsum);
+        }
+        if (B.n != counts[th]) return -3;
+      }
+      cnt[p * 3 + pass] = offs[64]; dist[p * 3 + pass] = dsum;
+    }
+  }
+  static uint64_t mq2[94];
+  for (int i = 0; i < 94; i++) mq2[i] = mq2_pair(mqtab, i);
+  uint32_t cxs[19];
+  std::vector<uint32_t> buf32((size_t)w * h + 16);
+  uint8_t* bufp = (uint8_t*)buf32.data();
+  T1Lane t;
+  t.cx = cxs; t.mqtab = mqtab; t.mq2 = mq2; t.zclut = zclut; t.out = bufp;
   t.cs = 1; t.cap = (int)buf32.size() * 4; t.w = w; t.h = h; t.orient = orient; t.nbps = nb;
   T1Result r;
   int pl[T1_MAXPASS]; long long pd[T1_MAXPASS];

@@ -29,6 +29,7 @@ def lib():
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, _u8p]
         L.emul_t1_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.emul_t1_block_split.argtypes = L.emul_t1_block.argtypes
+        L.emul_t1_block_cm2.argtypes = L.emul_t1_block.argtypes
         L.emul_border_luma.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _i16p]
         L.emul_synthesize_step.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _i16p, C.c_char_p, C.c_float,
                                            C.c_int, _u8p]
@@ -82,12 +83,12 @@ def synthesize_step(low_t, W, H, bs, S, high, mv, types, uf=0.25):
     return r, out
 
 
-def t1_block(vals, orient, split=False):
+def t1_block(vals, orient, split=False, cm2=False):
     v = np.ascontiguousarray(vals, dtype=np.int32)
     h, w = v.shape
     out = np.empty(w * h * 4 + 64, dtype=np.uint8)
     npasses, nbps = C.c_int(), C.c_int()
     pl = np.zeros(64, dtype=np.int32)
     pd = np.zeros(64, dtype=np.int64)
-    n = (lib().emul_t1_block_split if split else lib().emul_t1_block)(v.ctypes.data, w, h, orient, out.ctypes.data, C.byref(npasses), C.byref(nbps), pl.ctypes.data, pd.ctypes.data)
+    n = (lib().emul_t1_block_cm2 if cm2 else (lib().emul_t1_block_split if split else lib().emul_t1_block))(v.ctypes.data, w, h, orient, out.ctypes.data, C.byref(npasses), C.byref(nbps), pl.ctypes.data, pd.ctypes.data)
     return out[:max(n, 0)].tobytes(), npasses.value, nbps.value, pl[:npasses.value].copy(), pd[:npasses.value].copy()
