@@ -613,23 +613,36 @@ void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneD
 }
 
 #define CM2_OUT_BYTES 10240  // the largest pass segment (clean-up: 10 decisions per stripe column at most)
-__global__ void __launch_bounds__(64) k_t1_cm2(const int* jobs, int njobs, const CbDesc* cbs, const int* nbps_in,
-                                                const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist,
-                                                int want_dist) {
-  __shared__ uint32_t s_cw[18][66];
+#ifndef CM2_JOBS
+#define CM2_JOBS 1           // jobs (waves) per workgroup (<= 4): their membership recurrences share wave 0, 16 lanes each.
+#endif                       // Measured: 1 -> 3.8 ms, 4 -> 4.8 ms per 17-picture step (the other waves idle through the chain)
+__global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int njobs, const CbDesc* cbs, const int* nbps_in,
+                                                           const unsigned long long* mags, uint8_t* segs, int* cnt,
+                                                           long long* dist, int want_dist) {
+  __shared__ uint32_t s_cwq[CM2_JOBS][18][66];
   __shared__ uint32_t s_sp[64];
-  __shared__ uint8_t s_zc[512];
-  __shared__ __attribute__((aligned(16))) uint8_t s_out[CM2_OUT_BYTES];
-  const int job = blockIdx.x, lane = threadIdx.x;
-  if (job >= njobs) return;
-  const int jb = jobs[job], b = jb >> 4, p = jb & 15;
-  const CbDesc cb = cbs[b];
-  const int w = cb.w, h = cb.h, nstr = (h + 3) >> 2, nb = nbps_in[b];
+  __shared__ uint8_t s_zcq[CM2_JOBS][512];
+  __shared__ __attribute__((aligned(16))) uint8_t s_outq[CM2_JOBS][CM2_OUT_BYTES];
+  __shared__ int s_geo[CM2_JOBS][2];
+  const int jq = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int job = blockIdx.x * CM2_JOBS + jq;
+  const bool live = job < njobs;
+  uint32_t (*s_cw)[66] = s_cwq[jq];
+  uint8_t* s_zc = s_zcq[jq];
+  uint8_t* s_out = s_outq[jq];
+  int b = 0, p = 0, w = 0, h = 0, nstr = 0, nb = 0, orient = 0;
+  if (live) {
+    const int jb = jobs[job];
+    b = jb >> 4; p = jb & 15;
+    const CbDesc cb = cbs[b];
+    w = cb.w; h = cb.h; nstr = (h + 3) >> 2; nb = nbps_in[b]; orient = cb.orient;
+  }
   const unsigned long long* mg = mags + (size_t)b * 1024;
   // tables + column words (lane = column x, all stripes: 512-byte rows of magnitudes)
-  s_sp[lane] = CM2_SPREAD_INIT((uint32_t)lane);
+  if (jq == 0) s_sp[lane] = CM2_SPREAD_INIT((uint32_t)lane);
+  if (lane == 0) { s_geo[jq][0] = w; s_geo[jq][1] = nstr; }
   {
-    const int oc = cb.orient == 1 ? 1 : (cb.orient == 3 ? 3 : 0);
+    const int oc = orient == 1 ? 1 : (orient == 3 ? 3 : 0);
     for (int i = lane; i < 512; i += 64) s_zc[i] = (uint8_t)t1_zc_from_nb(i, oc);
   }
   for (int i = lane; i < 18 * 66; i += 64) (&s_cw[0][0])[i] = 0;
@@ -639,58 +652,105 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const int* jobs, int njobs, const
     if (lane < w) s_cw[s + 1][lane + 1] = cm2_colword(mg[s * 64 + lane], p, rows, true);
   }
   __syncthreads();
-  // membership: lane = stripe, two columns behind the stripe above; a step's stores follow all of its loads
-  {
-    const int steps = w + 2 * (nstr - 1);
+  // membership of all CM2_JOBS jobs on wave 0: lane = (job, stripe), each stripe two columns behind the one above.  One
+  // wave: the lanes' loads of a step all issue before its stores, and LDS executes a wave's operations in order, so the
+  // steps need no barrier.
+  if (jq == 0) {
+    const int mj0 = lane >> 4, ms = lane & 15;
+    const bool mlive = mj0 < CM2_JOBS;
+    const int mj = mlive ? mj0 : 0;
+    const int mw = mlive ? s_geo[mj][0] : 0, mn = mlive ? s_geo[mj][1] : 0;
+    uint32_t (*cwm)[66] = s_cwq[mj];
+    int steps = mn ? mw + 2 * (mn - 1) : 0;
+    for (int o = 32; o >= 1; o >>= 1) { int v = __shfl_xor(steps, o, 64); steps = v > steps ? v : steps; }
     for (int t = 0; t < steps; t++) {
-      const int x = t - 2 * lane;
-      const bool on = lane < nstr && x >= 0 && x < w;
-      uint32_t res = 0;
-      if (on) res = cm2_member(&s_cw[lane][x], &s_cw[lane + 1][x], &s_cw[lane + 2][x]);
-      __syncthreads();
-      if (on) s_cw[lane + 1][x + 1] |= res;
-      __syncthreads();
+      const int x = t - 2 * ms;
+      if (ms < mn && x >= 0 && x < mw) {
+        const uint32_t res = cm2_member(&cwm[ms][x], &cwm[ms + 1][x], &cwm[ms + 2][x]);
+        cwm[ms + 1][x + 1] |= res;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
+  __syncthreads();
+  if (!live) return;  // no workgroup-wide barrier below this line
   Cm2Ctx cx;
   cx.zc = s_zc; cx.sp = s_sp; cx.p = p; cx.want_dist = want_dist != 0;
   const bool first = p == nb - 1;
-  for (int pass = 0; pass < 3; pass++) {
-    if (first && pass < 2) { if (lane == 0) { cnt[(size_t)job * 3 + pass] = 0; if (want_dist) dist[(size_t)job * 3 + pass] = 0; } continue; }
-    // count
-    Cm2CountSink C;
-    C.n = 0;
+  const int pass0 = first ? 2 : 0;
+  // count the three passes' decisions of this lane's 16 stripe columns (one neighbourhood assembly per column)
+  int n3[3] = {0, 0, 0};
+  for (int i = lane * 16; i < lane * 16 + 16; i++) {
+    const int s = i >> 6, x = i & 63;
+    if (s >= nstr || x >= w) continue;
+    Cm2Col c;
+    cm2_gather(c, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x]);
     long long dd = 0;
-    for (int i = lane * 16; i < lane * 16 + 16; i++) {
-      const int s = i >> 6, x = i & 63;
-      if (s < nstr && x < w) cm2_column(C, cx, pass, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x], 0ull, dd);
+    for (int pass = pass0; pass < 3; pass++) {
+      Cm2CountSink C;
+      C.n = 0;
+      cm2_pass(C, cx, pass, c, 0ull, dd);
+      n3[pass] += C.n;
     }
-    // exclusive prefix sum over the 64 lanes
-    int incl = C.n;
+  }
+  int off3[3], tot3[3];
+  for (int pass = 0; pass < 3; pass++) {
+    int incl = n3[pass];
     for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    const int total = __shfl(incl, 63, 64);
-    Cm2ByteSink B;
-    B.out = s_out + (incl - C.n); B.n = 0;
-    dd = 0;
+    off3[pass] = incl - n3[pass];
+    tot3[pass] = __shfl(incl, 63, 64);
+  }
+  uint8_t* seg = segs + (size_t)job * T1_SEG_BYTES;
+  long long d3[3] = {0, 0, 0};
+  // 16-byte aligned bases of the three streams inside s_out when all of them fit at once
+  const int base1 = (tot3[0] + 15) & ~15, base2 = base1 + ((tot3[1] + 15) & ~15);
+  if (base2 + tot3[2] <= CM2_OUT_BYTES) {
+    Cm2ByteSink B0, B1, B2;
+    B0.out = s_out + off3[0]; B0.n = 0;
+    B1.out = s_out + base1 + off3[1]; B1.n = 0;
+    B2.out = s_out + base2 + off3[2]; B2.n = 0;
     for (int i = lane * 16; i < lane * 16 + 16; i++) {
       const int s = i >> 6, x = i & 63;
-      if (s < nstr && x < w)
-        cm2_column(B, cx, pass, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x], want_dist ? mg[i] : 0ull, dd);
+      if (s >= nstr || x >= w) continue;
+      Cm2Col c;
+      cm2_gather(c, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x]);
+      const uint64_t mag = want_dist ? mg[i] : 0ull;
+      if (!first) { cm2_pass(B0, cx, 0, c, mag, d3[0]); cm2_pass(B1, cx, 1, c, mag, d3[1]); }
+      cm2_pass(B2, cx, 2, c, mag, d3[2]);
     }
-    __syncthreads();
-    uint8_t* seg = segs + (size_t)job * T1_SEG_BYTES + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
-    for (int o = lane * 16; o < total; o += 64 * 16) *(uint4*)(seg + o) = *(const uint4*)(s_out + o);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (int pass = pass0; pass < 3; pass++) {
+      const uint8_t* src = s_out + (pass == 0 ? 0 : (pass == 1 ? base1 : base2));
+      uint8_t* dst = seg + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
+      for (int o = lane * 16; o < tot3[pass]; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(src + o);
+    }
+  } else {  // a dense plane: one pass at a time through the buffer
+    for (int pass = pass0; pass < 3; pass++) {
+      Cm2ByteSink B;
+      B.out = s_out + off3[pass]; B.n = 0;
+      for (int i = lane * 16; i < lane * 16 + 16; i++) {
+        const int s = i >> 6, x = i & 63;
+        if (s < nstr && x < w)
+          cm2_column(B, cx, pass, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x], want_dist ? mg[i] : 0ull, d3[pass]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+      uint8_t* dst = seg + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
+      for (int o = lane * 16; o < tot3[pass]; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(s_out + o);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+    }
+  }
+  for (int pass = 0; pass < 3; pass++) {
     if (want_dist) {
+      long long dd = d3[pass];
       for (int o = 32; o >= 1; o >>= 1) dd += __shfl_xor(dd, o, 64);
       if (lane == 0) dist[(size_t)job * 3 + pass] = dd;
     }
-    if (lane == 0) cnt[(size_t)job * 3 + pass] = total;
-    __syncthreads();  // s_out is reused by the next pass
+    if (lane == 0) cnt[(size_t)job * 3 + pass] = tot3[pass];
   }
 }
 void launch_t1_cm2(hipStream_t st, const int* jobs, int njobs, const CbDesc* cbs, const int* nbps, const unsigned long long* mags,
                    uint8_t* segs, int* cnt, long long* dist, int want_dist) {
-  if (njobs > 0) hipLaunchKernelGGL(k_t1_cm2, dim3(njobs), dim3(64), 0, st, jobs, njobs, cbs, nbps, mags, segs, cnt, dist, want_dist);
+  if (njobs > 0) hipLaunchKernelGGL(k_t1_cm2, dim3((njobs + CM2_JOBS - 1) / CM2_JOBS), dim3(64 * CM2_JOBS), 0, st, jobs, njobs, cbs, nbps, mags, segs, cnt, dist, want_dist);
 }
 
 // gather: segment of block b (bytes 1..len of its lane buffer) -> dst + offs[b]

@@ -87,47 +87,60 @@ struct Cm2ByteSink {  // decisions as bytes cx | d << 5, in order
   T1HD_M void sym(int cx, int d) { out[n++] = (uint8_t)(cx | (d << 5)); }
 };
 
+// Everything the three passes of one stripe column need, assembled once from the 3 x 3 neighbourhood of column words.
+struct Cm2Col {
+  uint32_t w;                 // the column's own word
+  uint32_t s0[3], s1[3], s2[3];  // 6-row vectors of sig0 / S1 / S2 for columns x-1, x, x+1
+  uint32_t chiL, chiC, chiR;  // 6-row sign vectors at T1_CHI_SHIFT (the layout t1_code_sign reads)
+};
+T1HD void cm2_gather(Cm2Col& c, const uint32_t u[3], const uint32_t m[3], const uint32_t d[3]) {
+  c.w = m[1];
+  for (int k = 0; k < 3; k++) {
+    c.s0[k] = cm2_six(u[k], m[k], d[k], CW_SIG0);
+    c.s1[k] = cm2_six(u[k], m[k], d[k], CW_S1);
+    c.s2[k] = cm2_six(u[k], m[k], d[k], CW_S2);
+  }
+  c.chiL = cm2_six(u[0], m[0], d[0], CW_NEG) << T1_CHI_SHIFT;
+  c.chiC = cm2_six(u[1], m[1], d[1], CW_NEG) << T1_CHI_SHIFT;
+  c.chiR = cm2_six(u[2], m[2], d[2], CW_NEG) << T1_CHI_SHIFT;
+}
+
 // The decisions of one stripe column in one pass (0 significance propagation, 1 magnitude refinement, 2 clean-up), in
 // coding order, with the column words final (M/S1/S2 set everywhere).  mag = the column's four packed magnitudes (only the
 // distortion estimates read it).
 template <class Sink>
-T1HD void cm2_column(Sink& K, const Cm2Ctx& cx, int pass, const uint32_t u[3], const uint32_t m[3], const uint32_t d[3],
-                     uint64_t mag, long long& dist) {
-  const uint32_t w = m[1];
+T1HD void cm2_pass(Sink& K, const Cm2Ctx& cx, int pass, const Cm2Col& c, uint64_t mag, long long& dist) {
+  const uint32_t w = c.w;
   const uint32_t val4 = (w >> CW_VAL) & 0xF;
   if (!val4) return;
   const int rows = val4 == 0xF ? 4 : (val4 == 7 ? 3 : (val4 == 3 ? 2 : 1));
   const uint32_t bit4 = (w >> CW_BIT) & 0xF, M4 = (w >> CW_M) & 0xF, sig04 = (w >> CW_SIG0) & 0xF;
   const int p = cx.p;
-  uint32_t s0[3], s1[3];
-  for (int c = 0; c < 3; c++) { s0[c] = cm2_six(u[c], m[c], d[c], CW_SIG0); s1[c] = cm2_six(u[c], m[c], d[c], CW_S1); }
   if (pass == 1) {
     const uint32_t todo = sig04 & val4;
     if (!todo) return;
-    const uint32_t f = cx.sp[s0[0] | s1[0]] | (cx.sp[s0[1] | s1[1]] << 1) | (cx.sp[s0[2] | s1[2]] << 2);
+    const uint32_t f = cx.sp[c.s0[0] | c.s1[0]] | (cx.sp[c.s0[1] | c.s1[1]] << 1) | (cx.sp[c.s0[2] | c.s1[2]] << 2);
     for (int k = 0; k < 4; k++) {
       if (!((todo >> k) & 1)) continue;
       const int nb = (f >> (3 * k)) & 0x1FF;
-      const int c = ((w >> (CW_MU + k)) & 1) ? 16 : ((nb & 0x1EF) ? 15 : 14);
-      K.sym(c, (bit4 >> k) & 1);
+      const int ctx = ((w >> (CW_MU + k)) & 1) ? 16 : ((nb & 0x1EF) ? 15 : 14);
+      K.sym(ctx, (bit4 >> k) & 1);
       if (cx.want_dist) dist += t1_dist_ref(t1_mag(mag, k), p);
     }
     return;
   }
-  const uint32_t chiL = cm2_six(u[0], m[0], d[0], CW_NEG) << T1_CHI_SHIFT, chiR = cm2_six(u[2], m[2], d[2], CW_NEG) << T1_CHI_SHIFT;
-  const uint32_t chiC = cm2_six(u[1], m[1], d[1], CW_NEG) << T1_CHI_SHIFT;
   if (pass == 0) {
-    const uint32_t L6 = s0[0] | (s1[0] & 0x1F), C6 = s0[1] | (s1[1] & 1), R6 = s0[2] | (s1[2] & 1);
+    const uint32_t L6 = c.s0[0] | (c.s1[0] & 0x1F), C6 = c.s0[1] | (c.s1[1] & 1), R6 = c.s0[2] | (c.s1[2] & 1);
     uint32_t f = cx.sp[L6] | (cx.sp[C6] << 1) | (cx.sp[R6] << 2);
     if (!f) return;
-    f |= chiC;
+    f |= c.chiC;
     for (int k = 0; k < rows; k++) {
       const int nb = (f >> (3 * k)) & 0x1FF;
       if ((nb & 0x10) || (nb & 0x1EF) == 0) continue;
       const int bit = (bit4 >> k) & 1;
       K.sym(cx.zc[nb & 0x1EF], bit);
       if (bit) {
-        t1_code_sign(K, chiL, chiR, f, k, (int)((w >> (CW_NEG + k)) & 1));
+        t1_code_sign(K, c.chiL, c.chiR, f, k, (int)((w >> (CW_NEG + k)) & 1));
         f |= 1u << (3 * (k + 1) + 1);
         if (cx.want_dist) dist += t1_dist_sig(t1_mag(mag, k), p);
       }
@@ -136,9 +149,7 @@ T1HD void cm2_column(Sink& K, const Cm2Ctx& cx, int pass, const uint32_t u[3], c
   }
   // clean-up
   if (((sig04 | M4) & val4) == val4) return;  // every row was coded by one of the other passes
-  uint32_t s2[3];
-  for (int c = 0; c < 3; c++) s2[c] = cm2_six(u[c], m[c], d[c], CW_S2);
-  const uint32_t L6 = s0[0] | s1[0] | (s2[0] & 0x1F), C6 = s0[1] | s1[1] | (s2[1] & 1), R6 = s0[2] | s1[2] | (s2[2] & 1);
+  const uint32_t L6 = c.s0[0] | c.s1[0] | (c.s2[0] & 0x1F), C6 = c.s0[1] | c.s1[1] | (c.s2[1] & 1), R6 = c.s0[2] | c.s1[2] | (c.s2[2] & 1);
   uint32_t f = cx.sp[L6] | (cx.sp[C6] << 1) | (cx.sp[R6] << 2);
   int k = 0;
   if (rows == 4 && f == 0 && M4 == 0) {  // run-length mode (D.3.4)
@@ -147,13 +158,13 @@ T1HD void cm2_column(Sink& K, const Cm2Ctx& cx, int pass, const uint32_t u[3], c
     K.sym(T1_CTX_RUN, 1);
     K.sym(T1_CTX_UNI, fk >> 1);
     K.sym(T1_CTX_UNI, fk & 1);
-    f |= chiC;
-    t1_code_sign(K, chiL, chiR, f, fk, (int)((w >> (CW_NEG + fk)) & 1));
+    f |= c.chiC;
+    t1_code_sign(K, c.chiL, c.chiR, f, fk, (int)((w >> (CW_NEG + fk)) & 1));
     f |= 1u << (3 * (fk + 1) + 1);
     if (cx.want_dist) dist += t1_dist_sig(t1_mag(mag, fk), p);
     k = fk + 1;
   } else {
-    f |= chiC;
+    f |= c.chiC;
   }
   for (; k < rows; k++) {
     const int nb = (f >> (3 * k)) & 0x1FF;
@@ -161,11 +172,19 @@ T1HD void cm2_column(Sink& K, const Cm2Ctx& cx, int pass, const uint32_t u[3], c
     const int bit = (bit4 >> k) & 1;
     K.sym(cx.zc[nb & 0x1EF], bit);
     if (bit) {
-      t1_code_sign(K, chiL, chiR, f, k, (int)((w >> (CW_NEG + k)) & 1));
+      t1_code_sign(K, c.chiL, c.chiR, f, k, (int)((w >> (CW_NEG + k)) & 1));
       f |= 1u << (3 * (k + 1) + 1);
       if (cx.want_dist) dist += t1_dist_sig(t1_mag(mag, k), p);
     }
   }
+}
+template <class Sink>
+T1HD void cm2_column(Sink& K, const Cm2Ctx& cx, int pass, const uint32_t u[3], const uint32_t m[3], const uint32_t d[3],
+                     uint64_t mag, long long& dist) {
+  if (!((m[1] >> CW_VAL) & 0xF)) return;
+  Cm2Col c;
+  cm2_gather(c, u, m, d);
+  cm2_pass(K, cx, pass, c, mag, dist);
 }
 
 }  // namespace qsvc
