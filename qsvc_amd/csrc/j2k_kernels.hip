@@ -685,13 +685,10 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
     if (s >= nstr || x >= w) continue;
     Cm2Col c;
     cm2_gather(c, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x]);
-    long long dd = 0;
-    for (int pass = pass0; pass < 3; pass++) {
-      Cm2CountSink C;
-      C.n = 0;
-      cm2_pass(C, cx, pass, c, 0ull, dd);
-      n3[pass] += C.n;
-    }
+    int n[3];
+    cm2_counts(c, n);
+    if (!first) { n3[0] += n[0]; n3[1] += n[1]; }
+    n3[2] += n[2];
   }
   int off3[3], tot3[3];
   for (int pass = 0; pass < 3; pass++) {

@@ -178,6 +178,31 @@ T1HD void cm2_pass(Sink& K, const Cm2Ctx& cx, int pass, const Cm2Col& c, uint64_
     }
   }
 }
+// The number of decisions cm2_pass emits for the column in each pass, from the masks alone (every member of a pass costs one
+// decision, every sample that becomes significant one more for its sign; a run-length column 1, or 3 + the sign).
+T1HD int cm2_popc4(uint32_t v) { v &= 0xF; v = (v & 5) + ((v >> 1) & 5); return (int)((v & 3) + (v >> 2)); }
+T1HD void cm2_counts(const Cm2Col& c, int n[3]) {
+  const uint32_t w = c.w;
+  const uint32_t val4 = (w >> CW_VAL) & 0xF;
+  n[0] = n[1] = n[2] = 0;
+  if (!val4) return;
+  const uint32_t bit4 = (w >> CW_BIT) & 0xF, M4 = (w >> CW_M) & 0xF, sig04 = (w >> CW_SIG0) & 0xF;
+  const uint32_t S14 = (w >> CW_S1) & 0xF, S24 = (w >> CW_S2) & 0xF;
+  n[0] = cm2_popc4(M4) + cm2_popc4(S14);
+  n[1] = cm2_popc4(sig04 & val4);
+  const uint32_t C4 = val4 & ~sig04 & ~M4;
+  if (!C4) return;
+  const uint32_t any = c.s0[0] | c.s1[0] | (c.s2[0] & 0x1F) | c.s0[1] | c.s1[1] | (c.s2[1] & 1) | c.s0[2] | c.s1[2] | (c.s2[2] & 1);
+  if (val4 == 0xF && any == 0 && M4 == 0) {
+    if (!bit4) { n[2] = 1; return; }
+    const int fk = (bit4 & 1) ? 0 : ((bit4 & 2) ? 1 : ((bit4 & 4) ? 2 : 3));
+    const uint32_t rest = 0xFu & ~((2u << fk) - 1);  // rows below fk
+    n[2] = 4 + cm2_popc4(C4 & rest) + cm2_popc4(S24 & rest);
+    return;
+  }
+  n[2] = cm2_popc4(C4) + cm2_popc4(S24);
+}
+
 template <class Sink>
 T1HD void cm2_column(Sink& K, const Cm2Ctx& cx, int pass, const uint32_t u[3], const uint32_t m[3], const uint32_t d[3],
                      uint64_t mag, long long& dist) {

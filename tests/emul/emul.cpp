@@ -330,6 +330,16 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
           cm2_column(C, cx, pass, &cw[s][x], &cw[s + 1][x], &cw[s + 2][x], mags[s * 64 + x], dd);
         }
         counts[th] = C.n;
+        int nf = 0;  // the mask-only count must agree with the emission
+        for (int i = th * 16; i < th * 16 + 16; i++) {
+          int s = i >> 6, x = i & 63;
+          if (s >= nstr || x >= w) continue;
+          Cm2Col col; int n3[3];
+          cm2_gather(col, &cw[s][x], &cw[s + 1][x], &cw[s + 2][x]);
+          cm2_counts(col, n3);
+          nf += n3[pass];
+        }
+        if (nf != C.n) return -4;
       }
       offs[0] = 0;
       for (int th = 0; th < 64; th++) offs[th + 1] = offs[th] + counts[th];
