@@ -624,6 +624,7 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   __shared__ uint8_t s_zcq[CM2_JOBS][512];
   __shared__ __attribute__((aligned(16))) uint8_t s_outq[CM2_JOBS][CM2_OUT_BYTES];
   __shared__ int s_geo[CM2_JOBS][2];
+  __shared__ uint64_t s_rowM[CM2_JOBS][64];
   const int jq = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int job = blockIdx.x * CM2_JOBS + jq;
   const bool live = job < njobs;
@@ -647,29 +648,58 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   }
   for (int i = lane; i < 18 * 66; i += 64) (&s_cw[0][0])[i] = 0;
   __syncthreads();
-  for (int s = 0; s < nstr; s++) {
-    const int rows = h - 4 * s > 4 ? 4 : h - 4 * s;
-    if (lane < w) s_cw[s + 1][lane + 1] = cm2_colword(mg[s * 64 + lane], p, rows, true);
+  // column words (lane = column x); at the same time the rows' sig0 / bit masks are collected by ballots: afterwards lane y
+  // holds row y (bit x = column x)
+  uint64_t Zr = 0, Br = 0;
+  uint32_t cwreg[16];
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    uint32_t c = 0;
+    if (s < nstr) {  // uniform
+      const int rows = h - 4 * s > 4 ? 4 : h - 4 * s;
+      if (lane < w) c = cm2_colword(mg[s * 64 + lane], p, rows, true);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint64_t zb = __ballot((c >> (CW_SIG0 + k)) & 1), bb = __ballot((c >> (CW_BIT + k)) & 1);
+        if (lane == 4 * s + k) { Zr = zb; Br = bb; }
+      }
+    }
+    cwreg[s] = c;
+  }
+  // membership: fixpoint of cm2_row_update over the 64 rows (t1_cm2.h)
+  {
+    const uint64_t wmask = w == 64 ? ~0ull : ((1ull << w) - 1);
+    const uint64_t cand = (lane < h ? wmask : 0ull) & ~Zr;
+    auto up = [&](uint64_t v) {  // the value of lane - 1 (0 for lane 0)
+      uint32_t lo = __shfl_up((uint32_t)v, 1, 64), hi = __shfl_up((uint32_t)(v >> 32), 1, 64);
+      return lane ? ((uint64_t)lo | ((uint64_t)hi << 32)) : 0ull;
+    };
+    auto dn = [&](uint64_t v) {  // the value of lane + 1 (0 for lane 63)
+      uint32_t lo = __shfl_down((uint32_t)v, 1, 64), hi = __shfl_down((uint32_t)(v >> 32), 1, 64);
+      return lane < 63 ? ((uint64_t)lo | ((uint64_t)hi << 32)) : 0ull;
+    };
+    const uint64_t seed = cm2_row_seed(Zr, up(Zr), dn(Zr));
+    uint64_t M = 0;
+    for (;;) {
+      const uint64_t S1 = M & Br;
+      const uint64_t Mn = cm2_row_update(cand, Br, seed, up(S1), dn(S1), lane & 3);
+      const bool changed = Mn != M;
+      M = Mn;
+      if (!__any(changed)) break;
+    }
+    s_rowM[jq][lane] = M;
   }
   __syncthreads();
-  // membership of all CM2_JOBS jobs on wave 0: lane = (job, stripe), each stripe two columns behind the one above.  One
-  // wave: the lanes' loads of a step all issue before its stores, and LDS executes a wave's operations in order, so the
-  // steps need no barrier.
-  if (jq == 0) {
-    const int mj0 = lane >> 4, ms = lane & 15;
-    const bool mlive = mj0 < CM2_JOBS;
-    const int mj = mlive ? mj0 : 0;
-    const int mw = mlive ? s_geo[mj][0] : 0, mn = mlive ? s_geo[mj][1] : 0;
-    uint32_t (*cwm)[66] = s_cwq[mj];
-    int steps = mn ? mw + 2 * (mn - 1) : 0;
-    for (int o = 32; o >= 1; o >>= 1) { int v = __shfl_xor(steps, o, 64); steps = v > steps ? v : steps; }
-    for (int t = 0; t < steps; t++) {
-      const int x = t - 2 * ms;
-      if (ms < mn && x >= 0 && x < mw) {
-        const uint32_t res = cm2_member(&cwm[ms][x], &cwm[ms + 1][x], &cwm[ms + 2][x]);
-        cwm[ms + 1][x + 1] |= res;
-      }
-      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    if (s < nstr && lane < w) {
+      const uint32_t c = cwreg[s];
+      uint32_t M4 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) M4 |= (uint32_t)((s_rowM[jq][4 * s + k] >> lane) & 1) << k;
+      const uint32_t S1 = M4 & (c >> CW_BIT) & 0xF;
+      const uint32_t S2 = (c >> CW_VAL) & ~(c >> CW_SIG0) & ~M4 & (c >> CW_BIT) & 0xF;
+      s_cw[s + 1][lane + 1] = c | (M4 << CW_M) | (S1 << CW_S1) | (S2 << CW_S2);
     }
   }
   __syncthreads();

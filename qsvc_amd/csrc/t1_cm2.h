@@ -71,6 +71,27 @@ T1HD uint32_t cm2_member(const uint32_t u[3], const uint32_t m[3], const uint32_
   return (M << CW_M) | (S1 << CW_S1) | (S2 << CW_S2);
 }
 
+// The same membership as a fixpoint over ROW masks (bit x of row y; 64 rows = the 64 lanes of the wave).  With
+// S1 = M & bit the recurrence of cm2_member reads, for row y = 4s + k,
+//   M[y] = cand[y] & ( seedZ[y]                                       neighbours significant before the plane
+//                    | S1[y] << 1                                      (y, x-1): a carry chain along the row
+//                    | S1[y-1] << 1 | S1[y-1] | (k == 0 ? S1[y-1] >> 1 : 0)   row above: x-1, x always earlier in the scan,
+//                                                                      x+1 only when it lies in the stripe above
+//                    | (k < 3 ? S1[y+1] << 1 : 0) )                    (y+1, x-1) of the same stripe
+// The chain along the row is an adder's carry chain (generate = g & bit, propagate = cand & bit), resolved by one 64-bit
+// addition; the coupling between rows converges by iteration from M = 0 (monotone, least fixpoint = the scan-order result).
+T1HD uint64_t cm2_row_update(uint64_t cand, uint64_t bt, uint64_t seedZ, uint64_t s1_up, uint64_t s1_dn, int k) {
+  const uint64_t prop = (s1_up << 1) | s1_up | (k == 0 ? (s1_up >> 1) : 0) | (k < 3 ? (s1_dn << 1) : 0);
+  const uint64_t g = cand & (seedZ | prop);
+  const uint64_t gp = g & bt, pp = cand & bt;
+  const uint64_t A = gp | pp, B = gp;
+  const uint64_t cin = (A + B) ^ A ^ B;  // carry INTO each bit = S1 of the sample to the left
+  return g | (cand & cin);
+}
+T1HD uint64_t cm2_row_seed(uint64_t z, uint64_t z_up, uint64_t z_dn) {
+  return (z << 1) | (z >> 1) | (z_up << 1) | z_up | (z_up >> 1) | (z_dn << 1) | z_dn | (z_dn >> 1);
+}
+
 struct Cm2Ctx {
   const uint8_t* zc;     // [512] zero-coding LUT of the block's orientation class
   const uint32_t* sp;    // [64] CM2_SPREAD_INIT

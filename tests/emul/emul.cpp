@@ -306,14 +306,36 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
     memset(cw, 0, sizeof cw);
     for (int s = 0; s < nstr; s++)
       for (int x = 0; x < w; x++) cw[s + 1][x + 1] = cm2_colword(mags[s * 64 + x], p, h - 4 * s > 4 ? 4 : h - 4 * s, true);
-    for (int t = 0; t < w + 2 * (nstr - 1); t++) {       // membership: stripe lane s works on column t - 2s
-      uint32_t res[16]; bool on[16];
-      for (int s = 0; s < nstr; s++) {
-        int x = t - 2 * s;
-        on[s] = x >= 0 && x < w;
-        if (on[s]) res[s] = cm2_member(&cw[s][x], &cw[s + 1][x], &cw[s + 2][x]);
+    {  // membership as the kernel computes it: row masks, fixpoint of cm2_row_update over the 64 "lanes"
+      uint64_t Z[66] = {0}, Bt[66] = {0}, cand[66] = {0}, M[66] = {0}, seed[66] = {0};
+      const uint64_t wmask = w == 64 ? ~0ull : ((1ull << w) - 1);
+      for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+          uint32_t c = cw[(y >> 2) + 1][x + 1];
+          Z[y + 1] |= (uint64_t)((c >> (CW_SIG0 + (y & 3))) & 1) << x;
+          Bt[y + 1] |= (uint64_t)((c >> (CW_BIT + (y & 3))) & 1) << x;
+        }
+      for (int y = 0; y < 64; y++) { cand[y + 1] = (y < h ? wmask : 0) & ~Z[y + 1]; seed[y + 1] = cm2_row_seed(Z[y + 1], Z[y], Z[y + 2]); }
+      for (bool changed = true; changed;) {
+        uint64_t Mn[66] = {0};
+        changed = false;
+        for (int y = 0; y < 64; y++) {
+          Mn[y + 1] = cm2_row_update(cand[y + 1], Bt[y + 1], seed[y + 1], y ? (M[y] & Bt[y]) : 0, y < 63 ? (M[y + 2] & Bt[y + 2]) : 0, y & 3);
+          changed |= Mn[y + 1] != M[y + 1];
+        }
+        memcpy(M, Mn, sizeof M);
       }
-      for (int s = 0; s < nstr; s++) if (on[s]) cw[s + 1][t - 2 * s + 1] |= res[s];  // all lanes store after all computed
+      for (int s = 0; s < nstr; s++)
+        for (int x = 0; x < w; x++) {
+          uint32_t c = cw[s + 1][x + 1], M4 = 0;
+          for (int k = 0; k < 4; k++) M4 |= (uint32_t)((M[4 * s + k + 1] >> x) & 1) << k;
+          const uint32_t S1 = M4 & (c >> CW_BIT) & 0xF;
+          const uint32_t S2 = (c >> CW_VAL) & ~(c >> CW_SIG0) & ~M4 & (c >> CW_BIT) & 0xF;
+          // cross-check with the scan-order recurrence of cm2_member, evaluated in place in scan order
+          uint32_t ref = cm2_member(&cw[s][x], &cw[s + 1][x], &cw[s + 2][x]);
+          if (ref != ((M4 << CW_M) | (S1 << CW_S1) | (S2 << CW_S2))) return -5;
+          cw[s + 1][x + 1] = c | ref;
+        }
     }
     Cm2Ctx cx{zclut + 512 * (orient == 1 ? 1 : (orient == 3 ? 2 : 0)), sp, p, true};
     const bool active = true, first = p == nb - 1;
