@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 W, H, TRLS, GOPS, BS, S0, SRLS = 1920, 1080, 4, 2, 8, 4, 5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = "r01_v3_pmc_hbm.json"
+PMC_FILE = "r01_v4_pmc_hbm.json"
 
 
 def log(*a):
@@ -203,6 +203,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # MQ lanes per wave (read by the library at every launch): 64 when several encodes share the GPU (fewest issue slots per
+    # decision), 16 for one sequence alone (shortest chain).  A caller's own QSVC_MQ_LANES wins.
+    user_lanes = os.environ.get("QSVC_MQ_LANES")
+    if user_lanes is None:
+        os.environ["QSVC_MQ_LANES"] = "64" if S > 1 else "16"
     run_steps(args.warmup)
     for e in engs:
         e.set_profiling(True)
@@ -223,6 +228,10 @@ def main():
         e.set_profiling(False)
     serial_ms = None
     if world == 1:  # latency of ONE sequence alone on the chip (informational)
+        if user_lanes is None:
+            os.environ["QSVC_MQ_LANES"] = "16"
+        step(0)
+        engs[0].sync()
         t1 = time.perf_counter()
         for _ in range(2):
             step(0)
@@ -266,7 +275,7 @@ def main():
             traffic = None
             try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-                kname = {"j2k_t1_mq": "k_t1_mq<16>", "j2k_t1_cm": "k_t1_cm<64>", "j2k_t1_encode": "k_t1_encode<8>"}.get(dom)
+                kname = {"j2k_t1_mq": "k_t1_mq<%s>" % (user_lanes or ("64" if S > 1 else "16")), "j2k_t1_cm": "k_t1_cm2", "j2k_t1_encode": "k_t1_encode<8>"}.get(dom)
                 if kname in pmc:
                     traffic = pmc[kname]["hbm_bytes_per_launch_raw"]
             except Exception:

@@ -548,7 +548,9 @@ void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc*
     else if (cl == 32) hipLaunchKernelGGL(k_t1_cm<32>, dim3(nwaves, 2), dim3(32), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
     else hipLaunchKernelGGL(k_t1_cm<64>, dim3(nwaves, 1), dim3(64), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
   } else {
-    static const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 16; return (v == 4 || v == 8 || v == 32 || v == 64) ? v : 16; }();
+    // lanes (code-blocks) per MQ wave: 16 gives the shortest chain for one sequence alone, 64 the best throughput when several
+    // encodes share the GPU (fewer issue slots per decision).  Read at every launch so a host can switch between the two.
+    const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 16; return (v == 4 || v == 8 || v == 32 || v == 64) ? v : 16; }();
     long long* pdp = want_dist ? pass_dist : nullptr;
 #define MQ_LAUNCH(N) hipLaunchKernelGGL(k_t1_mq<N>, dim3((nslots + N - 1) / N), dim3(N), 0, st, cbs, ncb, nbps, joboff, order, nslots, segs, cnt, dist, outbuf, outcap, res, pass_len, pdp)
     switch (ml) { case 4: MQ_LAUNCH(4); break; case 8: MQ_LAUNCH(8); break; case 32: MQ_LAUNCH(32); break; case 64: MQ_LAUNCH(64); break; default: MQ_LAUNCH(16); }
