@@ -310,7 +310,7 @@ struct PlaneSrc { const uint8_t* src; int stride, W, H; const qsvc_j2k_params* p
 
 // Encode a batch of device-resident planes.  All planes share the transform/quantiser/code-block parameters
 // of src[0].prm; the number of layers and the slopes may differ per plane (they only steer the host's PCRD).
-static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8_t* out, size_t cap, size_t* offs) {
+static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8_t* out, size_t cap, size_t* offs) {
   if (!c->j2k) c->j2k = new J2kState();
   J2kState& S = *c->j2k;
   const qsvc_j2k_params* prm = src[0].prm;
@@ -604,6 +604,38 @@ static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint
     copier(0);
     for (auto& t : th) t.join();
   }
+  return QSVC_OK;
+}
+
+
+// Bounds the Tier-1 working set.  The decision slots are sized for the worst case (22.5 KB per code-block and bit-plane, up to
+// 15 planes): a long or large sequence is coded in consecutive groups of planes whose slots fit QSVC_T1_BUDGET_GB (default 32).
+// The code-streams do not depend on the grouping (planes are independent).
+static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8_t* out, size_t cap, size_t* offs) {
+  static const double budget_gb = [] { const char* e = getenv("QSVC_T1_BUDGET_GB"); double v = e ? atof(e) : 32.0; return v > 0.001 ? v : 0.001; }();
+  const size_t max_blocks = (size_t)(budget_gb * 1e9 / (15.0 * T1_SEG_BYTES));
+  const qsvc_j2k_params* prm = src[0].prm;
+  const int cbw = prm->cblk_w ? prm->cblk_w : 64, cbh = prm->cblk_h ? prm->cblk_h : 64;
+  auto est = [&](const PlaneSrc& p) {  // blocks of all subbands, a little over W*H / (cbw*cbh)
+    return ((size_t)(p.W + cbw - 1) / cbw + 2) * ((size_t)(p.H + cbh - 1) / cbh + 2) + 4 * (size_t)(prm->levels + 1);
+  };
+  size_t total = 0;
+  for (auto& p : src) total += est(p);
+  if (total <= max_blocks) return j2k_encode_chunk(c, src, out, cap, offs);
+  size_t pos = 0, first = 0;
+  std::vector<size_t> sub;
+  while (first < src.size()) {
+    size_t n = 0, blocks = 0;
+    while (first + n < src.size() && (n == 0 || blocks + est(src[first + n]) <= max_blocks)) { blocks += est(src[first + n]); n++; }
+    std::vector<PlaneSrc> part(src.begin() + first, src.begin() + first + n);
+    sub.assign(n + 1, 0);
+    int r = j2k_encode_chunk(c, part, out + pos, cap - pos, sub.data());
+    if (r) return r;
+    for (size_t k = 0; k < n; k++) offs[first + k] = pos + sub[k];
+    pos += sub[n];
+    first += n;
+  }
+  offs[src.size()] = pos;
   return QSVC_OK;
 }
 

@@ -144,3 +144,22 @@ def test_all_zero_planes_have_empty_packets(eng):
     cs = eng.j2k_encode_plane(pl, hip.j2k_params(reversible=True, levels=2))
     assert cs == J.encode_plane(pl, reversible=True, levels=2)
     np.testing.assert_array_equal(J.decode(cs), pl)
+
+
+def test_plane_groups_do_not_change_the_streams(eng):
+    """QSVC_T1_BUDGET_GB bounds the Tier-1 working set by coding the planes in groups; the streams are the same bytes."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from qsvc_amd import hip\nfrom qsvc_amd.synth import make_clip\n"
+            "e = hip.Engine(0); W, H = 256, 192\n"
+            "clip = make_clip('pan_noise', 5, W, H, 9); e.seq_config(W, H); e.put_frames(hip.LOW, 0, clip)\n"
+            "out = e.j2k_encode_frames(hip.LOW, 0, 0, 5, hip.j2k_params(reversible=True, levels=3))\n"
+            "print(len(out), hashlib.sha256(b''.join(out)).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for gb in ("32", "0.01"):  # 0.01 GB -> 29 blocks per group: every plane of this size becomes its own group
+        env = dict(os.environ, QSVC_T1_BUDGET_GB=gb)
+        runs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True))
+        assert runs[-1].returncode == 0, runs[-1].stderr[-800:]
+    assert runs[0].stdout == runs[1].stdout and runs[0].stdout.startswith("15 ")
