@@ -76,21 +76,6 @@ QHD int s53_sample(const LoF& Lo, const HiF& Hi, int k, int n) {
 // from texture::alloc (texture.cpp:34-113).  Returns the interior coordinate whose pixel-domain
 // value the cell (y,x) holds.  Q2: the lower-left corner holds the bottom-RIGHT pixel.  Q1: on row
 // r = H-b the cells x < -safe alias the right border of row r-1 and read back pixel (r-1, W-1).
-// Division by the block size without the (software) integer divide: n / bs == mulhi(n, rcp) with rcp = floor(2^32 / bs) + 1,
-// exact for 0 <= n and n * bs < 2^32 (pictures and block sizes here: n < 2^16, bs <= 256).  rcp comes from the host
-// (bdiv_rcp) because computing it costs the very division it replaces.
-struct BDiv {
-  int bs;
-  uint32_t rcp;
-};
-QHD uint32_t bdiv_rcp(int bs) { return (uint32_t)(0x100000000ull / (uint32_t)bs) + 1u; }
-QHD int bdiv(const BDiv& d, int n) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return (int)__umulhi((uint32_t)n, d.rcp);
-#else
-  return (int)(((uint64_t)(uint32_t)n * d.rcp) >> 32);
-#endif
-}
 struct BorderGeom {
   int H, W, b, safe;
 };
@@ -166,12 +151,12 @@ struct MvField {
 //   comp 0: luma planes; comp 1,2: chroma planes interpolated on the fly.
 // (y,x) must lie inside BY*bs x BX*bs.  The clip to 0..255 (decorrelate.cpp:841-848) is a no-op:
 // both operands are in 0..255.
-QHD int predict_luma(const uint8_t* r0, const uint8_t* r1, const BorderGeom& g, const MvField& mv, const BDiv& bd, int y, int x) {
-  int by = bdiv(bd, y), bx = bdiv(bd, x);
+QHD int predict_luma(const uint8_t* r0, const uint8_t* r1, const BorderGeom& g, const MvField& mv, int bs, int y, int x) {
+  int by = y / bs, bx = x / bs;
   return (luma_b(r0, g, y + mv.py(by, bx), x + mv.px(by, bx)) + luma_b(r1, g, y + mv.ny(by, bx), x + mv.nx(by, bx))) >> 1;
 }
-QHD int predict_chroma_full(const uint8_t* u0, const uint8_t* u1, const BorderGeom& g, const MvField& mv, const BDiv& bd, int y, int x) {
-  int by = bdiv(bd, y), bx = bdiv(bd, x);
+QHD int predict_chroma_full(const uint8_t* u0, const uint8_t* u1, const BorderGeom& g, const MvField& mv, int bs, int y, int x) {
+  int by = y / bs, bx = x / bs;
   return (chroma_up_b(u0, g, y + mv.py(by, bx), x + mv.px(by, bx)) + chroma_up_b(u1, g, y + mv.ny(by, bx), x + mv.nx(by, bx))) >> 1;
 }
 // Q7 -- pictures the block grid does not tile.  predict() writes only rows < BY*bs and columns < BX*bs of its three
@@ -256,18 +241,16 @@ struct MePlane {
 #define QSVC_ME_CANDS {{-1, -1}, {-1, 1}, {1, -1}, {1, 1}, {-1, 0}, {1, 0}, {0, 1}, {0, -1}, {0, 0}}
 // Partial SADs of one block over the pixels idx = lane, lane+nlanes, ...   sad[2*c+d], d: 0 PREV 1 NEXT.
 template <class T>
-QHD void me_block_sads(const MePlane<T>& r0, const MePlane<T>& r1, const MePlane<T>& pr, const BDiv& bd, int by, int bx, int pvy,
+QHD void me_block_sads(const MePlane<T>& r0, const MePlane<T>& r1, const MePlane<T>& pr, int bs, int by, int bx, int pvy,
                        int pvx, int nvy, int nvx, int lane, int nlanes, int* sad) {
   const int cand[9][2] = QSVC_ME_CANDS;
-  const int bs = bd.bs;
   for (int k = 0; k < 18; k++) sad[k] = 0;
   int y0 = by * bs, x0 = bx * bs;
   // whole 3x3 neighbourhood of both displaced blocks interior -> unchecked reads
   bool inner = y0 + pvy - 1 >= 0 && y0 + pvy + bs + 1 <= r0.g.H && x0 + pvx - 1 >= 0 && x0 + pvx + bs + 1 <= r0.g.W &&
                y0 + nvy - 1 >= 0 && y0 + nvy + bs + 1 <= r0.g.H && x0 + nvx - 1 >= 0 && x0 + nvx + bs + 1 <= r0.g.W;
   for (int idx = lane; idx < bs * bs; idx += nlanes) {
-    const int iq = bdiv(bd, idx);
-    int py = y0 + iq, px = x0 + idx - iq * bs;
+    int py = y0 + idx / bs, px = x0 + idx % bs;
     int pv = pr.in(py, px);
     if (inner) {
       for (int c = 0; c < 9; c++) {
@@ -320,17 +303,15 @@ QHD int upd_one(int v, int r, float uf) {
   return (int)aux;
 }
 template <class Res>
-QHD int update_gather(int v, const Res& R, const int16_t* mvx, const int16_t* mvy, int BY, int BX, const BDiv& bd, int H, int W,
+QHD int update_gather(int v, const Res& R, const int16_t* mvx, const int16_t* mvy, int BY, int BX, int bs, int H, int W,
                       int Hs, int Ws, int reach, int ty, int tx, float uf) {
-  const int bs = bd.bs;
   int sy_lo = ty == 0 ? 0 : ty - reach, sy_hi = ty == H - 1 ? H - 1 : ty + reach;
   int sx_lo = tx == 0 ? 0 : tx - reach, sx_hi = tx == W - 1 ? W - 1 : tx + reach;
   sy_lo = imax(sy_lo, 0); sx_lo = imax(sx_lo, 0);
   sy_hi = imin(sy_hi, imin(Hs, BY * bs) - 1); sx_hi = imin(sx_hi, imin(Ws, BX * bs) - 1);
   if (sy_hi < sy_lo || sx_hi < sx_lo) return v;
-  const int by_hi = bdiv(bd, sy_hi), bx_lo = bdiv(bd, sx_lo), bx_hi = bdiv(bd, sx_hi);
-  for (int by = bdiv(bd, sy_lo); by <= by_hi; by++)
-    for (int bx = bx_lo; bx <= bx_hi; bx++) {
+  for (int by = sy_lo / bs; by <= sy_hi / bs; by++)
+    for (int bx = sx_lo / bs; bx <= sx_hi / bs; bx++) {
       int dy = mvy[(size_t)by * BX + bx], dx = mvx[(size_t)by * BX + bx];
       int y0 = by * bs, y1 = imin(y0 + bs, Hs) - 1, x0 = bx * bs, x1 = imin(x0 + bs, Ws) - 1;
       int a, b, c, d;  // source rows [a,b], cols [c,d] of this block that land on the target

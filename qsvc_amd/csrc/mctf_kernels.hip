@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(64) k_me_search(MeArgs a) {
   int sad[18];
   if (live) {
     me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
-    me_block_sads<T>(r0, r1, pr, BDiv{a.g.bs, a.g.bs_rcp}, by, bx, pvy, pvx, nvy, nvx, lane, LPB, sad);
+    me_block_sads<T>(r0, r1, pr, a.g.bs, by, bx, pvy, pvx, nvy, nvx, lane, LPB, sad);
   } else {
 #pragma unroll
     for (int k = 0; k < 18; k++) sad[k] = 0;
@@ -93,8 +93,7 @@ __global__ void __launch_bounds__(256) k_pred_luma8(PredArgs a) {
     const uint8_t* r0 = frame_y(a.frames, g, 2 * i);
     const uint8_t* r1 = frame_y(a.frames, g, 2 * i + 2);
     const uint8_t* od = frame_y(a.frames, g, 2 * i + 1) + (size_t)y * g.W + x;
-    const BDiv bd{g.bs, g.bs_rcp};
-    const int by = bdiv(bd, y), bx = bdiv(bd, x);
+    const int by = y / g.bs, bx = x / g.bs;
     const size_t fld = (size_t)g.BY * g.BX;
     const bool predicted = by < g.BY && bx < g.BX;  // Q7: the margin of the luma prediction plane stays zero
     const int16_t* m = a.mv + (size_t)i * 4 * fld + (predicted ? (size_t)by * g.BX + bx : 0);
@@ -301,7 +300,7 @@ __global__ void __launch_bounds__(256) k_upd_chroma(UpdArgs a) {
         if (s[q].high) {
           const uint8_t* h = s[q].high + coff;
           auto R = [&](int sy, int sx) { return (int)h[(size_t)sy * cw + sx] - 128; };
-          v = update_gather(v, R, s[q].mvx, s[q].mvy, g.BY, g.BX, BDiv{g.bs, g.bs_rcp}, g.H, g.W, chh, cw, a.reach, yy, xx, a.uf);
+          v = update_gather(v, R, s[q].mvx, s[q].mvy, g.BY, g.BX, g.bs, g.H, g.W, chh, cw, a.reach, yy, xx, a.uf);
         }
     }
     sP[k / PC_FW][k % PC_FW] = (int16_t)v;

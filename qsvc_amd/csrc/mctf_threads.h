@@ -12,11 +12,9 @@
 
 namespace qsvc {
 
-
 struct LevelGeom {
   int W, H;      // luma size (both even)
   int bs;        // block size
-  uint32_t bs_rcp;  // bdiv_rcp(bs), set by the host
   int BY, BX;    // H/bs, W/bs (H % bs == 0 and W % bs == 0 on this path)
   int S;         // search range of this temporal level
   int P;         // pictures in low_{t-1}
@@ -116,7 +114,7 @@ QHD void pred_luma_thread(const PredArgs& a, int x, int y, int i, int& odd_bin, 
   MvField mv = {a.mv + (size_t)i * 4 * g.BY * g.BX, g.BY, g.BX};
   int p = 0;  // Q7: the unpredicted margin of the luma plane stays zero
   if (y < g.BY * g.bs && x < g.BX * g.bs)
-    p = predict_luma(frame_y(a.frames, g, 2 * i), frame_y(a.frames, g, 2 * i + 2), bg, mv, BDiv{g.bs, g.bs_rcp}, y, x);
+    p = predict_luma(frame_y(a.frames, g, 2 * i), frame_y(a.frames, g, 2 * i + 2), bg, mv, g.bs, y, x);
   size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
   if (a.odd_out) {
     a.odd_out[(size_t)(2 * i + 1) * g.F + (size_t)y * g.W + x] = (uint8_t)correlate_sample(a.high[off], p, a.types[i]);
@@ -133,9 +131,9 @@ QHD void pred_luma_thread(const PredArgs& a, int x, int y, int i, int& odd_bin, 
 // one sample of picture i's full-resolution chroma prediction plane as the chroma/2 analysis sees it (after the clip)
 QHD int pred_chroma_sample(const PredArgs& a, const uint8_t* u0, const uint8_t* u1, const BorderGeom& bg, const MvField& mv,
                            int i, int c, int yy, int xx) {
-  if (!a.margin) return predict_chroma_full(u0, u1, bg, mv, BDiv{a.g.bs, a.g.bs_rcp}, yy, xx);
+  if (!a.margin) return predict_chroma_full(u0, u1, bg, mv, a.g.bs, yy, xx);
   MarginGeom mg = margin_geom(a.g);
-  if (mg.inside(yy, xx)) return predict_chroma_full(u0, u1, bg, mv, BDiv{a.g.bs, a.g.bs_rcp}, yy, xx);
+  if (mg.inside(yy, xx)) return predict_chroma_full(u0, u1, bg, mv, a.g.bs, yy, xx);
   if (i == 0) return 0;  // fresh planes
   return iclamp(a.margin[((size_t)(i - 1) * 2 + (c - 1)) * mg.count() + mg.index(yy, xx)], 0, 255);
 }
@@ -231,7 +229,7 @@ QHD void upd_luma_thread(const UpdArgs& a, int x, int y, int j) {
     if (s[k].high) {
       const uint8_t* h = s[k].high;
       auto R = [&](int sy, int sx) { return (int)h[(size_t)sy * g.W + sx] - 128; };  // update.cpp:512-520
-      v = update_gather(v, R, s[k].mvx, s[k].mvy, g.BY, g.BX, BDiv{g.bs, g.bs_rcp}, g.H, g.W, g.H, g.W, a.reach, y, x, a.uf);
+      v = update_gather(v, R, s[k].mvx, s[k].mvy, g.BY, g.BX, g.bs, g.H, g.W, g.H, g.W, a.reach, y, x, a.uf);
     }
   a.low[(size_t)(a.dst_mul * j) * g.F + (size_t)y * g.W + x] = (uint8_t)v;
 }
@@ -254,7 +252,7 @@ QHD void upd_chroma_thread(const UpdArgs& a, int ci, int cj, int j, int c /*1|2*
       if (s[k].high) {
         const uint8_t* h = s[k].high + coff;
         auto R = [&](int sy, int sx) { return (int)h[(size_t)sy * cw + sx] - 128; };
-        v = update_gather(v, R, s[k].mvx, s[k].mvy, g.BY, g.BX, BDiv{g.bs, g.bs_rcp}, g.H, g.W, chh, cw, a.reach, yy, xx, a.uf);
+        v = update_gather(v, R, s[k].mvx, s[k].mvy, g.BY, g.BX, g.bs, g.H, g.W, chh, cw, a.reach, yy, xx, a.uf);
       }
     return v;
   };

@@ -222,7 +222,7 @@ static int level_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g) {
   // rows/cols beyond BY*bs are never predicted by the reference (decorrelate.cpp:508-509,562-567; trunk/readme.txt:119-125):
   // Q7, reproduced by the margin state of PredArgs (mctf_threads.h)
   if (c->H < bs || c->W < bs) return c->fail(QSVC_ERR_INVALID, "picture %dx%d smaller than block_size %d", c->W, c->H, bs);
-  g->W = c->W; g->H = c->H; g->bs = bs; g->bs_rcp = bdiv_rcp(bs); g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
+  g->W = c->W; g->H = c->H; g->bs = bs; g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
   return QSVC_OK;
 }
 
@@ -403,7 +403,7 @@ static int synth_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g, bo
   if (bs < 2 || bs > 256) return c->fail(QSVC_ERR_INVALID, "block_size %d", bs);
   if (P < 1) return c->fail(QSVC_ERR_INVALID, "pictures %d", P);
   if (c->H < bs || c->W < bs) return c->fail(QSVC_ERR_INVALID, "picture %dx%d smaller than block_size %d", c->W, c->H, bs);
-  g->W = c->W; g->H = c->H; g->bs = bs; g->bs_rcp = bdiv_rcp(bs); g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
+  g->W = c->W; g->H = c->H; g->bs = bs; g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
   Level& lv = c->lv[t];
   if (need_low && lv.low_n < g->nB + 1) return c->fail(QSVC_ERR_STATE, "low_%d holds %d pictures, %d needed", t, lv.low_n, g->nB + 1);
   if (lv.high_n < g->nB || lv.mv_filt_n < g->nB || (int)lv.types.size() < g->nB || (g->nB && lv.mv_bs != bs))

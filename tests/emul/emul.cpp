@@ -13,7 +13,7 @@ using namespace qsvc;
 
 static LevelGeom make_geom(int P, int W, int H, int bs, int S) {
   LevelGeom g;
-  g.W = W; g.H = H; g.bs = bs; g.bs_rcp = bdiv_rcp(bs); g.BY = H / bs; g.BX = W / bs; g.S = S; g.P = P; g.nB = P / 2;
+  g.W = W; g.H = H; g.bs = bs; g.BY = H / bs; g.BX = W / bs; g.S = S; g.P = P; g.nB = P / 2;
   g.F = (size_t)W * H + 2 * (size_t)(W / 2) * (H / 2);
   return g;
 }
@@ -73,8 +73,8 @@ int emul_motion_estimate(const uint8_t* low, int P, int W, int H, int bs, int S,
           int pvx, pvy, nvx, nvy, sad[18], tot[18] = {0};
           me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
           for (int lane = 0; lane < 64; lane++) {  // 64 lanes, summed like the wave reduction
-            if (l == 0) { MePlane<uint8_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, BDiv{bs, bdiv_rcp(bs)}, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
-            else { MePlane<int16_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, BDiv{bs, bdiv_rcp(bs)}, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
+            if (l == 0) { MePlane<uint8_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
+            else { MePlane<int16_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
             for (int k = 0; k < 18; k++) tot[k] += sad[k];
           }
           me_block_store(a, i, by, bx, tot, pvx, pvy, nvx, nvy);
