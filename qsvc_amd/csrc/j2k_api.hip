@@ -517,7 +517,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   std::vector<unsigned long long> goffs(ncb);
   std::vector<int> glens(ncb);
   size_t gtotal = 0;
-  S.st_cb = ncb; S.st_pass = 0; S.st_sym = 0;
+  S.st_cb += ncb;  // the statistics cover every plane group of the call (reset by j2k_encode_planes)
   for (int p = 0; p < np; p++) {
     const PlanePlan& pl = plans[plan_of[p]];
     const qsvc_j2k_params* pprm = src[p].prm;
@@ -614,6 +614,8 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
 static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8_t* out, size_t cap, size_t* offs) {
   static const double budget_gb = [] { const char* e = getenv("QSVC_T1_BUDGET_GB"); double v = e ? atof(e) : 32.0; return v > 0.001 ? v : 0.001; }();
   const size_t max_blocks = (size_t)(budget_gb * 1e9 / (15.0 * T1_SEG_BYTES));
+  if (!c->j2k) c->j2k = new J2kState();
+  c->j2k->st_cb = 0; c->j2k->st_pass = 0; c->j2k->st_sym = 0;
   const qsvc_j2k_params* prm = src[0].prm;
   const int cbw = prm->cblk_w ? prm->cblk_w : 64, cbh = prm->cblk_h ? prm->cblk_h : 64;
   auto est = [&](const PlaneSrc& p) {  // blocks of all subbands, a little over W*H / (cbw*cbh)
