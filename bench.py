@@ -70,6 +70,53 @@ def cpu_baseline():
             "mctf_s": round(t1 - t0, 3), "j2k_s": round(t2 - t1, 3), "codeblocks_per_s": round(ncb / (t2 - t1), 1)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` from a plain shell: N fresh rank processes (one per GPU), started BEFORE this process makes
+    any GPU call (it never does).  Rank 0's stdout (the JSON line) is ours; a failing rank fails the whole run."""
+    import socket
+    import subprocess
+    try:
+        import torch  # device_count() alone does not initialise the GPU runtime
+        have = torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        have = None
+    if have is not None and have < n:
+        log(f"bench.py: --gpus {n} asked for, {have} visible: refusing (a silent fall-back to fewer GPUs would mislabel the result)")
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = time.time() + 1500
+    alive = list(range(n))
+    while alive:
+        for r in list(alive):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            alive.remove(r)
+            if c != 0:
+                log(f"bench.py: rank {r} exited with {c}")
+                rc = rc or (c if 0 < c < 256 else 1)
+        if (rc or time.time() > deadline) and alive:  # one rank failed: the others would wait for it forever
+            for r in alive:
+                procs[r].terminate()
+            for r in alive:
+                try:
+                    procs[r].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            rc = rc or 1
+            break
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +128,13 @@ def main():
                     help="17-picture sequences encoded concurrently per GPU (one encoder context + host thread each); "
                          "a step = every session finishing one whole encode")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: refusing to measure a different job than asked for")
+        sys.exit(2)
 
     # Native libraries (gloo, RCCL) print banners on fd 1; stdout must carry exactly ONE JSON line, so fd 1 points at
     # stderr until the result is printed.
@@ -141,10 +195,11 @@ def main():
 
     class Lockstep:
         """All sessions of this rank reach the level's exchange point together; ONE thread then runs the sessions'
-        exchanges one after the other, so every rank issues its collectives in the same order."""
+        exchanges one after the other, so every rank issues its collectives in the same order.  A session that dies
+        aborts the barrier (threading.BrokenBarrierError in the others) instead of leaving them waiting."""
         def __init__(self):
             self.args = [None] * S
-            self.bar = threading.Barrier(S, action=self._run)
+            self.bar = threading.Barrier(S, action=self._run, timeout=300)
             self.err = None
 
         def _run(self):
@@ -184,18 +239,30 @@ def main():
         out = comps[k].texture(low_first, copy=False)  # code-streams stay in the engine's host buffer (no Python copies)
         nbytes_of[k] = sum(len(c) for v in out.values() for c in v)
 
+    failures = []
+
     def run_steps(n):
-        """n steps; a step = every session completing one whole encode."""
+        """n steps; a step = every session completing one whole encode.  Any session's exception fails the run."""
         def work(k):
-            for _ in range(n):
-                step(k)
-            engs[k].sync()
+            try:
+                for _ in range(n):
+                    step(k)
+                engs[k].sync()
+            except BaseException as ex:  # noqa: BLE001
+                failures.append((k, repr(ex)))
+                if lock is not None:
+                    lock.bar.abort()
         if S == 1:
             work(0)
-            return
-        th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
-        [t.start() for t in th]
-        [t.join() for t in th]
+        else:
+            th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        if failures:
+            for k, ex in failures:
+                log(f"[rank {rank}] session {k} failed: {ex}")
+            os._exit(1)  # no JSON line; peers blocked in a collective are reaped by the launcher
+        assert all(b == nbytes_of[0] for b in nbytes_of), f"sessions coded different byte counts: {nbytes_of}"
 
     def barrier():
         for e in engs:

@@ -73,13 +73,14 @@ int qsvc_put_frames(qsvc_ctx* ctx, int kind, int t, int first, int count, int to
 int qsvc_get_frames(qsvc_ctx* ctx, int kind, int t, int first, int count, uint8_t* i420);
 /* motion_t / motion_filtered_t (motion.cpp:69-101): [pictures/2][4][BY][BX] int16 */
 int qsvc_put_motion(qsvc_ctx* ctx, int kind, int t, int b_pictures, int block_size, const int16_t* mv);
-int qsvc_get_motion(qsvc_ctx* ctx, int kind, int t, int16_t* mv);
+/* get: the caller's buffer holds b_pictures fields at block_size; QSVC_ERR_STATE when that is not what is resident */
+int qsvc_get_motion(qsvc_ctx* ctx, int kind, int t, int b_pictures, int block_size, int16_t* mv);
 /* frame_types_t: one 'I'/'B' byte per B picture (decorrelate.cpp:982,1005) */
 int qsvc_put_frame_types(qsvc_ctx* ctx, int t, int b_pictures, const char* types);
-int qsvc_get_frame_types(qsvc_ctx* ctx, int t, char* types);
+int qsvc_get_frame_types(qsvc_ctx* ctx, int t, int b_pictures, char* types);
 /* [b_pictures][3][256] u32: luma histogram of the odd picture, of residue+128, of mv+128
  * (decorrelate.cpp:798-819,945-950) -- what the I/B decision is made from. */
-int qsvc_get_histograms(qsvc_ctx* ctx, int t, uint32_t* hist);
+int qsvc_get_histograms(qsvc_ctx* ctx, int t, int b_pictures, uint32_t* hist);
 
 /* ---- MCTF stages: one call = one reference executable over one temporal level -------------- */
 /* replaces `motion_estimate` (motion_estimate.cpp:490-912; me_for_image :260-412):

@@ -255,6 +255,12 @@ def compress(argv=None):
     a["_default_bs"] = schedule.default_block_size(a["pixels_in_x"], a["pixels_in_y"])  # compress.py:139-142
     _resolve_blocks(a)
     a["quantization_texture"] = int(str(a["quantization_texture"]).replace('"', ""))
+    if a["block_size"] > a["block_size_min"] and a["TRLs"] > 2:
+        # motion_compress.py:159-166 re-reads the levels with the wrong block grid when the block size shrinks (its loop
+        # control sits inside the `if`): the reference then emits garbled motion streams.  Not reproduced; refuse loudly
+        # rather than leave a code-stream without motion_residue_* / *.mjc behind.
+        C.die("--block_size > --block_size_min with TRLs > 2: the motion-field coding of a shrinking block size "
+              "(motion_compress.py:159-166) is not implemented on this path")
     from .. import hip
     W, H = a["pixels_in_x"], a["pixels_in_y"]
     low0 = C.read_frames("low_0", W, H, schedule.pictures(a["GOPs"], a["TRLs"]))
@@ -267,8 +273,7 @@ def compress(argv=None):
             from .motion_tools import run_motion_compress  # compress.py:197-212
             filt = {t: e.get_motion(hip.MOTION_FILTERED, t, P // 2, bs)
                     for (t, P, S, bs) in schedule.level_schedule(a["GOPs"], a["TRLs"], a["block_size"], a["block_size_min"], a["search_range"])}
-            if a["block_size"] == a["block_size_min"]:
-                run_motion_compress(e, W, H, a["TRLs"], a["GOPs"], a["block_size"], a["block_size_min"], filtered=filt)
+            run_motion_compress(e, W, H, a["TRLs"], a["GOPs"], a["block_size"], a["block_size_min"], filtered=filt)
         _texture(e, a, device=True)
     except hip.QsvcError as ex:
         C.die(str(ex))

@@ -85,7 +85,10 @@ def run_motion_compress(e, W, H, TRLs, GOPs, block_size, block_size_min, filtere
         for it in range(1, TRLs):
             filtered[it] = _fields(f"motion_filtered_{it}", f, BY, BX)
             f //= 2
-    res = motion.residue_chain(filtered, TRLs, block_size, block_size_min)
+    try:
+        res = motion.residue_chain(filtered, TRLs, block_size, block_size_min)
+    except NotImplementedError as ex:
+        C.die(str(ex))
     for it in range(1, TRLs):
         C.write_motion(f"motion_residue_{it}", res[it])
         encode_residue(e, f"motion_residue_{it}", res[it])

@@ -8,28 +8,36 @@ from . import common as C
 
 
 def header_size(data: bytes) -> int:
-    """header_size.c:42-98, literally: count the SOP markers FF 91 00 04; returns the value printed after 'OUT'."""
-    n = len(data)
-    i = 0
-    cont, num, start, first, total = 0, 1, -1, 0, 0
+    """header_size.c:42-98: count the SOP markers FF 91 00 04; returns the value printed after 'OUT'.
 
-    def getc():
-        nonlocal i, num
-        num += 1
-        if i < n:
-            c = data[i]
-            i += 1
-            return c
-        i += 1
-        return -1
-    while i <= n:  # while(!feof(f)): one more fgetc after the last byte
-        if getc() == 0xFF and getc() == 0x91 and getc() == 0x00 and getc() == 0x04:
+    The tool's scanner consumes the bytes it compares (an FF that fails the 0x91 test is not looked at again as a
+    first byte), and numByte = 1 + number of fgetc calls, one of which returns EOF.  Same state machine here, hopping
+    from FF to FF with bytes.find instead of running Python per byte."""
+    data = bytes(data)
+    n = len(data)
+    cont, start, first, total = 0, -1, 0, 0
+    i = 0
+    while True:
+        p = data.find(b"\xff", i)
+        if p < 0:
+            break
+        # c1 = data[p]; the next fgetc results are consumed whether they match or not
+        if data[p + 1:p + 2] != b"\x91":
+            i = p + 2
+        elif data[p + 2:p + 3] != b"\x00":
+            i = p + 3
+        elif data[p + 3:p + 4] != b"\x04":
+            i = p + 4
+        else:
+            num = p + 5  # numByte after the four reads
             if cont == 0:
                 first = num - 4 - 1
             else:
                 total += 7 if (num - start) == 7 else 6
             start = num
             cont += 1
+            i = p + 4
+    num = n + 2  # n bytes + the read that returned EOF, counted from 1
     total += 7 if (num - start + 1) == 7 else 6
     return first + total + 2
 

@@ -419,8 +419,13 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   } else {
     // the per-block bit-plane counts decide the job list: one (group, plane) wave per plane any block of the group has
     S.h_nbps.resize(ncb);
+    int perr = 0;
     HIPCHK(c, hipMemcpyAsync(S.h_nbps.data(), S.nbps_d.p, (size_t)ncb * 4, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(&perr, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    // a block with more bit-planes than its subband allows (or than the 15-bit magnitude format holds) must never reach
+    // the context-modelling / MQ kernels: their job and pass tables are sized for nbps <= 15
+    if (perr) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
     S.h_joboff.resize(ncb);
     S.h_waves.clear();
     size_t njobs = 0;

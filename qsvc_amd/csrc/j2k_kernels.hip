@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_t1_pack(const CbDesc* cbs, int ncb, con
   if (threadIdx.x == 0) {
     int m = smax[0], nb = 0;
     while (nb < 31 && (m >> nb)) nb++;
-    nbps_out[b] = nb;
+    nbps_out[b] = nb > 15 ? 15 : nb;
     if (nb > cb.Mb || nb > 15) atomicOr(err, 1);  // magnitude does not fit M_b / the 15-bit lane format
   }
 }
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) k_t1_nbps(const CbDesc* cbs, int ncb, int
   if (b >= ncb) return;
   int m = nbps[b], nb = 0;
   while (nb < 31 && (m >> nb)) nb++;
-  nbps[b] = nb;
+  nbps[b] = nb > 15 ? 15 : nb;
   if (nb > cbs[b].Mb || nb > 15) atomicOr(err, 1);  // magnitude does not fit M_b / the 15-bit lane format
 }
 void launch_t1_pack(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef, uint32_t* mags,
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
   t.cx = s_cx + lane; t.cs = T1_MQ_LANES; t.mqtab = s_mq; t.mq2 = s_mq2; t.zclut = nullptr;
   t.w = t.h = t.orient = 0; t.nbps = 0; t.out = outbuf; t.cap = 0;
   size_t job0 = 0;
-  if (b < ncb) { t.nbps = nbps_in[b]; t.out = outbuf + (size_t)b * outcap; t.cap = outcap; job0 = (size_t)joboff[b]; }
+  if (b < ncb) { t.nbps = nbps_in[b] > 15 ? 15 : nbps_in[b]; t.out = outbuf + (size_t)b * outcap; t.cap = outcap; job0 = (size_t)joboff[b]; }
   int top = t.nbps - 1;
   for (int o = T1_MQ_LANES / 2; o >= 1; o >>= 1) { int a = __shfl_xor(top, o, 64); top = a > top ? a : top; }
   top = __builtin_amdgcn_readfirstlane(top);
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
         cur = nxt;
       }
       t.nsym += (uint32_t)n;
-      if (lane_pass) { pl[np] = t.n + 4; if (pd) pd[np] = dist[job * 3 + pass]; np++; }
+      if (lane_pass && np < T1_MAXPASS) { pl[np] = t.n + 4; if (pd) pd[np] = dist[job * 3 + pass]; np++; }
     }
   }
   T1Result r;
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(256) k_t1_pack_blk(const CbDesc* cbs, int ncb,
   if (threadIdx.x == 0) {
     int m = smax[0], nb = 0;
     while (nb < 31 && (m >> nb)) nb++;
-    nbps_out[b] = nb;
+    nbps_out[b] = nb > 15 ? 15 : nb;  // the error flag stops the host before any Tier-1 launch
     if (nb > cb.Mb || nb > 15) atomicOr(err, 1);
   }
 }

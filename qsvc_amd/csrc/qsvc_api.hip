@@ -175,32 +175,40 @@ int qsvc_put_motion(qsvc_ctx* c, int kind, int t, int nB, int bs, const int16_t*
   HIPCHK(c, hipStreamSynchronize(c->st));
   return QSVC_OK;
 }
-int qsvc_get_motion(qsvc_ctx* c, int kind, int t, int16_t* mv) {
-  if (!c || !mv || t < 1 || t > QSVC_MAX_T) return QSVC_ERR_INVALID;
+int qsvc_get_motion(qsvc_ctx* c, int kind, int t, int b_pictures, int block_size, int16_t* mv) {
+  if (!c || !mv || t < 1 || t > QSVC_MAX_T || b_pictures < 0) return QSVC_ERR_INVALID;
   Level& l = c->lv[t];
   int nB = kind == QSVC_MOTION_RAW ? l.mv_raw_n : l.mv_filt_n;
   if (!l.mv_bs) return c->fail(QSVC_ERR_STATE, "no motion for t=%d", t);
+  // the caller sized its buffer from (b_pictures, block_size): both must describe what is resident
+  if (block_size != l.mv_bs || b_pictures > nB)
+    return c->fail(QSVC_ERR_STATE, "motion of t=%d holds %d fields at block size %d (asked for %d at %d)", t, nB, l.mv_bs, b_pictures, block_size);
   DevBuf& b = kind == QSVC_MOTION_RAW ? l.mv_raw : l.mv_filt;
-  size_t bytes = (size_t)nB * 4 * (c->H / l.mv_bs) * (c->W / l.mv_bs) * sizeof(int16_t);
+  size_t bytes = (size_t)b_pictures * 4 * (c->H / l.mv_bs) * (c->W / l.mv_bs) * sizeof(int16_t);
+  if (!bytes) return QSVC_OK;
   HIPCHK(c, hipMemcpyAsync(mv, b.p, bytes, hipMemcpyDeviceToHost, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   return QSVC_OK;
 }
 int qsvc_put_frame_types(qsvc_ctx* c, int t, int nB, const char* types) {
-  if (!c || !types || t < 1 || t > QSVC_MAX_T) return QSVC_ERR_INVALID;
+  if (!c || !types || t < 1 || t > QSVC_MAX_T || nB < 0) return QSVC_ERR_INVALID;
   c->lv[t].types.assign(types, types + nB);
   return QSVC_OK;
 }
-int qsvc_get_frame_types(qsvc_ctx* c, int t, char* types) {
-  if (!c || !types || t < 1 || t > QSVC_MAX_T) return QSVC_ERR_INVALID;
-  memcpy(types, c->lv[t].types.data(), c->lv[t].types.size());
+int qsvc_get_frame_types(qsvc_ctx* c, int t, int b_pictures, char* types) {
+  if (!c || !types || t < 1 || t > QSVC_MAX_T || b_pictures < 0) return QSVC_ERR_INVALID;
+  if ((size_t)b_pictures > c->lv[t].types.size())
+    return c->fail(QSVC_ERR_STATE, "frame_types_%d holds %zu entries (asked for %d)", t, c->lv[t].types.size(), b_pictures);
+  memcpy(types, c->lv[t].types.data(), (size_t)b_pictures);
   return QSVC_OK;
 }
-int qsvc_get_histograms(qsvc_ctx* c, int t, uint32_t* hist) {
-  if (!c || !hist || t < 1 || t > QSVC_MAX_T) return QSVC_ERR_INVALID;
+int qsvc_get_histograms(qsvc_ctx* c, int t, int b_pictures, uint32_t* hist) {
+  if (!c || !hist || t < 1 || t > QSVC_MAX_T || b_pictures < 0) return QSVC_ERR_INVALID;
   Level& l = c->lv[t];
   if (!l.hist.p) return c->fail(QSVC_ERR_STATE, "no histograms for t=%d", t);
-  HIPCHK(c, hipMemcpyAsync(hist, l.hist.p, (size_t)l.high_n * 3 * 256 * 4, hipMemcpyDeviceToHost, c->st));
+  if (b_pictures > l.high_n) return c->fail(QSVC_ERR_STATE, "histograms of t=%d cover %d pictures (asked for %d)", t, l.high_n, b_pictures);
+  if (!b_pictures) return QSVC_OK;
+  HIPCHK(c, hipMemcpyAsync(hist, l.hist.p, (size_t)b_pictures * 3 * 256 * 4, hipMemcpyDeviceToHost, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   return QSVC_OK;
 }

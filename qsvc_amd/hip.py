@@ -58,10 +58,10 @@ def load_library() -> C.CDLL:
     L.qsvc_put_frames.argtypes = [vp, i, i, i, i, i, u8p]
     L.qsvc_get_frames.argtypes = [vp, i, i, i, i, u8p]
     L.qsvc_put_motion.argtypes = [vp, i, i, i, i, i16p]
-    L.qsvc_get_motion.argtypes = [vp, i, i, i16p]
+    L.qsvc_get_motion.argtypes = [vp, i, i, i, i, i16p]
     L.qsvc_put_frame_types.argtypes = [vp, i, i, C.c_char_p]
-    L.qsvc_get_frame_types.argtypes = [vp, i, C.c_char_p]
-    L.qsvc_get_histograms.argtypes = [vp, i, vp]
+    L.qsvc_get_frame_types.argtypes = [vp, i, i, C.c_char_p]
+    L.qsvc_get_histograms.argtypes = [vp, i, i, vp]
     L.qsvc_motion_estimate.argtypes = [vp, i, i, i, i]
     L.qsvc_decorrelate.argtypes = [vp, i, i, i, i, i]
     L.qsvc_update.argtypes = [vp, i, i, i, C.c_float]
@@ -151,7 +151,7 @@ class Engine:
 
     def get_motion(self, kind, t, nB, block_size) -> np.ndarray:
         out = np.empty((nB, 4, self.H // block_size, self.W // block_size), dtype=np.int16)
-        self._chk(self.L.qsvc_get_motion(self.h, kind, t, out.ctypes.data))
+        self._chk(self.L.qsvc_get_motion(self.h, kind, t, nB, block_size, out.ctypes.data))
         return out
 
     def put_frame_types(self, t, types: bytes):
@@ -159,12 +159,12 @@ class Engine:
 
     def get_frame_types(self, t, nB) -> bytes:
         buf = C.create_string_buffer(nB + 1)
-        self._chk(self.L.qsvc_get_frame_types(self.h, t, buf))
+        self._chk(self.L.qsvc_get_frame_types(self.h, t, nB, buf))
         return buf.raw[:nB]
 
     def get_histograms(self, t, nB) -> np.ndarray:
         out = np.empty((nB, 3, 256), dtype=np.uint32)
-        self._chk(self.L.qsvc_get_histograms(self.h, t, out.ctypes.data))
+        self._chk(self.L.qsvc_get_histograms(self.h, t, nB, out.ctypes.data))
         return out
 
     # ---- stages

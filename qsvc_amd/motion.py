@@ -49,9 +49,9 @@ def demux_components(residue: np.ndarray) -> np.ndarray:
 def residue_chain(filtered: dict, TRLs: int, block_size: int, block_size_min: int) -> dict:
     """filtered: {t: motion_filtered_t}.  -> {t: motion_residue_t} following the loop of motion_compress.py:146-186 for
     the case block_size == block_size_min (the only one the reference's schedule produces through `compress`)."""
-    if block_size != block_size_min:
-        raise NotImplementedError("motion_compress with a shrinking block size (motion_compress.py:159-166 quirk) is not reproduced")
     iterations = TRLs - 1
+    if block_size > block_size_min and iterations > 1:  # one iteration: the loop of :140-166 never runs, the grid is level 1's
+        raise NotImplementedError("motion_compress with a shrinking block size (motion_compress.py:159-166 quirk) is not reproduced")
     res = {}
     for it in range(1, iterations):
         res[it] = interlevel_decorrelate(filtered[it], filtered[it + 1])

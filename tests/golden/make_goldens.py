@@ -111,10 +111,16 @@ def main():
     np.savez_compressed(os.path.join(HERE, "motion_kat.npz"), **mk)
     print("motion_kat", len(mk))
 
-    # header_size (trunk/src/header_size.c compiled into oracle/_ref) on deterministic marker streams
+    make_header_size_goldens()
+
+
+def make_header_size_goldens():
+    """header_size (trunk/src/header_size.c compiled into oracle/_ref) on deterministic marker streams + adversarial byte
+    patterns for its consuming scanner (FF FF 91 00 04 does not match; files ending inside a marker)."""
     import json, subprocess, tempfile
     hs = []
     rng = np.random.default_rng(11)
+    bodies = []
     for case in range(8):
         body = bytearray(b"\xff\x4f" + bytes(rng.integers(0, 255, size=int(rng.integers(20, 90)), dtype=np.uint8)))
         for k in range(int(rng.integers(1, 7))):
@@ -122,14 +128,24 @@ def main():
             n = int(rng.choice([1, 1, 5, 40]))
             body += bytes(rng.integers(0, 255, size=n, dtype=np.uint8))
         body += b"\xff\xd9"
+        bodies.append(bytes(body))
+    sop = b"\xff\x91\x00\x04"
+    bodies += [b"", b"\xff", b"\xff\x91", b"\xff\x91\x00", sop, sop + b"\x00\x00\xff\xd9", b"\xff\xff\x91\x00\x04\x00\x01ab" + sop + b"\x00",
+               b"\xff\x4fxx\xff\x91\xff\x91\x00\x04\x00\x00" + sop + b"\x00\x01\x00" + sop + b"\x00\x02\xff\xd9",
+               b"\xff\x4f" + sop + b"\x00\x00\xff" + sop + b"\x00\x01\x80\xff\x91\x00\xff\x91\x00\x04\xff",
+               bytes(rng.integers(0, 256, size=3000, dtype=np.uint8)) + sop + b"\x00\x00q" + sop]
+    for body in bodies:
         with tempfile.NamedTemporaryFile(suffix=".j2c", delete=False) as f:
-            f.write(bytes(body))
+            f.write(body)
         out = subprocess.run([os.path.join(O.REF_DIR, "header_size"), f.name], capture_output=True, text=True).stdout
         os.unlink(f.name)
-        hs.append({"hex": bytes(body).hex(), "out": int([l for l in out.splitlines() if l.startswith("OUT")][0][4:])})
+        hs.append({"hex": body.hex(), "out": int([l for l in out.splitlines() if l.startswith("OUT")][0][4:])})
     json.dump(hs, open(os.path.join(HERE, "header_size.json"), "w"))
     print("header_size", [h["out"] for h in hs])
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["header_size"]:
+        make_header_size_goldens()
+    else:
+        main()

@@ -45,3 +45,28 @@ def test_interleave_is_split_inverse():
     import numpy as np
     low = np.arange(5 * 6, dtype=np.uint8).reshape(5, 6)
     np.testing.assert_array_equal(C.interleave(low[0::2], low[1::2]), low)
+
+
+def test_compress_refuses_the_shrinking_block_motion_chain(tmp_path):
+    """compress.py:197-212 always runs motion_compress; with --block_size > --block_size_min and more than one interlevel
+    iteration the reference's loop (motion_compress.py:159-166) garbles the fields.  This path refuses instead of leaving
+    a code-stream without motion_residue_* behind -- before any GPU work, with the drivers' exit status 255."""
+    import subprocess, sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    np.zeros(9 * 64 * 64 * 3 // 2, dtype=np.uint8).tofile(tmp_path / "low_0")
+    r = subprocess.run([os.path.join(root, "bin", "mctf"), "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=4", "--GOPs=1",
+                        "--block_size=32", "--block_size_min=16"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 255, (r.returncode, r.stderr[-500:])
+    assert "block_size_min" in r.stderr
+    assert not list(tmp_path.glob("*.j2c")) and not list(tmp_path.glob("frame_types_*"))
+
+
+def test_residue_chain_single_iteration_keeps_the_level1_grid():
+    import numpy as np
+    from qsvc_amd import motion
+    f = np.arange(2 * 4 * 3 * 5, dtype=np.int16).reshape(2, 4, 3, 5)
+    res = motion.residue_chain({1: f}, 2, 32, 16)  # TRLs=2: only the bidirectional step (motion_compress.py:176-186)
+    np.testing.assert_array_equal(res[1], motion.bidirectional_decorrelate(f))
+    with pytest.raises(NotImplementedError):
+        motion.residue_chain({1: f, 2: f[:1]}, 3, 32, 16)

@@ -111,3 +111,39 @@ def test_config5_8k_one_gop_shard(eng):
     np.testing.assert_array_equal(J.decode(out[(hip.HIGH, 2)][3 + 1]), planes_of(f, W, H)[1])   # a 3840x2160 chroma plane, lossless
     mv = eng.get_motion(hip.MOTION_RAW, 1, 4, 32)
     assert (mv[:, 0, 2:-2, 2:-2] == 2).mean() > 0.97 and (mv[:, 3, 2:-2, 2:-2] == -1).mean() > 0.97
+
+
+# ---- full-size pins by the reference's own binaries (tests/golden/fullsize_digests.json, made by
+# tests/golden/make_fullsize_goldens.py from oracle/_ref in the build container): zero oracle cost on the GPU box ----------
+def _fullsize_cases():
+    import json, os
+    from helpers import GOLDEN
+    return json.load(open(os.path.join(GOLDEN, "fullsize_digests.json")))
+
+
+@pytest.mark.parametrize("name", ["cfg3_pan_noise", "cfg3_edge", "cfg4_pan_noise_2levels"])
+def test_fullsize_levels_match_reference_digests(eng, name):
+    """BASELINE config 3 (all three 1080p levels: S = 4/8/16, 135x240 block grid) and levels 1-2 of config 4 (3840x2160,
+    block 16): motion_t, motion_filtered_t, frame_types_t, high_t, low_t == the compiled reference tools' files
+    (motion_estimate.cpp:260-481, decorrelate.cpp:583-1075, update.cpp:506-656), by SHA-256 per picture and per file."""
+    from helpers import sha
+    from qsvc_amd import hip
+    c = _fullsize_cases()[name]
+    W, H, bs = c["W"], c["H"], c["block_size"]
+    clip = make_clip(c["kind"], c["frames"], W, H, c["seed"])
+    assert sha(clip) == c["input_sha"], "synthetic clip generator drifted from the committed digests"
+    eng.seq_config(W, H)
+    eng.put_frames(hip.LOW, 0, clip)
+    for lv in c["levels"]:
+        t, P, S = lv["t"], lv["pictures"], lv["search_range"]
+        assert lv["block_size"] == bs
+        eng.analyze_step(t, P, bs, S)
+        nB = P // 2
+        got = {"motion": eng.get_motion(hip.MOTION_RAW, t, nB, bs), "motion_filtered": eng.get_motion(hip.MOTION_FILTERED, t, nB, bs),
+               "high": eng.get_frames(hip.HIGH, t, 0, nB), "low": eng.get_frames(hip.LOW, t, 0, nB + 1)}
+        assert eng.get_frame_types(t, nB).decode() == lv["frame_types"], f"frame_types_{t}"
+        for k, a in got.items():
+            per = [sha(x)[:16] for x in a]
+            bad = [i for i, (g, w) in enumerate(zip(per, lv[k + "_per_picture"])) if g != w]
+            assert not bad, f"{name}: {k}_{t} differs from the reference in pictures {bad}"
+            assert sha(a) == lv[k], f"{name}: {k}_{t} digest"

@@ -163,3 +163,22 @@ def test_plane_groups_do_not_change_the_streams(eng):
         runs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True))
         assert runs[-1].returncode == 0, runs[-1].stderr[-800:]
     assert runs[0].stdout == runs[1].stdout and runs[0].stdout.startswith("15 ")
+
+
+def test_too_many_bitplanes_is_an_error_not_a_fault(eng):
+    """A quantiser step so small that a subband needs more than its M_b (or more than 15) magnitude bit-planes must come back
+    as QSVC_ERR_UNSUPPORTED before any Tier-1 kernel runs on the unclamped count (j2k_api.hip: err_d is read in the same sync
+    as the bit-plane counts).  Reachable from the public --base_step extension and from int16 planes holding -32768."""
+    from qsvc_amd import hip
+    y = _luma("noise", 256, 192, 9)
+    with pytest.raises(hip.QsvcError) as ei:
+        eng.j2k_encode_plane(y, hip.j2k_params(reversible=False, levels=3, base_step=1.0 / 65536))
+    assert ei.value.code == -2
+    planes = np.zeros((2, 40, 48), dtype=np.int16)
+    planes[1, 7, 9] = -32768
+    with pytest.raises(hip.QsvcError) as ei:
+        eng.j2k_encode_planes_s16(planes, hip.j2k_params(reversible=True, levels=0, layers=1))
+    assert ei.value.code == -2
+    # the context is still usable afterwards
+    cs = eng.j2k_encode_plane(y, hip.j2k_params(reversible=True, levels=3))
+    np.testing.assert_array_equal(J.decode(cs), y)

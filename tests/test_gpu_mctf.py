@@ -229,3 +229,27 @@ def test_degenerate_picture_counts(eng, oracle):
     want = oracle.analyze_step(clip[:3], W, H, bs, S)
     np.testing.assert_array_equal(eng.get_frames(hip.LOW, 1, 0, 2), want["low"])
     np.testing.assert_array_equal(eng.get_frames(hip.HIGH, 1, 0, 1), want["high"])
+
+
+def test_getters_check_the_callers_capacity():
+    """qsvc_get_motion / _frame_types / _histograms copy what the CALLER sized its buffer for, and refuse (QSVC_ERR_STATE) when
+    that is more than -- or laid out differently from -- what is resident."""
+    from qsvc_amd import hip
+    from qsvc_amd.synth import make_clip
+    W, H, bs = 128, 96, 16
+    e = hip.Engine(0)
+    try:
+        e.seq_config(W, H)
+        e.put_frames(hip.LOW, 0, make_clip("pan", 5, W, H, 1))
+        e.analyze_step(1, 5, bs, 4)
+        assert e.get_motion(hip.MOTION_RAW, 1, 1, bs).shape == (1, 4, H // bs, W // bs)   # fewer than resident: fine
+        assert len(e.get_frame_types(1, 1)) == 1 and e.get_histograms(1, 2).shape == (2, 3, 256)
+        for call in (lambda: e.get_motion(hip.MOTION_RAW, 1, 3, bs), lambda: e.get_motion(hip.MOTION_FILTERED, 1, 2, bs // 2),
+                     lambda: e.get_frame_types(1, 3), lambda: e.get_histograms(1, 3)):
+            with pytest.raises(hip.QsvcError) as ei:
+                call()
+            assert ei.value.code == -4
+        with pytest.raises(hip.QsvcError):
+            e._chk(e.L.qsvc_put_frame_types(e.h, 1, -1, b"B"))
+    finally:
+        e.close()
