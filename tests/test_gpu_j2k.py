@@ -182,3 +182,21 @@ def test_too_many_bitplanes_is_an_error_not_a_fault(eng):
     # the context is still usable afterwards
     cs = eng.j2k_encode_plane(y, hip.j2k_params(reversible=True, levels=3))
     np.testing.assert_array_equal(J.decode(cs), y)
+
+
+@pytest.mark.parametrize("kind,W,H,levels", [("pan_noise", 352, 288, 4), ("noise", 65, 129, 1), ("pan_noise", 1920, 1080, 4)])
+def test_hip_codestream_equals_openjpeg_encoder(eng, kind, W, H, levels):
+    """The HIP path against the SECOND encoder directly (not through the restatement): per code-block zero bit-planes, passes
+    and MQ segments, and the whole packet sequence once our SOP markers are removed (tests/test_j2k_vs_openjpeg.py)."""
+    from qsvc_amd import hip
+    from test_j2k_vs_openjpeg import assert_same_blocks, openjpeg_encode
+    y = _luma(kind, W, H, 43)
+    assert_same_blocks(eng.j2k_encode_plane(y, hip.j2k_params(reversible=True, levels=levels)), openjpeg_encode(y, levels))
+
+
+def test_hip_motion_planes_equal_openjpeg_encoder(eng):
+    from qsvc_amd import hip
+    from test_j2k_vs_openjpeg import assert_same_blocks, openjpeg_encode
+    r = np.random.default_rng(5).integers(-40, 40, size=(8, 135, 240)).astype(np.int16)
+    for cs, pl in zip(eng.j2k_encode_planes_s16(r, hip.j2k_params(reversible=True, levels=0, layers=1)), r):
+        assert_same_blocks(cs, openjpeg_encode(pl.view(np.uint16), 0, signed=True))
