@@ -193,9 +193,10 @@ struct HostCb {  // host view of one coded block
 }  // namespace
 
 struct J2kState {
-  DevBuf coefA, coefB, planes_d, cbs_d, nbps_d, mags, flags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
-  DevBuf waves_d, joboff_d, order_d, jobs_d, segs_d, cnt_d, dist_d;  // split Tier-1
-  std::vector<int> h_nbps, h_joboff, h_waves, h_order, h_jobs;
+  DevBuf coefA, llA, llB, sbtab_d, planes_d, cbs_d, nbps_d, mags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
+  DevBuf joboff_d, order_d, jobs_d, segs_d, cnt_d, dist_d;  // Tier-1: job list, decision segments
+  std::vector<int> h_nbps, h_joboff, h_order, h_jobs;
+  std::vector<DwtSb> sbtab;
   std::vector<uint8_t> t2scratch;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
   std::vector<PlaneDesc> planes;
@@ -210,8 +211,8 @@ struct J2kState {
 void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
-  DevBuf* all[] = {&s->coefA, &s->coefB, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->flags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->waves_d, &s->joboff_d, &s->order_d, &s->jobs_d, &s->segs_d, &s->cnt_d, &s->dist_d};
+  DevBuf* all[] = {&s->coefA, &s->llA, &s->llB, &s->sbtab_d, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->outbuf, &s->res_d, &s->plen_d,
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->jobs_d, &s->segs_d, &s->cnt_d, &s->dist_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   delete s;
@@ -371,23 +372,35 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
           d.orient = (short)s.orient; d.Mb = (short)s.Mb; d.delta = s.delta;
         }
   }
-  // Tier-1 form: "split" (default) = bit-plane-parallel context modelling + MQ kernel; "fused" = one kernel,
-  // `lanes` code-blocks per wave through an LDS window.
-  static const bool split = [] { const char* e = getenv("QSVC_T1_MODE"); return !(e && !strcmp(e, "fused")); }();
-  // context modelling of the split form: "cm2" (default) = sample-parallel, one wave per (block, bit-plane), no flag words in
-  // HBM (t1_cm2.h); "split" = the lane-per-block form over flag words (k_t1_flags_init + k_t1_cm)
-  static const bool cm2 = [] { const char* e = getenv("QSVC_T1_MODE"); return !(e && (!strcmp(e, "fused") || !strcmp(e, "split"))); }();
-  static const int lanes_env = [] { const char* e = getenv("QSVC_T1_LANES"); int v = e ? atoi(e) : 8; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 8; }();
-  const int lanes = split ? 64 : lanes_env;
-  const int ngroups = (ncb + lanes - 1) / lanes;
+  // ---- device plan: compact low-band buffers (ping-pong), subband table of the DWT kernel ----------------------------------
   const bool want_dist = any_dist;
   int r;
-  if ((r = S.coefA.ensure(c, total * 4))) return r;
-  if ((r = S.coefB.ensure(c, total * 4))) return r;
+  size_t llA_n = 0, llB_n = 0;
+  const int nsb = 1 + 3 * maxL;
+  S.sbtab.resize((size_t)np * nsb);
+  for (int p = 0; p < np; p++) {
+    const int w1 = (src[p].W + 1) >> 1, h1 = (src[p].H + 1) >> 1, w2 = (w1 + 1) >> 1, h2 = (h1 + 1) >> 1;
+    S.planes[p].ll[0] = llA_n; S.planes[p].ll[1] = llB_n;
+    llA_n += ((size_t)((w1 + 3) & ~3) * h1 + 7) & ~(size_t)7;   // 16-byte aligned plane starts (int16 / float32 elements)
+    llB_n += ((size_t)((w2 + 3) & ~3) * h2 + 7) & ~(size_t)7;
+    const PlanePlan& pl = plans[plan_of[p]];
+    for (int k = 0; k < nsb; k++) {
+      const Subband& sb = pl.sb[k];
+      S.sbtab[(size_t)p * nsb + k] = DwtSb{first_cb[p] + sb.first_cb, sb.gx, sb.Mb, sb.delta};
+    }
+  }
+  const size_t ll_elem = rev ? 2 : 4;
+  if (maxL == 0) { if ((r = S.coefA.ensure(c, total * 4))) return r; }
+  else {
+    if ((r = S.llA.ensure(c, llA_n * ll_elem + 64))) return r;
+    if ((r = S.llB.ensure(c, llB_n * ll_elem + 64))) return r;
+    if ((r = S.sbtab_d.ensure(c, S.sbtab.size() * sizeof(DwtSb)))) return r;
+    HIPCHK(c, hipMemcpyAsync(S.sbtab_d.p, S.sbtab.data(), S.sbtab.size() * sizeof(DwtSb), hipMemcpyHostToDevice, c->st));
+  }
   if ((r = S.planes_d.ensure(c, np * sizeof(PlaneDesc)))) return r;
   if ((r = S.cbs_d.ensure(c, (size_t)ncb * sizeof(CbDesc)))) return r;
   if ((r = S.nbps_d.ensure(c, (size_t)ncb * 4))) return r;
-  if ((r = S.mags.ensure(c, (size_t)ngroups * lanes * T1_MAGS_WORDS * 4))) return r;
+  if ((r = S.mags.ensure(c, (size_t)ncb * T1_MAGS_BYTES))) return r;
   if ((r = S.outbuf.ensure(c, (size_t)ncb * J2K_OUTCAP))) return r;
   if ((r = S.res_d.ensure(c, (size_t)ncb * sizeof(CbOut)))) return r;
   if ((r = S.plen_d.ensure(c, (size_t)ncb * T1_MAXPASS * 4))) return r;
@@ -399,25 +412,24 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   HIPCHK(c, hipMemcpyAsync(S.cbs_d.p, S.cbs.data(), (size_t)ncb * sizeof(CbDesc), hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
   Prof pf;
-  pf.begin(c, rev ? "j2k_dwt53" : "j2k_dwt97");
-  launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, S.coefA.p, S.coefB.p, maxL, rev);
-  pf.end(c);
-  pf.begin(c, "j2k_t1_pack");
-  if (cm2) launch_t1_pack_blk(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (unsigned long long*)S.mags.p,
-                              (int*)S.nbps_d.p, (int*)S.err_d.p, rev);
-  else launch_t1_pack(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (uint32_t*)S.mags.p, (int*)S.nbps_d.p,
-                      (int*)S.err_d.p, rev, lanes);
-  pf.end(c);
-  if (!split) {
-    if ((r = S.flags.ensure(c, (size_t)ngroups * lanes * T1_FLAGS_WORDS * 4))) return r;
-    pf.begin(c, "j2k_t1_encode");
-    HIPCHK(c, hipMemsetAsync(S.flags.p, 0, (size_t)ngroups * lanes * T1_FLAGS_WORDS * 4, c->st));
-    launch_t1_encode(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const uint32_t*)S.mags.p, (uint32_t*)S.flags.p,
-                     (uint8_t*)S.outbuf.p, J2K_OUTCAP, (CbOut*)S.res_d.p, (int*)S.plen_d.p, want_dist ? (long long*)S.pdist_d.p : nullptr,
-                     want_dist ? 1 : 0, lanes);
+  if (maxL > 0) {
+    // one kernel per level: tile in LDS, vertical + horizontal lifting, LL to the next level, the other subbands quantised and
+    // packed straight into the Tier-1 magnitudes; the blocks' largest magnitudes are collected by atomicMax into nbps_d
+    pf.begin(c, rev ? "j2k_dwt53" : "j2k_dwt97");
+    HIPCHK(c, hipMemsetAsync(S.nbps_d.p, 0, (size_t)ncb * 4, c->st));
+    launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, (const DwtSb*)S.sbtab_d.p, maxL, rev, S.llA.p, S.llB.p,
+                     (unsigned long long*)S.mags.p, (int*)S.nbps_d.p, nullptr, ilog2i(cbw), ilog2i(cbh), (int*)S.err_d.p);
+    launch_t1_nbps(c->st, (const CbDesc*)S.cbs_d.p, ncb, (int*)S.nbps_d.p, (int*)S.err_d.p);
     pf.end(c);
-  } else {
-    // the per-block bit-plane counts decide the job list: one (group, plane) wave per plane any block of the group has
+  } else {  // Clevels = 0 (motion-field planes): level shift, then quantise + pack per code-block
+    pf.begin(c, "j2k_t1_pack");
+    launch_level_shift(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, S.coefA.p, rev);
+    launch_t1_pack_blk(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (unsigned long long*)S.mags.p,
+                       (int*)S.nbps_d.p, (int*)S.err_d.p, rev);
+    pf.end(c);
+  }
+  {
+    // the per-block bit-plane counts decide the job list: one context-modelling wave per (block, bit-plane)
     S.h_nbps.resize(ncb);
     int perr = 0;
     HIPCHK(c, hipMemcpyAsync(S.h_nbps.data(), S.nbps_d.p, (size_t)ncb * 4, hipMemcpyDeviceToHost, c->st));
@@ -427,19 +439,10 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     // the context-modelling / MQ kernels: their job and pass tables are sized for nbps <= 15
     if (perr) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
     S.h_joboff.resize(ncb);
-    S.h_waves.clear();
     size_t njobs = 0;
-    for (int g = 0; g < ngroups; g++) {
-      int mx = 0;
-      for (int b = g * 64; b < std::min(ncb, g * 64 + 64); b++) {
-        int nb = S.h_nbps[b] > 15 ? 15 : S.h_nbps[b];  // > 15 is reported through err_d below
-        S.h_joboff[b] = (int)njobs; njobs += nb; mx = std::max(mx, nb);
-      }
-      for (int p = 0; p < mx; p++) S.h_waves.push_back((g << 8) | p);
-    }
-    const int nwaves = (int)S.h_waves.size();
+    for (int b = 0; b < ncb; b++) { S.h_joboff[b] = (int)njobs; njobs += S.h_nbps[b] > 15 ? 15 : S.h_nbps[b]; }
     // MQ slot table: slot k of the MQ launch codes block order[k] (ncb = idle lane).  The blocks with the longest expected
-    // chains (bit-planes x area) are set apart in waves of few lanes, whose lock-step costs less per decision; the others
+    // chains (bit-planes x area) can be set apart in waves of few lanes, whose lock-step costs less per decision; the others
     // keep their natural order, 16 to a wave.  QSVC_MQ_NARROW="<fraction>,<lanes>" (default off = "0,16").
     static const double narrow_frac = [] { const char* e = getenv("QSVC_MQ_NARROW"); return e ? atof(e) : 0.0; }();
     static const int narrow_lanes = [] { const char* e = getenv("QSVC_MQ_NARROW"); const char* q = e ? strchr(e, ',') : nullptr; int v = q ? atoi(q + 1) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
@@ -474,15 +477,10 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     // the MQ stage reads joboff[b] of every block, also when no block of the batch has a bit-plane (all-zero planes)
     if ((r = S.joboff_d.ensure(c, (size_t)ncb * 4))) return r;
     HIPCHK(c, hipMemcpyAsync(S.joboff_d.p, S.h_joboff.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
-    if (nwaves) {
-      if ((r = S.waves_d.ensure(c, (size_t)nwaves * 4))) return r;
-      if (!cm2) if ((r = S.flags.ensure(c, (size_t)nwaves * T1_FLAGS_WORDS * 64 * 4))) return r;
-      if ((r = S.segs_d.ensure(c, (njobs ? njobs : 1) * (size_t)T1_SEG_BYTES))) return r;
-      if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
-      if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
-      HIPCHK(c, hipMemcpyAsync(S.waves_d.p, S.h_waves.data(), (size_t)nwaves * 4, hipMemcpyHostToDevice, c->st));
-    }
-    if (cm2 && njobs) {  // job list: (block << 4 | plane) at joboff[block] + plane
+    if ((r = S.segs_d.ensure(c, (njobs ? njobs : 1) * (size_t)T1_SEG_BYTES))) return r;
+    if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
+    if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
+    if (njobs) {  // job list: (block << 4 | plane) at joboff[block] + plane
       S.h_jobs.resize(njobs);
       for (int b = 0; b < ncb; b++) {
         int nb = S.h_nbps[b] > 15 ? 15 : S.h_nbps[b];
@@ -495,14 +493,11 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
                     (const unsigned long long*)S.mags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p, want_dist ? 1 : 0);
       pf.end(c);
     }
-    for (int stage = cm2 ? 2 : 0; stage < 3; stage++) {
-      if (!nwaves && stage < 2) continue;
-      pf.begin(c, stage == 0 ? "j2k_t1_flags" : (stage == 1 ? "j2k_t1_cm" : "j2k_t1_mq"));
-      launch_t1_split(c->st, (const int*)S.waves_d.p, nwaves, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p,
-                      (const int*)S.order_d.p, nslots, (const uint32_t*)S.mags.p, (uint32_t*)S.flags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p,
-                      (uint8_t*)S.outbuf.p, J2K_OUTCAP, (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, stage);
-      pf.end(c);
-    }
+    pf.begin(c, "j2k_t1_mq");
+    launch_t1_mq(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p, (const int*)S.order_d.p, nslots,
+                 (const uint8_t*)S.segs_d.p, (const int*)S.cnt_d.p, (const long long*)S.dist_d.p, (uint8_t*)S.outbuf.p, J2K_OUTCAP,
+                 (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0);
+    pf.end(c);
   }
   S.res.resize(ncb);
   int err = 0;
@@ -728,14 +723,21 @@ int qsvc_j2k_dwt(qsvc_ctx* c, const uint8_t* plane, int H, int W, int reversible
   int r;
   if ((r = S.up_d.ensure(c, N))) return r;
   if ((r = S.coefA.ensure(c, N * 4))) return r;
-  if ((r = S.coefB.ensure(c, N * 4))) return r;
   if ((r = S.planes_d.ensure(c, sizeof(PlaneDesc)))) return r;
+  if ((r = S.err_d.ensure(c, 16))) return r;
   int L = levels;
   while (L > 0 && ((W >> (L - 1)) < 1 || (H >> (L - 1)) < 1)) L--;
-  PlaneDesc pd{0, (const uint8_t*)S.up_d.p, W, W, H, 0};
+  const int w1 = (W + 1) >> 1, h1 = (H + 1) >> 1, w2 = (w1 + 1) >> 1, h2 = (h1 + 1) >> 1;
+  if ((r = S.llA.ensure(c, ((size_t)((w1 + 3) & ~3) * h1 + 8) * 4 + 64))) return r;
+  if ((r = S.llB.ensure(c, ((size_t)((w2 + 3) & ~3) * h2 + 8) * 4 + 64))) return r;
+  PlaneDesc pd{0, {0, 0}, (const uint8_t*)S.up_d.p, W, W, H, 0};
   HIPCHK(c, hipMemcpyAsync(S.up_d.p, plane, N, hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipMemcpyAsync(S.planes_d.p, &pd, sizeof pd, hipMemcpyHostToDevice, c->st));
-  launch_dwt(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, S.coefA.p, S.coefB.p, L, reversible != 0);
+  HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
+  // the same tile kernel as the encoder's, with the subbands written to a Mallat-layout plane instead of the Tier-1 layout
+  if (L == 0) launch_level_shift(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, S.coefA.p, reversible != 0);
+  else launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, nullptr, L, reversible != 0, S.llA.p, S.llB.p, nullptr, nullptr,
+                        S.coefA.p, 6, 6, (int*)S.err_d.p);
   HIPCHK(c, hipMemcpyAsync(out, S.coefA.p, N * 4, hipMemcpyDeviceToHost, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   HIPCHK(c, hipGetLastError());

@@ -1,0 +1,325 @@
+// qsvc_amd/csrc/j2k_dwt.hip -- forward DWT of the JPEG 2000 stage (ITU-T T.800 Annex F) as ONE kernel per decomposition
+// level: a workgroup stages a haloed tile of the level's input in LDS, runs the vertical and then the horizontal lifting
+// there, and the four subbands leave the chip exactly once:
+//   * LL goes to the next level's input buffer (int16 for the reversible 5/3 path, float32 for 9/7), compact, its own stride;
+//   * HL / LH / HH (and LL of the last level) are quantised (Annex E) and written straight into the Tier-1 layout
+//     (`mags`: per code-block, per 4-row stripe column one u64 of 4 x (sign<<15 | 15-bit magnitude)), with the block's
+//     largest magnitude collected on the way -- there is no coefficient plane in HBM and no separate pack pass.
+// It replaces the part of the reference's external `kdu_compress` call (trunk/src/texture_compress_fb_j2k.py:183-195) that
+// transforms and quantises a component.  Bit-exactness: every lifting step is the restatement's expression (oracle/j2k_oracle.c)
+// with the same boundary rule -- a neighbour outside the signal is replaced by the neighbour on the other side, which is what
+// the restatement's index clamps amount to for 5/3 and 9/7 alike -- products and sums rounded separately (no FMA contraction).
+//
+// Tile: 64 x 32 samples of each subband = 128 x 64 input samples (+ halo 2 for 5/3, 4 for 9/7), staged as 32-bit words with an
+// odd row stride: the vertical steps run with lanes along a row, the horizontal steps with lanes along a column, both free of
+// LDS bank conflicts.  A lifting step only writes samples of one parity and only reads samples of the other, so each step is
+// a plain parallel map over the tile with one barrier after it.  No MFMA: there is no contraction here.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "j2k_kernels.h"
+
+namespace qsvc {
+
+#define DT_TW 64                    // subband columns per tile (= the widest code-block)
+#ifndef DT_TH
+#define DT_TH 32                    // subband rows per tile
+#endif
+#ifndef DT_UNROLL
+#define DT_UNROLL 4
+#endif
+#define DT_NC (2 * DT_TW + 8)       // staged input columns [2*tx0 - 4, 2*tx0 + 132): a multiple of 4 for wide loads
+#define DT_NCP (DT_NC + 1)          // odd row stride (words)
+#define DT_CL 4                     // columns left of the tile's first output column
+
+#define F97_ALPHA (-1.586134342059924f)
+#define F97_BETA (-0.052980118572961f)
+#define F97_GAMMA (0.882911075530934f)
+#define F97_DELTA (0.443506852043971f)
+#define F97_K (1.230174104914001f)
+
+template <bool REV> struct DwtTraits { typedef int T; typedef int16_t LL; static const int HALO = 2; };
+template <> struct DwtTraits<false> { typedef float T; typedef float LL; static const int HALO = 4; };
+
+// one lifting step on the element `x` with its two neighbours (already boundary-resolved)
+template <int STEP> __device__ __forceinline__ int lift53(int x, int lo, int hi) {
+  return STEP == 0 ? x - ((lo + hi) >> 1) : x + ((lo + hi + 2) >> 2);   // T.800 F.4.8.1 (floor by arithmetic shift)
+}
+template <int STEP> __device__ __forceinline__ float lift97(float x, float lo, float hi) {
+  const float c = STEP == 0 ? F97_ALPHA : (STEP == 1 ? F97_BETA : (STEP == 2 ? F97_GAMMA : F97_DELTA));
+  return __fadd_rn(x, __fmul_rn(c, __fadd_rn(lo, hi)));                 // T.800 F.4.8.2, rounded separately
+}
+
+// Vertical step STEP over the staged tile: updates rows of parity (STEP even -> odd rows), lanes along a row.
+template <bool REV, int STEP, int NR>
+__device__ __forceinline__ void sweep_v(typename DwtTraits<REV>::T* T, int tid, int g0, int n) {
+  typedef typename DwtTraits<REV>::T TT;
+  const int par = (STEP & 1) ^ 1;
+#pragma unroll DT_UNROLL
+  for (int idx = tid; idx < (NR / 2) * DT_NC; idx += 256) {
+    const int c = idx % DT_NC, l = 2 * (idx / DT_NC) + par, g = g0 + l;
+    if (g < 0 || g >= n) continue;
+    TT* p = T + l * DT_NCP + c;
+    const TT a = l > 0 ? p[-DT_NCP] : p[0], b = l + 1 < NR ? p[DT_NCP] : p[0];
+    const TT lo = g > 0 ? a : b, hi = g + 1 < n ? b : a;
+    if (REV) p[0] = (TT)lift53<STEP>((int)p[0], (int)lo, (int)hi); else p[0] = (TT)lift97<STEP>((float)p[0], (float)lo, (float)hi);
+  }
+}
+// Horizontal step over the output rows [r0, r0 + nrows) of the tile: lanes along a column (row stride is odd).
+template <bool REV, int STEP>
+__device__ __forceinline__ void sweep_h(typename DwtTraits<REV>::T* T, int tid, int r0, int nrows, int g0, int n) {
+  typedef typename DwtTraits<REV>::T TT;
+  const int par = (STEP & 1) ^ 1;
+#pragma unroll DT_UNROLL
+  for (int idx = tid; idx < nrows * (DT_NC / 2); idx += 256) {
+    const int r = r0 + idx % nrows, l = 2 * (idx / nrows) + par, g = g0 + l;
+    if (g < 0 || g >= n) continue;
+    TT* p = T + r * DT_NCP + l;
+    const TT a = l > 0 ? p[-1] : p[0], b = l + 1 < DT_NC ? p[1] : p[0];
+    const TT lo = g > 0 ? a : b, hi = g + 1 < n ? b : a;
+    if (REV) p[0] = (TT)lift53<STEP>((int)p[0], (int)lo, (int)hi); else p[0] = (TT)lift97<STEP>((float)p[0], (float)lo, (float)hi);
+  }
+}
+
+// OR over each aligned group of `span` lanes (span a power of two, 4 .. 64) with DPP row shifts / broadcasts: no LDS
+// round trips.  The LAST lane of every group ends up with the group's OR (other lanes hold partial values).
+__device__ __forceinline__ int wave_or_segments(int v, int span) {
+  v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);               // row_shr:1
+  v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);               // row_shr:2
+  if (span >= 8) v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+  if (span >= 16) v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  if (span >= 32) v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  if (span >= 64) v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+struct DwtArgs {
+  const PlaneDesc* planes;
+  const DwtSb* sbtab;        // [nplanes][1 + 3 L]: LL_L, then HL, LH, HH for d = L .. 1 (code-stream order)
+  int nsb;                   // 1 + 3 L
+  int lev, L;                // this launch: decomposition level lev + 1 of L
+  const void* llin;          // LL_lev (lev >= 1): compact planes at PlaneDesc::ll[(lev - 1) & 1]
+  void* llout;               // LL_{lev+1}
+  unsigned long long* mags;  // Tier-1 magnitudes, 1024 u64 per code-block
+  int* maxmag;               // per code-block OR of the magnitudes (atomicOr; zeroed by the caller): same bit length as the maximum
+  void* plane_out;           // OUT_PLANE: the Mallat-layout plane of the unit-test entry point (int32 / float32)
+  int cbwl, cbhl;            // log2 of the code-block size
+  int* err;
+};
+
+// LL stride of a plane's level-l low band (elements): a multiple of 4 so that rows stay 8 / 16-byte aligned
+__host__ __device__ __forceinline__ int dwt_ll_stride(int w) { return (w + 3) & ~3; }
+
+template <bool REV, bool FROM_U8, bool OUT_PLANE>
+__global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
+  typedef typename DwtTraits<REV>::T TT;
+  typedef typename DwtTraits<REV>::LL LLT;
+  constexpr int HALO = DwtTraits<REV>::HALO;
+  constexpr int NR = 2 * DT_TH + 2 * HALO;
+  __shared__ TT sT[NR * DT_NCP];
+  const int tid = threadIdx.x;
+  const PlaneDesc pd = a.planes[blockIdx.z];
+  int w = pd.W, h = pd.H;
+  for (int l = 0; l < a.lev; l++) { w = (w + 1) >> 1; h = (h + 1) >> 1; }
+  const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, hw = w >> 1, hh = h >> 1;
+  const int tx0 = blockIdx.x * DT_TW, ty0 = blockIdx.y * DT_TH;
+  if (tx0 >= lw || ty0 >= lh) return;                      // planes of one batch differ in size (luma / chroma)
+  const int gc0 = 2 * tx0 - DT_CL, gr0 = 2 * ty0 - HALO;   // global coordinates of the staged tile's origin
+
+  // ---- stage the tile: rows [gr0, gr0 + NR) x columns [gc0, gc0 + DT_NC), zero outside the signal -----------------------
+  {
+    const uint8_t* u = pd.src;
+    const LLT* lin = (const LLT*)a.llin + pd.ll[(a.lev - 1) & 1];
+    const int sstr = FROM_U8 ? pd.u8stride : dwt_ll_stride(w);
+    const bool wide = FROM_U8 ? ((((uintptr_t)u) & 3) == 0 && (sstr & 3) == 0) : true;
+    // all of a thread's wide loads are issued before the first one is unpacked (memory-level parallelism: ~10 per thread)
+    constexpr int NQ = NR * (DT_NC / 4), NIT = (NQ + 255) / 256;
+    typedef typename std::conditional<FROM_U8, uint32_t, typename std::conditional<REV, uint2, float4>::type>::type Raw;
+    Raw raw[NIT];
+    unsigned fast = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int idx = tid + it * 256, lr = idx / (DT_NC / 4), q = idx % (DT_NC / 4), gr = gr0 + lr, gc = gc0 + 4 * q;
+      if (idx < NQ && gr >= 0 && gr < h && gc >= 0 && gc + 3 < w && wide) {
+        fast |= 1u << it;
+        if (FROM_U8) raw[it] = *(const Raw*)(u + (size_t)gr * sstr + gc);
+        else raw[it] = *(const Raw*)(lin + (size_t)gr * sstr + gc);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int idx = tid + it * 256, lr = idx / (DT_NC / 4), q = idx % (DT_NC / 4), gr = gr0 + lr, gc = gc0 + 4 * q;
+      if (idx >= NQ) break;
+      TT v[4] = {0, 0, 0, 0};
+      if (fast & (1u << it)) {
+        if constexpr (FROM_U8) {
+          const uint32_t d = raw[it];
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = (TT)((int)((d >> (8 * k)) & 255) - 128);
+        } else if constexpr (REV) {
+          const uint2 d = raw[it];
+          v[0] = (TT)(int16_t)(d.x & 0xFFFF); v[1] = (TT)(int16_t)(d.x >> 16);
+          v[2] = (TT)(int16_t)(d.y & 0xFFFF); v[3] = (TT)(int16_t)(d.y >> 16);
+        } else {
+          const float4 d = raw[it];
+          v[0] = (TT)d.x; v[1] = (TT)d.y; v[2] = (TT)d.z; v[3] = (TT)d.w;
+        }
+      } else if (gr >= 0 && gr < h && gc + 3 >= 0 && gc < w) {  // picture edge or an unaligned source: sample by sample
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (gc + k >= 0 && gc + k < w)
+            v[k] = FROM_U8 ? (TT)((int)u[(size_t)gr * sstr + gc + k] - 128) : (TT)lin[(size_t)gr * sstr + gc + k];
+      }
+      TT* p = sT + lr * DT_NCP + 4 * q;
+#pragma unroll
+      for (int k = 0; k < 4; k++) p[k] = v[k];
+    }
+  }
+  __syncthreads();
+  // ---- vertical lifting, then horizontal lifting on the rows that are output ----------------------------------------------
+#ifndef DT_EXP_NOSWEEP
+  if (h >= 2) {
+    sweep_v<REV, 0, NR>(sT, tid, gr0, h); __syncthreads();
+    sweep_v<REV, 1, NR>(sT, tid, gr0, h); __syncthreads();
+    if (!REV) {
+      sweep_v<REV, 2, NR>(sT, tid, gr0, h); __syncthreads();
+      sweep_v<REV, 3, NR>(sT, tid, gr0, h); __syncthreads();
+      const float invK = 1.0f / F97_K;
+      for (int idx = tid; idx < NR * DT_NC; idx += 256) {  // low (even rows) * 1/K, high (odd rows) * K
+        const int l = idx / DT_NC, c = idx % DT_NC;
+        float* p = (float*)sT + l * DT_NCP + c;
+        p[0] = __fmul_rn(p[0], ((gr0 + l) & 1) ? F97_K : invK);
+      }
+      __syncthreads();
+    }
+  }
+  if (w >= 2) {
+    sweep_h<REV, 0>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+    sweep_h<REV, 1>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+    if (!REV) {
+      sweep_h<REV, 2>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+      sweep_h<REV, 3>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+      const float invK = 1.0f / F97_K;
+      for (int idx = tid; idx < 2 * DT_TH * DT_NC; idx += 256) {
+        const int r = HALO + idx % (2 * DT_TH), l = idx / (2 * DT_TH);
+        float* p = (float*)sT + r * DT_NCP + l;
+        p[0] = __fmul_rn(p[0], ((gc0 + l) & 1) ? F97_K : invK);
+      }
+      __syncthreads();
+    }
+  }
+#endif
+  // Sample (ry, rx) parity classes of the tile are now the subbands: (0,0) LL, (0,1) HL, (1,0) LH, (1,1) HH.
+  // A signal of one sample passes through as a low sample (the restatement's `n >= 2 ? lift : x`).
+  auto coef = [&](int ky, int kx, int ry, int rx) { return sT[(HALO + 2 * ky + ry) * DT_NCP + DT_CL + 2 * kx + rx]; };
+  const bool last = a.lev == a.L - 1;
+
+  if (OUT_PLANE) {  // unit-test form: the Mallat layout of the whole plane, 32-bit
+    TT* out = (TT*)a.plane_out + pd.off;
+    for (int idx = tid; idx < 4 * DT_TH * DT_TW; idx += 256) {
+      const int sub = idx / (DT_TH * DT_TW), ky = (idx / DT_TW) % DT_TH, kx = idx % DT_TW, ry = sub >> 1, rx = sub & 1;
+      const int y = ty0 + ky, x = tx0 + kx;
+      if (y >= (ry ? hh : lh) || x >= (rx ? hw : lw)) continue;
+      if (sub == 0 && !last) continue;
+      out[(size_t)(y + (ry ? lh : 0)) * pd.W + x + (rx ? lw : 0)] = coef(ky, kx, ry, rx);
+    }
+  }
+  // ---- LL -> next level's input (compact, 4 samples per thread-store) ----------------------------------------------------
+  if (!last) {
+    LLT* lout = (LLT*)a.llout + pd.ll[a.lev & 1];
+    const int ostr = dwt_ll_stride(lw);
+    for (int idx = tid; idx < DT_TH * (DT_TW / 4); idx += 256) {
+      const int ky = idx / (DT_TW / 4), kx = 4 * (idx % (DT_TW / 4)), y = ty0 + ky, x = tx0 + kx;
+      if (y >= lh || x >= ostr) continue;
+      TT v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = coef(ky, kx + k, 0, 0);   // columns in [lw, ostr) are padding, never read back
+      if (REV) {
+        bool big = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) big |= (x + k < lw) && ((int)v[k] > 32767 || (int)v[k] < -32768);
+        if (big) atomicOr(a.err, 1);  // cannot happen for 8-bit input through <= 10 levels at the guard bits in use
+        uint2 d;
+        d.x = ((uint32_t)(int)v[0] & 0xFFFF) | ((uint32_t)(int)v[1] << 16);
+        d.y = ((uint32_t)(int)v[2] & 0xFFFF) | ((uint32_t)(int)v[3] << 16);
+        *(uint2*)(lout + (size_t)y * ostr + x) = d;
+      } else {
+        *(float4*)(lout + (size_t)y * ostr + x) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+      }
+    }
+  }
+  if (OUT_PLANE) return;
+#ifdef DT_EXP_NOOUT
+  if (a.lev >= 0) return;
+#endif
+  // ---- HL, LH, HH (and the last LL): quantise, pack 4 rows of a stripe column, store into the block's Tier-1 layout ---------
+  const DwtSb* sbp = a.sbtab + (size_t)blockIdx.z * a.nsb;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int span = a.cbwl >= 6 ? 64 : (1 << a.cbwl);            // lanes of one code-block
+  const bool tall = (1 << a.cbhl) >= DT_TH;                      // the tile's stripes of a subband lie in one block row
+  for (int sub = last ? 0 : 1; sub < 4; sub++) {                 // wave-uniform (subband, stripe); lane = column
+    const int ry = sub >> 1, rx = sub & 1;
+    const int sbh = ry ? hh : lh, sbw = rx ? hw : lw;
+    const int x = tx0 + lane;
+    // code-stream order: LL_L first, then for d = L .. 1: HL, LH, HH; this level is d = lev + 1
+    const DwtSb sb = sbp[sub == 0 ? 0 : 1 + 3 * (a.L - 1 - a.lev) + (sub == 1 ? 0 : (sub == 2 ? 1 : 2))];
+    int acc = 0, accy = ty0;
+    auto flush = [&]() {  // OR over the lanes of each code-block (DPP, no LDS), one atomic per block
+      int v = wave_or_segments(acc, span);
+      // the group's last lane speaks for the block (it may itself lie beyond the subband's last column: its acc was 0)
+      if ((lane & (span - 1)) == span - 1 && v)
+        atomicOr(&a.maxmag[sb.first_cb + (accy >> a.cbhl) * sb.gx + (x >> a.cbwl)], v);
+      acc = 0;
+    };
+    for (int s = wv; s < DT_TH / 4; s += 4) {
+      const int y = ty0 + 4 * s;
+      if (y >= sbh) break;                                       // uniform
+      uint64_t word = 0;
+      if (x < sbw) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (y + k >= sbh) break;
+          const TT v = coef(4 * s + k, lane, ry, rx);
+          int mag, neg;
+          if (REV) { const int iv = (int)v; neg = iv < 0; mag = neg ? -iv : iv; }
+          else { const float fv = (float)v; mag = (int)floorf(__fdiv_rn(fabsf(fv), sb.delta)); neg = fv < 0.0f && mag; }  // T.800 E.1
+          acc |= mag;
+          word |= (uint64_t)((mag & 0x7FFF) | (neg << 15)) << (16 * k);
+        }
+        const int bx = x >> a.cbwl, by = y >> a.cbhl;
+        const size_t b = (size_t)sb.first_cb + (size_t)by * sb.gx + bx;
+        a.mags[b * 1024 + (size_t)(((y & ((1 << a.cbhl) - 1)) >> 2) * 64 + (x & ((1 << a.cbwl) - 1)))] = word;
+      }
+      accy = y;
+      if (!tall) flush();
+    }
+    if (tall) flush();
+  }
+}
+
+// Forward DWT of a batch of planes sharing L >= 1 levels.  mode 0: Tier-1 magnitudes; mode 1: Mallat plane (unit tests).
+void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, const DwtSb* d_sbtab, int L,
+                      bool reversible, void* llA, void* llB, unsigned long long* mags, int* maxmag, void* plane_out,
+                      int cbw_log2, int cbh_log2, int* err) {
+  int w = maxW, h = maxH;
+  for (int l = 0; l < L; l++) {
+    const int lw = (w + 1) >> 1, lh = (h + 1) >> 1;
+    DwtArgs a;
+    a.planes = d_planes; a.sbtab = d_sbtab; a.nsb = 1 + 3 * L; a.lev = l; a.L = L;
+    a.llin = (l & 1) ? llA : llB;    // LL_l lives in A for odd l, in B for even l >= 2
+    a.llout = (l & 1) ? llB : llA;   // LL_{l+1}
+    a.mags = mags; a.maxmag = maxmag; a.plane_out = plane_out; a.cbwl = cbw_log2; a.cbhl = cbh_log2; a.err = err;
+    dim3 grid((lw + DT_TW - 1) / DT_TW, (lh + DT_TH - 1) / DT_TH, nplanes), block(256);
+#define DWT_LAUNCH(REV, U8, PL) hipLaunchKernelGGL((k_dwt_tile<REV, U8, PL>), grid, block, 0, st, a)
+    if (plane_out) {
+      if (reversible) { if (l == 0) DWT_LAUNCH(true, true, true); else DWT_LAUNCH(true, false, true); }
+      else { if (l == 0) DWT_LAUNCH(false, true, true); else DWT_LAUNCH(false, false, true); }
+    } else {
+      if (reversible) { if (l == 0) DWT_LAUNCH(true, true, false); else DWT_LAUNCH(true, false, false); }
+      else { if (l == 0) DWT_LAUNCH(false, true, false); else DWT_LAUNCH(false, false, false); }
+    }
+#undef DWT_LAUNCH
+    w = lw; h = lh;
+  }
+}
+
+}  // namespace qsvc

@@ -7,7 +7,9 @@
 namespace qsvc {
 
 struct PlaneDesc {   // one image component plane of the batch
-  size_t off;        // element offset of the plane in the coefficient buffers (stride = W)
+  size_t off;        // element offset of the plane in a full-size 32-bit plane buffer (stride = W): planes without any
+                     // decomposition level, and the Mallat-layout output of the unit-test entry point
+  size_t ll[2];      // element offsets of this plane's compact low bands: [0] LL_1, LL_3, ... ; [1] LL_2, LL_4, ...
   const uint8_t* src; // source samples (device): 8-bit unsigned (level shift -128) or 16-bit signed (no shift)
   int u8stride;      // source row stride in samples
   int W, H;
@@ -26,20 +28,26 @@ struct CbOut {
   unsigned long long nsym;
 };
 
-// Tier-1 working set per code-block, lane-interleaved within a group of `lanes` blocks
-#define T1_MAGS_WORDS (16 * 64 * 2)               // u32 words per block: [stripe][x][half] (x lanes)
-#define T1_FLAGS_WORDS (18 * T1_FW)               // u32 words per block (x lanes)
+struct DwtSb {       // one subband of one plane as the DWT kernel addresses its code-blocks
+  int first_cb;      // index of the subband's first code-block in the batch
+  int gx;            // code-blocks per row
+  int Mb;
+  float delta;       // quantiser step (irreversible path)
+};
 
-void launch_dwt(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, void* A,
-                void* B, int levels, bool reversible);
-void launch_t1_pack(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef, uint32_t* mags,
-                    int* nbps, int* err, bool reversible, int lanes);
-void launch_t1_encode(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint32_t* mags, uint32_t* flags,
-                      uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist, int lanes);
-void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff,
-                     const int* order, int nslots,
-                     const uint32_t* mags, uint32_t* flags, uint8_t* segs, int* cnt, long long* dist, uint8_t* outbuf, int outcap,
-                     CbOut* res, int* pass_len, long long* pass_dist, int want_dist, int stage);
+// Tier-1 magnitudes: 1024 u64 per code-block, [stripe][x] = 4 x (sign << 15 | 15-bit magnitude) of rows 4s .. 4s+3
+#define T1_MAGS_BYTES (1024 * 8)
+
+// forward DWT, L >= 1 levels (j2k_dwt.hip); plane_out != nullptr selects the Mallat-plane form of the unit-test entry point
+void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, const DwtSb* d_sbtab, int L,
+                      bool reversible, void* llA, void* llB, unsigned long long* mags, int* maxmag, void* plane_out,
+                      int cbw_log2, int cbh_log2, int* err);
+// planes without a decomposition level: level shift into a 32-bit plane, then launch_t1_pack_blk
+void launch_level_shift(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, void* A, bool reversible);
+void launch_t1_nbps(hipStream_t st, const CbDesc* cbs, int ncb, int* nbps, int* err);
+void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int nslots,
+                  const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf, int outcap, CbOut* res, int* pass_len,
+                  long long* pass_dist, int want_dist);
 void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef,
                         unsigned long long* mags, int* nbps, int* err, bool reversible);
 void launch_t1_cm2(hipStream_t st, const int* jobs, int njobs, const CbDesc* cbs, const int* nbps, const unsigned long long* mags,

@@ -1,9 +1,8 @@
 // qsvc_amd/csrc/j2k_kernels.hip -- gfx950 kernels of the JPEG 2000 texture stage that replaces the
 // reference's external `kdu_compress` call (trunk/src/texture_compress_fb_j2k.py:183-195):
-//   * forward DWT, ITU-T T.800 Annex F: reversible 5/3 (int32) and irreversible 9/7 (float32),
-//     vertical pass then horizontal pass per level, in-place Mallat layout, batched over planes;
-//   * dead-zone quantiser (Annex E) + packing into the lane-interleaved Tier-1 layout;
-//   * EBCOT Tier-1 (Annex C + D): 64 code-blocks per wavefront, one per lane (t1_core.h);
+//   * (forward DWT + quantiser: j2k_dwt.hip; planes without any decomposition level go through k_level_shift +
+//     k_t1_pack_blk here);
+//   * EBCOT Tier-1 (Annex C + D): sample-parallel context modelling (t1_cm2.h) + MQ coder (t1_core.h);
 //   * gather of the code-block segments into one contiguous buffer for the host's Tier-2.
 // No MFMA: integer/bit work and short float lifting chains.
 #include <hip/hip_runtime.h>
@@ -14,90 +13,7 @@
 namespace qsvc {
 
 // ---------------------------------------------------------------------------------------------
-// DWT.  One thread per output coefficient of one 1-D pass; the lifting chain is re-evaluated per
-// output with the oracle's exact operation order (clamped neighbour indices = whole-sample
-// symmetric extension), products and sums rounded separately (no FMA contraction).
-#define F97_ALPHA (-1.586134342059924f)
-#define F97_BETA (-0.052980118572961f)
-#define F97_GAMMA (0.882911075530934f)
-#define F97_DELTA (0.443506852043971f)
-#define F97_K (1.230174104914001f)
-
-template <class Ld>
-__device__ __forceinline__ int dwt53_coef(const Ld& X, int k, int n) {  // T.800 F.4.8.1
-  int nl = (n + 1) >> 1, nh = n >> 1;
-  auto Hc = [&](int i) {
-    i = i < 0 ? 0 : (i >= nh ? nh - 1 : i);
-    int a = X(2 * i), b = (2 * i + 2 < n) ? X(2 * i + 2) : a;
-    return X(2 * i + 1) - ((a + b) >> 1);
-  };
-  if (k >= nl) return Hc(k - nl);
-  return X(2 * k) + ((Hc(k - 1) + Hc(k) + 2) >> 2);
-}
-template <class Ld>
-__device__ __forceinline__ float dwt97_coef(const Ld& X, int k, int n) {  // T.800 F.4.8.2
-  int nl = (n + 1) >> 1, nh = n >> 1;
-  auto E0 = [&](int i) { return X(2 * (i >= nl ? nl - 1 : i)); };
-  auto O1 = [&](int i) {
-    i = i < 0 ? 0 : (i >= nh ? nh - 1 : i);
-    return __fadd_rn(X(2 * i + 1), __fmul_rn(F97_ALPHA, __fadd_rn(E0(i), E0(i + 1))));
-  };
-  auto E1 = [&](int i) {
-    i = i >= nl ? nl - 1 : i;
-    return __fadd_rn(X(2 * i), __fmul_rn(F97_BETA, __fadd_rn(O1(i - 1), O1(i))));
-  };
-  auto O2 = [&](int i) {
-    i = i < 0 ? 0 : (i >= nh ? nh - 1 : i);
-    return __fadd_rn(O1(i), __fmul_rn(F97_GAMMA, __fadd_rn(E1(i), E1(i + 1))));
-  };
-  if (k >= nl) return __fmul_rn(O2(k - nl), F97_K);
-  float e2 = __fadd_rn(E1(k), __fmul_rn(F97_DELTA, __fadd_rn(O2(k - 1), O2(k))));
-  const float invK = 1.0f / F97_K;
-  return __fmul_rn(e2, invK);
-}
-
-// vertical pass of level `lev` (region hr x wr of each plane): src -> dst (same layout)
-template <bool REV, bool FROM_U8>
-__global__ void __launch_bounds__(256) k_dwt_v(const PlaneDesc* planes, const void* srcv, void* dstv, int lev) {
-  PlaneDesc pd = planes[blockIdx.z];
-  int wr = pd.W, hr = pd.H;
-  for (int l = 0; l < lev; l++) { wr = (wr + 1) >> 1; hr = (hr + 1) >> 1; }
-  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= wr || y >= hr) return;
-  size_t o = pd.off + (size_t)y * pd.W + x;
-  if (REV) {
-    const int32_t* s = (const int32_t*)srcv + pd.off;
-    const uint8_t* u = pd.src;
-    auto X = [&](int yy) {
-      if (!FROM_U8) return s[(size_t)yy * pd.W + x];
-      return pd.s16 ? (int)((const int16_t*)u)[(size_t)yy * pd.u8stride + x] : (int)u[(size_t)yy * pd.u8stride + x] - 128;
-    };
-    ((int32_t*)dstv)[o] = hr >= 2 ? dwt53_coef(X, y, hr) : X(y);
-  } else {
-    const float* s = (const float*)srcv + pd.off;
-    const uint8_t* u = pd.src;
-    auto X = [&](int yy) { return FROM_U8 ? (float)((int)u[(size_t)yy * pd.u8stride + x] - 128) : s[(size_t)yy * pd.W + x]; };
-    ((float*)dstv)[o] = hr >= 2 ? dwt97_coef(X, y, hr) : X(y);
-  }
-}
-template <bool REV>
-__global__ void __launch_bounds__(256) k_dwt_h(const PlaneDesc* planes, const void* srcv, void* dstv, int lev) {
-  PlaneDesc pd = planes[blockIdx.z];
-  int wr = pd.W, hr = pd.H;
-  for (int l = 0; l < lev; l++) { wr = (wr + 1) >> 1; hr = (hr + 1) >> 1; }
-  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= wr || y >= hr) return;
-  size_t row = pd.off + (size_t)y * pd.W;
-  if (REV) {
-    const int32_t* s = (const int32_t*)srcv + row;
-    auto X = [&](int xx) { return s[xx]; };
-    ((int32_t*)dstv)[row + x] = wr >= 2 ? dwt53_coef(X, x, wr) : X(x);
-  } else {
-    const float* s = (const float*)srcv + row;
-    auto X = [&](int xx) { return s[xx]; };
-    ((float*)dstv)[row + x] = wr >= 2 ? dwt97_coef(X, x, wr) : X(x);
-  }
-}
+// The forward DWT lives in j2k_dwt.hip (one LDS-tiled kernel per level, subbands written as Tier-1 magnitudes).
 // level 0 with no decomposition at all: just the level shift
 template <bool REV>
 __global__ void __launch_bounds__(256) k_level_shift(const PlaneDesc* planes, void* dstv) {
@@ -109,131 +25,14 @@ __global__ void __launch_bounds__(256) k_level_shift(const PlaneDesc* planes, vo
   else ((float*)dstv)[pd.off + (size_t)y * pd.W + x] = (float)v;
 }
 
-void launch_dwt(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, void* A,
-                void* B, int levels, bool reversible) {
-  dim3 block(64, 4);
-  if (levels == 0) {
-    dim3 grid((maxW + 63) / 64, (maxH + 3) / 4, nplanes);
-    if (reversible) hipLaunchKernelGGL(k_level_shift<true>, grid, block, 0, st, d_planes, A);
-    else hipLaunchKernelGGL(k_level_shift<false>, grid, block, 0, st, d_planes, A);
-    return;
-  }
-  int w = maxW, h = maxH;
-  for (int l = 0; l < levels; l++) {
-    dim3 grid((w + 63) / 64, (h + 3) / 4, nplanes);
-    // vertical: A (or the u8 source at level 0) -> B ; horizontal: B -> A
-    if (reversible) {
-      if (l == 0) hipLaunchKernelGGL((k_dwt_v<true, true>), grid, block, 0, st, d_planes, A, B, l);
-      else hipLaunchKernelGGL((k_dwt_v<true, false>), grid, block, 0, st, d_planes, A, B, l);
-      hipLaunchKernelGGL(k_dwt_h<true>, grid, block, 0, st, d_planes, B, A, l);
-    } else {
-      if (l == 0) hipLaunchKernelGGL((k_dwt_v<false, true>), grid, block, 0, st, d_planes, A, B, l);
-      else hipLaunchKernelGGL((k_dwt_v<false, false>), grid, block, 0, st, d_planes, A, B, l);
-      hipLaunchKernelGGL(k_dwt_h<false>, grid, block, 0, st, d_planes, B, A, l);
-    }
-    w = (w + 1) >> 1; h = (h + 1) >> 1;
-  }
+void launch_level_shift(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, void* A, bool reversible) {
+  dim3 block(64, 4), grid((maxW + 63) / 64, (maxH + 3) / 4, nplanes);
+  if (reversible) hipLaunchKernelGGL(k_level_shift<true>, grid, block, 0, st, d_planes, A);
+  else hipLaunchKernelGGL(k_level_shift<false>, grid, block, 0, st, d_planes, A);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Quantise + pack one code-block per workgroup into the lane-interleaved Tier-1 layout.
-template <bool REV>
-__global__ void __launch_bounds__(256) k_t1_pack(const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coefv,
-                                                  uint32_t* mags, int* nbps_out, int* err, int lanes) {
-  int b = blockIdx.x;
-  if (b >= ncb) return;
-  CbDesc cb = cbs[b];
-  PlaneDesc pd = planes[cb.plane];
-  int g = b / lanes, lane = b % lanes;
-  uint32_t* mg = mags + (size_t)g * T1_MAGS_WORDS * lanes + lane;
-  __shared__ int smax[256];
-  int x = threadIdx.x & 63, sq = threadIdx.x >> 6;
-  int mymax = 0;
-  for (int s = sq; s < 16; s += 4) {
-    uint64_t word = 0;
-    if (x < cb.w) {
-      for (int k = 0; k < 4; k++) {
-        int y = 4 * s + k;
-        if (y >= cb.h) break;
-        size_t i = pd.off + (size_t)(cb.y0 + y) * pd.W + cb.x0 + x;
-        int mag, neg;
-        if (REV) {
-          int v = ((const int32_t*)coefv)[i];
-          neg = v < 0; mag = neg ? -v : v;
-        } else {
-          float v = ((const float*)coefv)[i];
-          mag = (int)floorf(__fdiv_rn(fabsf(v), cb.delta));  // dead-zone quantiser, T.800 E.1
-          neg = v < 0.0f && mag;
-        }
-        mymax = mag > mymax ? mag : mymax;
-        word |= (uint64_t)((mag & 0x7FFF) | (neg << 15)) << (16 * k);
-      }
-    }
-    mg[(size_t)((s * 64 + x) * 2 + 0) * lanes] = (uint32_t)word;
-    mg[(size_t)((s * 64 + x) * 2 + 1) * lanes] = (uint32_t)(word >> 32);
-  }
-  smax[threadIdx.x] = mymax;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if ((int)threadIdx.x < o) smax[threadIdx.x] = smax[threadIdx.x] > smax[threadIdx.x + o] ? smax[threadIdx.x] : smax[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    int m = smax[0], nb = 0;
-    while (nb < 31 && (m >> nb)) nb++;
-    nbps_out[b] = nb > 15 ? 15 : nb;
-    if (nb > cb.Mb || nb > 15) atomicOr(err, 1);  // magnitude does not fit M_b / the 15-bit lane format
-  }
-}
-// The same for the 64-lane layout of the split Tier-1, one workgroup per (stripe, group of 64 blocks): coefficient rows are
-// read coalesced along x, the packed words go through an LDS transpose and leave as full 256-byte runs along the lane
-// index (the per-block form above scatters 4-byte stores 256 bytes apart: 12x write amplification in HBM).
-// maxmag[b] collects the block's largest magnitude (atomicMax; zeroed by the launcher), k_t1_nbps turns it into nbps.
-#define PK_ROW 65
-template <bool REV>
-__global__ void __launch_bounds__(256) k_t1_pack64(const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coefv,
-                                                    uint32_t* mags, int* maxmag) {
-  __shared__ uint32_t sT[128 * PK_ROW];  // [(x*2 + k)][lane]
-  __shared__ int smax[64];
-  const int s = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-  const int x = tid & 63, lq = tid >> 6;
-  if (tid < 64) smax[tid] = 0;
-  __syncthreads();
-  for (int l = lq; l < 64; l += 4) {
-    const int b = g * 64 + l;
-    uint64_t word = 0;
-    int mymax = 0;
-    if (b < ncb) {
-      const CbDesc cb = cbs[b];
-      if (x < cb.w && 4 * s < cb.h) {
-        const PlaneDesc pd = planes[cb.plane];
-        for (int k = 0; k < 4; k++) {
-          int y = 4 * s + k;
-          if (y >= cb.h) break;
-          size_t i = pd.off + (size_t)(cb.y0 + y) * pd.W + cb.x0 + x;
-          int mag, neg;
-          if (REV) {
-            int v = ((const int32_t*)coefv)[i];
-            neg = v < 0; mag = neg ? -v : v;
-          } else {
-            float v = ((const float*)coefv)[i];
-            mag = (int)floorf(__fdiv_rn(fabsf(v), cb.delta));  // dead-zone quantiser, T.800 E.1
-            neg = v < 0.0f && mag;
-          }
-          mymax = mag > mymax ? mag : mymax;
-          word |= (uint64_t)((mag & 0x7FFF) | (neg << 15)) << (16 * k);
-        }
-      }
-    }
-    sT[(x * 2 + 0) * PK_ROW + l] = (uint32_t)word;
-    sT[(x * 2 + 1) * PK_ROW + l] = (uint32_t)(word >> 32);
-    if (mymax) atomicMax(&smax[l], mymax);
-  }
-  __syncthreads();
-  uint32_t* mg = mags + (size_t)g * T1_MAGS_WORDS * 64 + (size_t)s * 128 * 64;
-  for (int i = tid; i < 128 * 64; i += 256) mg[i] = sT[(i >> 6) * PK_ROW + (i & 63)];
-  if (tid < 64 && g * 64 + tid < ncb && smax[tid]) atomicMax(&maxmag[g * 64 + tid], smax[tid]);
-}
+// largest magnitude of every block (collected by the DWT kernel) -> number of magnitude bit-planes
 __global__ void __launch_bounds__(256) k_t1_nbps(const CbDesc* cbs, int ncb, int* nbps, int* err) {
   int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= ncb) return;
@@ -242,239 +41,15 @@ __global__ void __launch_bounds__(256) k_t1_nbps(const CbDesc* cbs, int ncb, int
   nbps[b] = nb > 15 ? 15 : nb;
   if (nb > cbs[b].Mb || nb > 15) atomicOr(err, 1);  // magnitude does not fit M_b / the 15-bit lane format
 }
-void launch_t1_pack(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef, uint32_t* mags,
-                    int* nbps, int* err, bool reversible, int lanes) {
-  if (lanes == 64) {
-    hipMemsetAsync(nbps, 0, (size_t)ncb * 4, st);
-    dim3 grid(16, (ncb + 63) / 64);
-    if (reversible) hipLaunchKernelGGL(k_t1_pack64<true>, grid, dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps);
-    else hipLaunchKernelGGL(k_t1_pack64<false>, grid, dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps);
-    hipLaunchKernelGGL(k_t1_nbps, dim3((ncb + 255) / 256), dim3(256), 0, st, cbs, ncb, nbps, err);
-    return;
-  }
-  if (reversible) hipLaunchKernelGGL(k_t1_pack<true>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err, lanes);
-  else hipLaunchKernelGGL(k_t1_pack<false>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err, lanes);
+void launch_t1_nbps(hipStream_t st, const CbDesc* cbs, int ncb, int* nbps, int* err) {
+  hipLaunchKernelGGL(k_t1_nbps, dim3((ncb + 255) / 256), dim3(256), 0, st, cbs, ncb, nbps, err);
 }
 
 // ---------------------------------------------------------------------------------------------
-// EBCOT Tier-1: one wavefront = 64 code-blocks, one per lane (t1_core.h).
-//
-// Block state streams through an LDS window: per pass every flag row (66 words x 64 lanes) and every
-// stripe's magnitudes are brought in ONCE by LDS-DMA (global_load_lds, 256 contiguous bytes per
-// wave-instruction, no VGPR round trip), one stripe ahead of the stripe being coded, and each flag row is
-// written back once.  The coding loop itself touches only LDS and registers, so the serial per-lane chain
-// never waits on HBM.  LDS per wave: 4 flag-row slots (67.6 KB) + 2 magnitude buffers (64 KB) + coder
-// tables (3 KB): one workgroup per CU.
+// EBCOT Tier-1 (T.800 Annex C + D) in two kernels: sample-parallel context modelling (k_t1_cm2, t1_cm2.h: one wave per
+// (code-block, bit-plane), decisions as one byte each into per-(block, plane, pass) segments) and the MQ coder over those
+// segments (k_t1_mq, t1_core.h: one code-block per lane).
 __constant__ uint32_t c_mqtab[47] = T1_MQ_TABLE_INIT;
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-template <int LANES>
-struct T1LdsStore {
-  uint32_t* F;            // LDS [4][T1_FW][LANES]
-  uint32_t* M;            // LDS [2][128][LANES]
-  uint32_t* gflags;       // this group's flag words in HBM (lane-interleaved); already offset by lane
-  const uint32_t* gmags;  // this group's magnitude words in HBM; already offset by lane
-  int lane;
-  __device__ __forceinline__ uint32_t ld(int r, int c) const { return F[((r & 3) * T1_FW + c) * LANES + lane]; }
-  __device__ __forceinline__ void st(int r, int c, uint32_t v) { F[((r & 3) * T1_FW + c) * LANES + lane] = v; }
-  __device__ __forceinline__ void orr(int r, int c, uint32_t b) { F[((r & 3) * T1_FW + c) * LANES + lane] |= b; }
-  __device__ __forceinline__ uint64_t mag(int s, int x) const {
-    const uint32_t* m = M + ((s & 1) * 128 + x * 2) * LANES + lane;
-    return (uint64_t)m[0] | ((uint64_t)m[LANES] << 32);
-  }
-  __device__ __forceinline__ void dma_row(int r) {  // flag row r -> slot r&3
-    const uint32_t* g = gflags + (size_t)r * T1_FW * LANES;
-    uint32_t* l = F + (r & 3) * T1_FW * LANES;
-#pragma unroll 6
-    for (int c = 0; c < T1_FW; c++)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + c * LANES), (lds_ptr_t)(l + c * LANES), 4, 0, 0);
-  }
-  __device__ __forceinline__ void dma_mags(int s) {  // magnitudes of stripe s -> buffer s&1
-    const uint32_t* g = gmags + (size_t)s * 128 * LANES;
-    uint32_t* l = M + (s & 1) * 128 * LANES;
-#pragma unroll 8
-    for (int i = 0; i < 128; i++)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * LANES), (lds_ptr_t)(l + i * LANES), 4, 0, 0);
-  }
-  __device__ __forceinline__ void wb_row(int r) {  // slot r&3 -> flag row r in HBM
-    uint32_t* g = gflags + (size_t)r * T1_FW * LANES;
-    const uint32_t* l = F + (r & 3) * T1_FW * LANES + lane;
-#pragma unroll 6
-    for (int c = 0; c < T1_FW; c++) g[c * LANES] = l[c * LANES];
-  }
-  __device__ __forceinline__ void pass_begin(int nstripes) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the previous pass's write-backs
-    dma_row(0); dma_row(1); dma_row(2);
-    dma_mags(0);
-  }
-  __device__ __forceinline__ void stripe_begin(int s, int nstripes) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows <= s+2 and magnitudes of stripe s have landed
-    if (s + 1 < nstripes) { dma_row(s + 3); dma_mags(s + 1); }  // one stripe ahead; slot (s+3)&3 held row s-1
-  }
-  __device__ __forceinline__ void stripe_end(int s) { wb_row(s); }
-  __device__ __forceinline__ void pass_end(int nstripes) { wb_row(nstripes); wb_row(nstripes + 1); }
-};
-
-template <int LANES>
-__global__ void __launch_bounds__(LANES) k_t1_encode(const CbDesc* cbs, int ncb, const int* nbps_in, const uint32_t* mags,
-                                                      uint32_t* flags, uint8_t* outbuf, int outcap, CbOut* res, int* pass_len,
-                                                      long long* pass_dist, int want_dist) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint32_t* s_F = (uint32_t*)smem;                           // 4*66*LANES words
-  uint32_t* s_M = s_F + 4 * T1_FW * LANES;                   // 2*128*LANES words
-  uint32_t* s_mq = s_M + 2 * 128 * LANES;                    // 47 (padded to 64)
-  uint8_t* s_zc = (uint8_t*)(s_mq + 64);                     // 3*512
-  uint32_t* s_cx = (uint32_t*)(s_zc + 3 * 512);              // 19*LANES words
-  int lane = threadIdx.x, g = blockIdx.x, b = g * LANES + lane;
-  for (int i = lane; i < 47; i += LANES) s_mq[i] = c_mqtab[i];
-  for (int i = lane; i < 3 * 512; i += LANES) {
-    int c = i >> 9;
-    s_zc[i] = (uint8_t)t1_zc_from_nb(i & 511, c == 0 ? 0 : (c == 1 ? 1 : 3));
-  }
-  __syncthreads();
-  T1Lane t;
-  t.cx = s_cx + lane; t.cs = LANES;
-  t.mqtab = s_mq; t.zclut = s_zc;
-  t.w = 0; t.h = 0; t.orient = 0; t.nbps = 0;
-  t.out = outbuf; t.cap = 0;
-  if (b < ncb) {
-    CbDesc cb = cbs[b];
-    t.w = cb.w; t.h = cb.h; t.orient = cb.orient; t.nbps = nbps_in[b];
-    t.out = outbuf + (size_t)b * outcap; t.cap = outcap;
-  }
-  T1LdsStore<LANES> S;
-  S.F = s_F; S.M = s_M; S.lane = lane;
-  S.gflags = flags + (size_t)g * T1_FLAGS_WORDS * LANES + lane;
-  S.gmags = mags + (size_t)g * T1_MAGS_WORDS * LANES + lane;
-  // wave-uniform scan bounds
-  int top = t.nbps - 1, wmax = t.nbps ? t.w : 0, hmax = t.nbps ? t.h : 0;
-  for (int o = LANES / 2; o >= 1; o >>= 1) {
-    int a = __shfl_xor(top, o, 64), c = __shfl_xor(wmax, o, 64), d = __shfl_xor(hmax, o, 64);
-    top = a > top ? a : top; wmax = c > wmax ? c : wmax; hmax = d > hmax ? d : hmax;
-  }
-  top = __builtin_amdgcn_readfirstlane(top); wmax = __builtin_amdgcn_readfirstlane(wmax); hmax = __builtin_amdgcn_readfirstlane(hmax);
-  T1Result r;
-  int bb = b < ncb ? b : 0;
-  r.pass_len = pass_len + (size_t)bb * T1_MAXPASS;
-  r.pass_dist = want_dist ? pass_dist + (size_t)bb * T1_MAXPASS : nullptr;
-  t1_encode_lane(t, S, top, wmax, hmax, want_dist != 0, r);
-  if (b < ncb) {
-    CbOut o;
-    o.len = r.len; o.npasses = r.npasses; o.nbps = r.nbps; o.overflow = r.overflow; o.nsym = r.nsym;
-    res[b] = o;
-  }
-}
-template <int LANES>
-static void launch_t1_encode_n(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint32_t* mags, uint32_t* flags,
-                               uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist) {
-  const int smem = ((4 * T1_FW + 2 * 128) * LANES + 64) * 4 + 3 * 512 + 19 * LANES * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_t1_encode<LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
-  int ngroups = (ncb + LANES - 1) / LANES;
-  hipLaunchKernelGGL(k_t1_encode<LANES>, dim3(ngroups), dim3(LANES), smem, st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res,
-                     pass_len, pass_dist, want_dist);
-}
-void launch_t1_encode(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const uint32_t* mags, uint32_t* flags,
-                      uint8_t* outbuf, int outcap, CbOut* res, int* pass_len, long long* pass_dist, int want_dist, int lanes) {
-  switch (lanes) {
-    case 8: launch_t1_encode_n<8>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
-    case 16: launch_t1_encode_n<16>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
-    case 32: launch_t1_encode_n<32>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
-    default: launch_t1_encode_n<64>(st, cbs, ncb, nbps, mags, flags, outbuf, outcap, res, pass_len, pass_dist, want_dist); break;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Split Tier-1: bit-plane-parallel context modelling + MQ kernel (t1_core.h "Split form").
-// A CM wave = (group of 64 code-blocks, bit-plane p): its 64 lanes model plane p of 64 different blocks.
-// The start-of-plane flag words are a pure function of the magnitudes, produced by k_t1_flags_init
-// (thread per flag word), so all ~10 planes of all blocks run concurrently: ~10x the waves of the fused
-// kernel, each with 1/10 of its serial chain.  Decisions (cx | d<<5, one byte) go to per-(block, plane, pass)
-// segments; k_t1_mq runs the MQ coder of each block over its segments, 16 blocks per wave.
-struct T1GlobalStore {  // flag words and magnitudes straight from HBM/L2, lane stride 64
-  uint32_t* flags;
-  const uint32_t* mags;
-  // Neighbour updates are fire-and-forget L2 atomics (no round trip in the lane's dependent chain); flag loads
-  // and stores are agent-scope so they meet those atomics in L2 instead of a stale L1 line.
-  __device__ __forceinline__ uint32_t ld(int r, int c) const {
-    return __hip_atomic_load(flags + (r * T1_FW + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __device__ __forceinline__ void st(int r, int c, uint32_t v) {
-    __hip_atomic_store(flags + (r * T1_FW + c) * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __device__ __forceinline__ void orr(int r, int c, uint32_t b) {
-    (void)__hip_atomic_fetch_or(flags + (r * T1_FW + c) * 64, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __device__ __forceinline__ uint64_t mag(int s, int x) const {
-    const uint32_t* m = mags + (size_t)((s * 64 + x) * 2) * 64;
-    return (uint64_t)m[0] | ((uint64_t)m[64] << 32);
-  }
-  __device__ __forceinline__ void pass_begin(int) {}
-  __device__ __forceinline__ void stripe_begin(int, int) {}
-  __device__ __forceinline__ void stripe_end(int) {}
-  __device__ __forceinline__ void pass_end(int) {}
-};
-
-// waves[k] = group << 8 | plane.  One thread per (flag word, lane) of a CM wave.
-__global__ void __launch_bounds__(256) k_t1_flags_init(const int* waves, const CbDesc* cbs, int ncb, const int* nbps_in,
-                                                        const uint32_t* mags, uint32_t* flags) {
-  int wv = blockIdx.y, g = waves[wv] >> 8, p = waves[wv] & 255;
-  int idx = blockIdx.x * 256 + threadIdx.x;  // word*64 + lane
-  if (idx >= T1_FLAGS_WORDS * 64) return;
-  int lane = idx & 63, word = idx >> 6, r = word / T1_FW, c = word % T1_FW;
-  int b = g * 64 + lane;
-  uint32_t f = 0;
-  if (b < ncb && r >= 1 && r <= 16 && c >= 1 && c <= 64 && p < nbps_in[b]) {
-    CbDesc cb = cbs[b];
-    int s = r - 1, x = c - 1, nstr = (cb.h + 3) >> 2;
-    if (x < cb.w && s < nstr) {
-      const uint32_t* mg = mags + (size_t)g * T1_MAGS_WORDS * 64 + lane;
-      auto M = [&](int ss, int xx) {
-        const uint32_t* m = mg + (size_t)((ss * 64 + xx) * 2) * 64;
-        return (uint64_t)m[0] | ((uint64_t)m[64] << 32);
-      };
-      f = t1_initial_flag(M, s, x, p, nstr, cb.w);
-    }
-  }
-  flags[(size_t)wv * T1_FLAGS_WORDS * 64 + idx] = f;
-}
-
-template <int CML>  // lanes per CM wave: 64, 32 or 16 consecutive blocks of the group
-__global__ void __launch_bounds__(CML) k_t1_cm(const int* waves, const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
-                                               const uint32_t* mags, uint32_t* flags, uint8_t* segs, int* cnt, long long* dist,
-                                               int want_dist) {
-  __shared__ uint8_t s_zc[3 * 512];
-  int wv = blockIdx.x, g = waves[wv] >> 8, p = waves[wv] & 255;
-  int lane = blockIdx.y * CML + threadIdx.x, b = g * 64 + lane;
-  for (int i = threadIdx.x; i < 3 * 512; i += CML) {
-    int c = i >> 9;
-    s_zc[i] = (uint8_t)t1_zc_from_nb(i & 511, c == 0 ? 0 : (c == 1 ? 1 : 3));
-  }
-  __syncthreads();
-  int w = 0, h = 0, orient = 0, nb = 0;
-  if (b < ncb) { CbDesc cb = cbs[b]; w = cb.w; h = cb.h; orient = cb.orient; nb = nbps_in[b]; }
-  const bool mine = p < nb;
-  int wmax = mine ? w : 0, hmax = mine ? h : 0;
-  for (int o = CML / 2; o >= 1; o >>= 1) {
-    int a = __shfl_xor(wmax, o, 64), d = __shfl_xor(hmax, o, 64);
-    wmax = a > wmax ? a : wmax; hmax = d > hmax ? d : hmax;
-  }
-  wmax = __builtin_amdgcn_readfirstlane(wmax); hmax = __builtin_amdgcn_readfirstlane(hmax);
-  T1GlobalStore S;
-  S.flags = flags + (size_t)wv * T1_FLAGS_WORDS * 64 + lane;
-  S.mags = mags + (size_t)g * T1_MAGS_WORDS * 64 + lane;
-  size_t job = mine ? (size_t)joboff[b] + p : 0;
-  int c3[3]; long long d3[3];
-  t1_cm_plane(S, s_zc, segs + job * T1_SEG_BYTES, p, w, h, orient, mine ? nb : 0, wmax, hmax, want_dist != 0, c3, d3);
-  if (mine) {
-    for (int k = 0; k < 3; k++) { cnt[job * 3 + k] = c3[k]; if (want_dist) dist[job * 3 + k] = d3[k]; }
-  }
-}
 
 template <int T1_MQ_LANES>
 __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
@@ -537,25 +112,16 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
   }
 }
 
-void launch_t1_split(hipStream_t st, const int* waves, int nwaves, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff,
-                     const int* order, int nslots, const uint32_t* mags, uint32_t* flags, uint8_t* segs, int* cnt, long long* dist, uint8_t* outbuf, int outcap,
-                     CbOut* res, int* pass_len, long long* pass_dist, int want_dist, int stage) {
-  if (stage == 0) {
-    hipLaunchKernelGGL(k_t1_flags_init, dim3((T1_FLAGS_WORDS * 64 + 255) / 256, nwaves), dim3(256), 0, st, waves, cbs, ncb, nbps, mags, flags);
-  } else if (stage == 1) {
-    static const int cl = [] { const char* e = getenv("QSVC_CM_LANES"); int v = e ? atoi(e) : 64; return (v == 16 || v == 32) ? v : 64; }();
-    if (cl == 16) hipLaunchKernelGGL(k_t1_cm<16>, dim3(nwaves, 4), dim3(16), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
-    else if (cl == 32) hipLaunchKernelGGL(k_t1_cm<32>, dim3(nwaves, 2), dim3(32), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
-    else hipLaunchKernelGGL(k_t1_cm<64>, dim3(nwaves, 1), dim3(64), 0, st, waves, cbs, ncb, nbps, joboff, mags, flags, segs, cnt, dist, want_dist);
-  } else {
-    // lanes (code-blocks) per MQ wave: 16 gives the shortest chain for one sequence alone, 64 the best throughput when several
-    // encodes share the GPU (fewer issue slots per decision).  Read at every launch so a host can switch between the two.
-    const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 16; return (v == 4 || v == 8 || v == 32 || v == 64) ? v : 16; }();
-    long long* pdp = want_dist ? pass_dist : nullptr;
+void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int nslots,
+                  const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf, int outcap, CbOut* res, int* pass_len,
+                  long long* pass_dist, int want_dist) {
+  // lanes (code-blocks) per MQ wave: 16 gives the shortest chain for one sequence alone, 64 the best throughput when several
+  // encodes share the GPU (fewer issue slots per decision).  Read at every launch so a host can switch between the two.
+  const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 16; return (v == 4 || v == 8 || v == 32 || v == 64) ? v : 16; }();
+  long long* pdp = want_dist ? pass_dist : nullptr;
 #define MQ_LAUNCH(N) hipLaunchKernelGGL(k_t1_mq<N>, dim3((nslots + N - 1) / N), dim3(N), 0, st, cbs, ncb, nbps, joboff, order, nslots, segs, cnt, dist, outbuf, outcap, res, pass_len, pdp)
-    switch (ml) { case 4: MQ_LAUNCH(4); break; case 8: MQ_LAUNCH(8); break; case 32: MQ_LAUNCH(32); break; case 64: MQ_LAUNCH(64); break; default: MQ_LAUNCH(16); }
+  switch (ml) { case 4: MQ_LAUNCH(4); break; case 8: MQ_LAUNCH(8); break; case 32: MQ_LAUNCH(32); break; case 64: MQ_LAUNCH(64); break; default: MQ_LAUNCH(16); }
 #undef MQ_LAUNCH
-  }
 }
 
 // ---------------------------------------------------------------------------------------------

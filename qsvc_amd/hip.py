@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqsvc_hip.so")
+LIB_PATH = os.environ.get("QSVC_HIP_LIB") or os.path.join(_HERE, "libqsvc_hip.so")  # the override is a kernel-tuning hook (A/B builds)
 
 LOW, HIGH, PRED = 0, 1, 2
 MOTION_RAW, MOTION_FILTERED = 0, 1
