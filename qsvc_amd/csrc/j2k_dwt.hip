@@ -10,7 +10,7 @@
 // with the same boundary rule -- a neighbour outside the signal is replaced by the neighbour on the other side, which is what
 // the restatement's index clamps amount to for 5/3 and 9/7 alike -- products and sums rounded separately (no FMA contraction).
 //
-// Tile: 64 x 32 samples of each subband = 128 x 64 input samples (+ halo 2 for 5/3, 4 for 9/7), staged as 32-bit words with an
+// Tile: 64 x 16 samples of each subband = 128 x 32 input samples (+ halo 2 for 5/3, 4 for 9/7), staged as 32-bit words with an
 // odd row stride: the vertical steps run with lanes along a row, the horizontal steps with lanes along a column, both free of
 // LDS bank conflicts.  A lifting step only writes samples of one parity and only reads samples of the other, so each step is
 // a plain parallel map over the tile with one barrier after it.  No MFMA: there is no contraction here.
@@ -22,7 +22,7 @@ namespace qsvc {
 
 #define DT_TW 64                    // subband columns per tile (= the widest code-block)
 #ifndef DT_TH
-#define DT_TH 32                    // subband rows per tile
+#define DT_TH 16                    // subband rows per tile (16: 19.7 KB of LDS, 8 workgroups per CU; measured faster than 32)
 #endif
 #ifndef DT_UNROLL
 #define DT_UNROLL 4
@@ -176,7 +176,6 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
   }
   __syncthreads();
   // ---- vertical lifting, then horizontal lifting on the rows that are output ----------------------------------------------
-#ifndef DT_EXP_NOSWEEP
   if (h >= 2) {
     sweep_v<REV, 0, NR>(sT, tid, gr0, h); __syncthreads();
     sweep_v<REV, 1, NR>(sT, tid, gr0, h); __syncthreads();
@@ -207,7 +206,6 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
       __syncthreads();
     }
   }
-#endif
   // Sample (ry, rx) parity classes of the tile are now the subbands: (0,0) LL, (0,1) HL, (1,0) LH, (1,1) HH.
   // A signal of one sample passes through as a low sample (the restatement's `n >= 2 ? lift : x`).
   auto coef = [&](int ky, int kx, int ry, int rx) { return sT[(HALO + 2 * ky + ry) * DT_NCP + DT_CL + 2 * kx + rx]; };
@@ -248,9 +246,6 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
     }
   }
   if (OUT_PLANE) return;
-#ifdef DT_EXP_NOOUT
-  if (a.lev >= 0) return;
-#endif
   // ---- HL, LH, HH (and the last LL): quantise, pack 4 rows of a stripe column, store into the block's Tier-1 layout ---------
   const DwtSb* sbp = a.sbtab + (size_t)blockIdx.z * a.nsb;
   const int lane = tid & 63, wv = tid >> 6;
