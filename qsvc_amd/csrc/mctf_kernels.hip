@@ -11,6 +11,12 @@
 
 namespace qsvc {
 
+__device__ __forceinline__ uint64_t ld8u(const uint8_t* p) {  // unaligned 8-byte load
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ME pyramid level: thread per coefficient, 64x4 tile per workgroup (row-contiguous stores).
 template <class T>
@@ -50,18 +56,106 @@ __global__ void __launch_bounds__(64) k_me_search(MeArgs a) {
 #pragma unroll
     for (int k = 0; k < 18; k++) sad[k] = 0;
   }
+  // 18 sums over the block's LPB lanes with DPP row shifts (a DPP row = 16 lanes = one 8x8 block's lanes when LPB = 16): the
+  // LAST lane of the block ends up with the totals; no LDS round trips (the xor-shuffle form costs 18 x log2(LPB) ds_bpermute)
 #pragma unroll
   for (int k = 0; k < 18; k++) {
     int v = sad[k];
-#pragma unroll
-    for (int off = LPB / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    if (LPB == 64) {
+      v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+      v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    }
     sad[k] = v;
   }
-  if (live && lane == 0) me_block_store(a, i, by, bx, sad, pvx, pvy, nvx, nvy);
+  if (live && lane == LPB - 1) me_block_store(a, i, by, bx, sad, pvx, pvy, nvx, nvy);
+}
+// 8x8 blocks, packed form: one lane per block ROW (8 lanes per block, 8 blocks per wave).  A lane holds its row of the predicted
+// picture and, per reference, the three displaced rows it can meet (mv.y - 1 .. mv.y + 1); the nine candidates are the 3 x 3
+// (row, byte offset) windows of those, each compared with v_sad_u8 / v_sad_u16 on packed samples.  18 sums over the block's 8
+// lanes by DPP row shifts.  Blocks whose windows leave the picture take the per-sample path with the border rule (Q1/Q2, H3).
+template <class T> struct MeRow;
+template <> struct MeRow<uint8_t> {
+  uint32_t w[2];
+  __device__ __forceinline__ void load(const uint8_t* p) { uint64_t v = ld8u(p); w[0] = (uint32_t)v; w[1] = (uint32_t)(v >> 32); }
+  __device__ __forceinline__ int sad(const MeRow& o) const {
+    return (int)__builtin_amdgcn_sad_u8(w[1], o.w[1], __builtin_amdgcn_sad_u8(w[0], o.w[0], 0u));
+  }
+};
+template <> struct MeRow<int16_t> {
+  uint32_t w[4];  // 8 samples, biased by 0x8000 so that the unsigned SAD equals the signed one
+  __device__ __forceinline__ void load(const int16_t* p) {
+    uint64_t a = ld8u((const uint8_t*)p), b = ld8u((const uint8_t*)(p + 4));
+    w[0] = (uint32_t)a ^ 0x80008000u; w[1] = (uint32_t)(a >> 32) ^ 0x80008000u;
+    w[2] = (uint32_t)b ^ 0x80008000u; w[3] = (uint32_t)(b >> 32) ^ 0x80008000u;
+  }
+  __device__ __forceinline__ int sad(const MeRow& o) const {
+    uint32_t s = __builtin_amdgcn_sad_u16(w[0], o.w[0], 0u);
+    s = __builtin_amdgcn_sad_u16(w[1], o.w[1], s);
+    s = __builtin_amdgcn_sad_u16(w[2], o.w[2], s);
+    return (int)__builtin_amdgcn_sad_u16(w[3], o.w[3], s);
+  }
+};
+template <class T>
+__global__ void __launch_bounds__(64) k_me_search8(MeArgs a) {
+  const int sub = threadIdx.x >> 3, row = threadIdx.x & 7;
+  const int bx = blockIdx.x * 8 + sub, by = blockIdx.y, i = blockIdx.z;
+  const bool live = bx < a.nbx;
+  MePlane<T> r0, r1, pr;
+  me_block_setup<T>(a, i, r0, r1, pr);
+  int pvx = 0, pvy = 0, nvx = 0, nvy = 0;
+  int sad[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) sad[k] = 0;
+  if (live) {
+    me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
+    const int y0 = by * 8, x0 = bx * 8, y = y0 + row;
+    const bool inner = y0 + pvy - 1 >= 0 && y0 + pvy + 9 <= r0.g.H && x0 + pvx - 1 >= 0 && x0 + pvx + 9 <= r0.g.W &&
+                       y0 + nvy - 1 >= 0 && y0 + nvy + 9 <= r0.g.H && x0 + nvx - 1 >= 0 && x0 + nvx + 9 <= r0.g.W;
+    if (inner) {
+      MeRow<T> p, w;
+      p.load(pr.snap + (size_t)y * pr.stride + x0);
+      const int cand[9][2] = QSVC_ME_CANDS;
+#pragma unroll
+      for (int c = 0; c < 9; c++) {
+        w.load(r0.snap + (size_t)(y + pvy + cand[c][0]) * r0.stride + x0 + pvx + cand[c][1]);
+        sad[2 * c] = p.sad(w);
+        w.load(r1.snap + (size_t)(y + nvy - cand[c][0]) * r1.stride + x0 + nvx - cand[c][1]);
+        sad[2 * c + 1] = p.sad(w);
+      }
+    } else {
+      const int cand[9][2] = QSVC_ME_CANDS;
+      for (int k = 0; k < 8; k++) {
+        const int pv = pr.in(y, x0 + k);
+        for (int c = 0; c < 9; c++) {
+          int d0 = pv - r0.at(y + pvy + cand[c][0], x0 + k + pvx + cand[c][1]);
+          int d1 = pv - r1.at(y + nvy - cand[c][0], x0 + k + nvx - cand[c][1]);
+          sad[2 * c] += d0 < 0 ? -d0 : d0;
+          sad[2 * c + 1] += d1 < 0 ? -d1 : d1;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 18; k++) {  // lane 7 of each group of 8 ends up with the block's total
+    int v = sad[k];
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    sad[k] = v;
+  }
+  if (live && row == 7) me_block_store(a, i, by, bx, sad, pvx, pvy, nvx, nvy);
 }
 void launch_me_search(hipStream_t st, const MeArgs& a) {
   dim3 block(64);
-  if (a.g.bs * a.g.bs <= 64) {
+  if (a.g.bs == 8) {
+    dim3 grid((a.nbx + 7) / 8, a.nby, a.g.nB);
+    if (a.l == 0) hipLaunchKernelGGL(k_me_search8<uint8_t>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(k_me_search8<int16_t>, grid, block, 0, st, a);
+  } else if (a.g.bs * a.g.bs <= 64) {
     dim3 grid((a.nbx + 3) / 4, a.nby, a.g.nB);
     if (a.l == 0) hipLaunchKernelGGL((k_me_search<uint8_t, 16>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_me_search<int16_t, 16>), grid, block, 0, st, a);
@@ -77,11 +171,6 @@ void launch_me_search(hipStream_t st, const MeArgs& a) {
 // they share one MC block, so the two displaced reference runs are two unaligned 8-byte loads when they lie inside
 // the picture (the common case); runs that touch the replicate border fall back to the per-pixel border rule
 // (Q1/Q2).  The odd picture is read and the high picture written 8 bytes at a time.  LDS histograms as before.
-__device__ __forceinline__ uint64_t ld8u(const uint8_t* p) {  // unaligned 8-byte load
-  uint64_t v;
-  __builtin_memcpy(&v, p, 8);
-  return v;
-}
 __global__ void __launch_bounds__(256) k_pred_luma8(PredArgs a) {
   __shared__ unsigned h[2][256];
   const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -227,6 +316,100 @@ __global__ void __launch_bounds__(256) k_pred_chroma(PredArgs a) {
     if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;
   }
 }
+// ---------------------------------------------------------------------------------------------
+// Chroma x2 interpolation of whole pictures (decorrelate.cpp:610-648 = one level of truncating 5/3 synthesis with zero high
+// bands): 4 output samples per thread, u8 (averages of u8 stay in 0..255).  The prediction / update tiles below then read the
+// up-sampled chroma like luma instead of re-interpolating it in every footprint.
+__global__ void __launch_bounds__(256) k_chroma_up(const uint8_t* frames, LevelGeom g, int mul, uint8_t* cup) {
+  const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+  const int pic = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
+  if (x0 >= g.W || y >= g.H) return;
+  const uint8_t* u = frame_c(frames, g, mul * pic, c);
+  const int cw = g.W / 2, k2 = x0 >> 1;
+  const int c0 = chroma_up_col(u, cw, y, k2, g.H);
+  const int c1 = k2 + 1 < cw ? chroma_up_col(u, cw, y, k2 + 1, g.H) : c0;
+  const int c2 = k2 + 2 < cw ? chroma_up_col(u, cw, y, k2 + 2, g.H) : c1;
+  const int o0 = c0, o1 = x0 + 2 < g.W ? (c0 + c1) >> 1 : c0, o2 = c1, o3 = x0 + 4 < g.W ? (c1 + c2) >> 1 : c1;
+  uint8_t* d = cup + ((size_t)blockIdx.z * g.H + y) * g.W + x0;
+  if ((g.W & 3) == 0) {
+    *(uint32_t*)d = (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16) | ((uint32_t)o3 << 24);
+  } else {
+    d[0] = (uint8_t)o0; d[1] = (uint8_t)o1;
+    if (x0 + 2 < g.W) { d[2] = (uint8_t)o2; d[3] = (uint8_t)o3; }
+  }
+}
+void launch_chroma_up(hipStream_t st, const uint8_t* frames, const LevelGeom& g, int mul, int count, uint8_t* cup) {
+  if (count > 0)
+    hipLaunchKernelGGL(k_chroma_up, dim3((g.W / 4 + 64) / 64, (g.H + 3) / 4, count * 2), dim3(64, 4), 0, st, frames, g, mul, cup);
+}
+
+// 8 consecutive samples of one row of a bordered u8 plane displaced by a motion vector: one unaligned 8-byte load when the run
+// lies inside the picture, the per-sample border rule (Q1/Q2) otherwise
+__device__ __forceinline__ uint64_t ref_run8(const uint8_t* r, const LevelGeom& g, int y, int x) {
+  if (y >= 0 && y < g.H && x >= 0 && x + 8 <= g.W) return ld8u(r + (size_t)y * g.W + x);
+  const BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+  uint64_t v = 0;
+  for (int k = 0; k < 8; k++) v |= (uint64_t)luma_b(r, bg, y, x + k) << (8 * k);
+  return v;
+}
+// Chroma prediction from the up-sampled planes, block size a multiple of 8, picture tiled by the block grid: the 20-row footprint
+// of a 32x8 tile is cut into runs of 8 samples that share one MC block (80 columns from 2*i0 - 8: one run per thread).
+#define PC8_FW 80
+__global__ void __launch_bounds__(256) k_pred_chroma8(PredArgs a) {
+  __shared__ int16_t sP[PC_FH][PC8_FW];
+  __shared__ int16_t sL[PC_FH][PC_TW];
+  const LevelGeom& g = a.g;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int i = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
+  const int i0 = blockIdx.x * PC_TW, j0 = blockIdx.y * PC_TH;
+  const int cw = g.W / 2, chh = g.H / 2;
+  const int xb = 2 * i0 - 8, yb = 2 * j0 - 2;
+  if (tid < PC_FH * (PC8_FW / 8)) {
+    const int ry = tid / (PC8_FW / 8), run = tid % (PC8_FW / 8), yy = yb + ry, xx = xb + 8 * run;
+    uint64_t p = 0;  // 8 prediction samples, one byte each (0..255)
+    if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
+      const size_t plane = (size_t)g.H * g.W, fld = (size_t)g.BY * g.BX;
+      const uint8_t* r0 = a.cup + ((size_t)i * 2 + (c - 1)) * plane;
+      const uint8_t* r1 = a.cup + ((size_t)(i + 1) * 2 + (c - 1)) * plane;
+      const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)(yy / g.bs) * g.BX + xx / g.bs;
+      const uint64_t p0 = ref_run8(r0, g, yy + m[fld], xx + m[0]);
+      const uint64_t p1 = ref_run8(r1, g, yy + m[3 * fld], xx + m[2 * fld]);
+      // per byte (a + b) >> 1 without carries between bytes (decorrelate.cpp:99-107)
+      p = (p0 & p1) + (((p0 ^ p1) & 0xFEFEFEFEFEFEFEFEull) >> 1);
+    }
+    int16_t* d = &sP[ry][8 * run];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = (int16_t)((p >> (8 * k)) & 255);
+  }
+  __syncthreads();
+  for (int k = tid; k < PC_FH * PC_TW; k += 256) {
+    int ry = k / PC_TW, ci = i0 + k % PC_TW;
+    int yy = yb + ry;
+    int v = 0;
+    if (yy >= 0 && yy < g.H && ci < cw) {
+      auto row = [&](int xx) { return (int)sP[ry][xx - xb]; };
+      v = a53_low(row, ci, g.W);
+    }
+    sL[ry][k % PC_TW] = (int16_t)v;
+  }
+  __syncthreads();
+  const int ci = i0 + (tid & (PC_TW - 1)), cj = j0 + tid / PC_TW;
+  if (ci < cw && cj < chh) {
+    const int lx = tid & (PC_TW - 1);
+    auto col = [&](int yy) { return (int)sL[yy - yb][lx]; };
+    int ll = (int16_t)a53_low(col, cj, g.H);
+    size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh + (size_t)cj * cw + ci;
+    size_t off = (size_t)i * g.F + coff;
+    if (a.odd_out) {
+      a.odd_out[(size_t)(2 * i + 1) * g.F + coff] = (uint8_t)correlate_sample(a.high[off], ll, a.types[i]);
+    } else {
+      int o = frame_c(a.frames, g, 2 * i + 1, c)[(size_t)cj * cw + ci];
+      int val = iclamp(o - ll, -128, 127);
+      a.high[off] = (uint8_t)(val + 128);
+    }
+    if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;
+  }
+}
 // Q7: the chroma margin state picture i leaves behind (one launch per picture, in order)
 __global__ void __launch_bounds__(256) k_pred_margin(PredArgs a, int i) {
   size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -255,7 +438,9 @@ void launch_predict(hipStream_t st, const PredArgs& a) {
   }
   if (g.bs % 8 == 0) hipLaunchKernelGGL(k_pred_luma8, dim3((g.W + 511) / 512, (g.H + 3) / 4, g.nB), block, 0, st, a);
   else hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);
-  hipLaunchKernelGGL(k_pred_chroma, dim3((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, g.nB * 2), block, 0, st, a);
+  const dim3 cgrid((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, g.nB * 2);
+  if (a.cup && !a.margin && g.bs % 8 == 0 && g.W % 8 == 0) hipLaunchKernelGGL(k_pred_chroma8, cgrid, block, 0, st, a);
+  else hipLaunchKernelGGL(k_pred_chroma, cgrid, block, 0, st, a);
   if (a.odd_out) return;
   size_t per_pic = (size_t)4 * g.BY * g.BX;
   int nblk = (int)((per_pic + 255) / 256);
@@ -264,11 +449,7 @@ void launch_predict(hipStream_t st, const PredArgs& a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// update: thread per target sample (ordered gather), all even pictures of the level at once.
-__global__ void __launch_bounds__(256) k_upd_luma(UpdArgs a) {
-  int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
-  if (x < a.g.W && y < a.g.H) upd_luma_thread(a, x, y, j);
-}
+// update.  General chroma form (any geometry): thread per target sample of the footprint, ordered gather.
 // Chroma: same 32x8 tiling as k_pred_chroma.  Tiles out of reach of the top-left quadrant (Q3) or without any
 // contributing B picture are a plain copy; otherwise the updated full-resolution samples of the footprint are
 // gathered once into LDS and the chroma/2 analysis runs out of LDS.
@@ -323,11 +504,263 @@ __global__ void __launch_bounds__(256) k_upd_chroma(UpdArgs a) {
     a.low[(size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci] = (uint8_t)(int16_t)a53_low(col, cj, g.H);
   }
 }
+// ---------------------------------------------------------------------------------------------
+// update, tiled: the reference's in-place scatter (update.cpp:85-146) done as a scatter INTO AN LDS TILE OF TARGETS.
+// One wave owns a tile of the even picture; it walks the source blocks of the B picture in the reference's raster order
+// (by, bx) and, for every block whose displaced footprint meets the tile, its 64 lanes apply that block's pixels to the tile
+// (read-modify-write in LDS with update.cpp:93-115's float operations).  Within one block the targets are distinct (one
+// vector per block), and the LDS operations of a wave are performed in program order, so every target sees its sources in
+// exactly the reference's order -- which is what the saturation needs -- while the candidate scan costs a few
+// scalar operations per block instead of a gather per target.  Targets ON the picture border collect everything that the
+// reference's clip() folds onto them, several per block and in (y, x) order: those few cells are left out of the scatter and
+// evaluated by the ordered gather (update_gather, mctf_core.h) afterwards.
+#define UPD_STAGE_REACH 16   // largest |mv| for which the source region of a workgroup's targets is staged in LDS
+// One side (one B picture's PREV or NEXT field) of the update of a wave's target tile [ty0, ty0+TH) x [tx0, tx0+TW).
+template <int TW, int TH>
+struct UpdScatter {
+  int by0, bx0, nbx, n;   // candidate source blocks: those within `reach` of the tile
+  int dy[2], dx[2];       // this lane's candidates' vectors (candidate k = 64 r + lane), fetched before anything waits
+  // The candidates' vectors are requested up front: the latency overlaps with the staging of the tile and of the residues.
+  __device__ __forceinline__ void plan(int ty0, int tx0, const int16_t* mvx, const int16_t* mvy, int BY, int BX, int bs, int Hs, int Ws,
+                                       int reach, int lane) {
+    const int Hl = imin(Hs, BY * bs), Wl = imin(Ws, BX * bs);
+    const int sy_lo = imax(ty0 - reach, 0), sy_hi = imin(ty0 + TH - 1 + reach, Hl - 1);
+    const int sx_lo = imax(tx0 - reach, 0), sx_hi = imin(tx0 + TW - 1 + reach, Wl - 1);
+    n = 0; by0 = bx0 = 0; nbx = 1;
+    dy[0] = dy[1] = dx[0] = dx[1] = 0;
+    if (sy_hi < sy_lo || sx_hi < sx_lo) return;
+    by0 = sy_lo / bs; bx0 = sx_lo / bs; nbx = sx_hi / bs - bx0 + 1; n = (sy_hi / bs - by0 + 1) * nbx;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int k = 64 * r + lane;
+      if (k < n) {
+        const size_t o = (size_t)(by0 + k / nbx) * BX + bx0 + k % nbx;
+        dy[r] = mvy[o]; dx[r] = mvx[o];
+      }
+    }
+  }
+  // reg: the residues of rows [ry0, ..) x columns [rx0, ..), row stride RW, or nullptr (then `h`, the B picture's plane, is read).
+  __device__ __forceinline__ void run(uint8_t* tile, const uint8_t* reg, int ry0, int rx0, int RW, int ty0, int tx0, const uint8_t* h,
+                                      int hstride, const int16_t* mvx, const int16_t* mvy, int BX, int bs, int Hs, int Ws, int H, int W,
+                                      float uf, int lane) {
+    const int lbs = 31 - __builtin_clz(bs);
+    const bool pow2 = (1 << lbs) == bs;
+    // 64 candidates at a time are tested against the tile in parallel; the hits are visited in ascending order = the reference's
+    // raster order of blocks, all 64 lanes applying one block's pixels (distinct targets) to the tile.
+    for (int base = 0; base < n; base += 64) {
+      const int k = base + lane;
+      const bool valid = k < n;
+      const int by = by0 + (valid ? k / nbx : 0), bx = bx0 + (valid ? k % nbx : 0);
+      int cdy, cdx;
+      if (base == 0) { cdy = dy[0]; cdx = dx[0]; }
+      else if (base == 64) { cdy = dy[1]; cdx = dx[1]; }
+      else { cdy = valid ? (int)mvy[(size_t)by * BX + bx] : 0; cdx = valid ? (int)mvx[(size_t)by * BX + bx] : 0; }
+      const int y0 = by * bs, x0 = bx * bs;
+      const bool hit = valid && !(y0 + cdy > ty0 + TH - 1 || y0 + bs - 1 + cdy < ty0 || x0 + cdx > tx0 + TW - 1 || x0 + bs - 1 + cdx < tx0);
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const int hdy = __builtin_amdgcn_readlane(cdy, l), hdx = __builtin_amdgcn_readlane(cdx, l);
+        const int hy0 = __builtin_amdgcn_readlane(y0, l), hx0 = __builtin_amdgcn_readlane(x0, l);
+        for (int p = lane; p < bs * bs; p += 64) {
+          const int py = pow2 ? p >> lbs : p / bs, px = pow2 ? p & (bs - 1) : p % bs;
+          const int sy = hy0 + py, sx = hx0 + px;
+          const int t_y = sy + hdy, t_x = sx + hdx, ly = t_y - ty0, lx = t_x - tx0;
+          if (sy < Hs && sx < Ws && t_y > 0 && t_y < H - 1 && t_x > 0 && t_x < W - 1 && (unsigned)ly < (unsigned)TH && (unsigned)lx < (unsigned)TW) {
+            const int r = (reg ? (int)reg[(sy - ry0) * RW + (sx - rx0)] : (int)h[(size_t)sy * hstride + sx]) - 128;
+            uint8_t* t = tile + ly * TW + lx;
+            *t = (uint8_t)upd_one((int)*t, r, uf);
+          }
+        }
+      }
+    }
+  }
+};
+// residues of rows [ry0, ry0+RH) x columns [rx0, rx0+RW) of a B picture's plane into LDS, 4 bytes per thread-load (all threads)
+template <int RW, int RH>
+__device__ __forceinline__ void upd_stage_region(uint8_t* reg, int ry0, int rx0, const uint8_t* h, int hstride, int Hs, int tid) {
+  for (int q = tid; q < RH * (RW / 4); q += 256) {
+    const int ly = q / (RW / 4), lx = 4 * (q % (RW / 4)), y = ry0 + ly, x = rx0 + lx;
+    uint32_t v = 0x80808080u;
+    if (y >= 0 && y < Hs && x >= 0 && x + 3 < hstride) v = *(const uint32_t*)(h + (size_t)y * hstride + x);
+    *(uint32_t*)(reg + ly * RW + lx) = v;
+  }
+}
+#define UL_TW 64
+#define UL_TH 16   // per wave; a workgroup of 4 waves covers 64 x 64 luma targets
+__global__ void __launch_bounds__(256) k_upd_luma_tile(UpdArgs a) {
+  constexpr int RW = UL_TW + 2 * UPD_STAGE_REACH, RH = 4 * UL_TH + 2 * UPD_STAGE_REACH;
+  __shared__ __attribute__((aligned(16))) uint8_t sT[4][UL_TH * UL_TW];
+  __shared__ __attribute__((aligned(16))) uint8_t sR[2][RH * RW];
+  const LevelGeom& g = a.g;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, j = blockIdx.z;
+  const int tx0 = blockIdx.x * UL_TW, wy0 = blockIdx.y * (4 * UL_TH), ty0 = wy0 + wv * UL_TH;
+  uint8_t* tile = sT[wv];
+  UpdSide s[2];
+  upd_sides(a, j, s);
+  const uint8_t* src = frame_y(a.frames, g, a.src_mul * j);
+  uint8_t* dst = a.low + (size_t)(a.dst_mul * j) * g.F;
+  const bool wide = (g.W & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 3) == 0;
+  const bool live = ty0 < g.H;  // wave-uniform
+  UpdScatter<UL_TW, UL_TH> sc[2];
+  for (int q = 0; q < 2; q++) {
+    sc[q].n = 0;
+    if (live && s[q].high) sc[q].plan(ty0, tx0, s[q].mvx, s[q].mvy, g.BY, g.BX, g.bs, g.H, g.W, a.reach, lane);
+  }
+  // the tile: 4 samples per lane-load (16 lanes per row)
+  if (live)
+    for (int q = lane; q < UL_TH * (UL_TW / 4); q += 64) {
+      const int ly = q / (UL_TW / 4), lx = 4 * (q % (UL_TW / 4)), y = ty0 + ly, x = tx0 + lx;
+      uint32_t v = 0;
+      if (y < g.H && x < g.W) {
+        if (wide) v = *(const uint32_t*)(src + (size_t)y * g.W + x);
+        else for (int k = 0; k < 4 && x + k < g.W; k++) v |= (uint32_t)src[(size_t)y * g.W + x + k] << (8 * k);
+      }
+      *(uint32_t*)(tile + ly * UL_TW + lx) = v;
+    }
+  // both sides' source regions for the whole workgroup (block-uniform conditions)
+  const bool staged = a.reach <= UPD_STAGE_REACH && (g.W & 3) == 0;
+  const int ry0 = wy0 - UPD_STAGE_REACH, rx0 = tx0 - UPD_STAGE_REACH;
+  if (staged) {
+    for (int q = 0; q < 2; q++)
+      if (s[q].high && (((uintptr_t)s[q].high) & 3) == 0) upd_stage_region<RW, RH>(sR[q], ry0, rx0, s[q].high, g.W, g.H, tid);
+    __syncthreads();
+  }
+  if (!live) return;
+  if (s[0].high || s[1].high) {
+    for (int q = 0; q < 2; q++)
+      if (s[q].high) {
+        const uint8_t* reg = staged && (((uintptr_t)s[q].high) & 3) == 0 ? sR[q] : nullptr;
+        sc[q].run(tile, reg, ry0, rx0, RW, ty0, tx0, s[q].high, g.W, s[q].mvx, s[q].mvy, g.BX, g.bs, g.H, g.W, g.H, g.W, a.uf, lane);
+      }
+    // cells on the picture border: ordered gather, the border cells of the tile spread over the lanes (a picture row: one
+    // cell per lane; a picture column: the tile's rows over the first lanes)
+    auto border_cell = [&](int y, int x) {
+      int v = src[(size_t)y * g.W + x];
+      for (int k = 0; k < 2; k++)
+        if (s[k].high) {
+          const uint8_t* h = s[k].high;
+          auto R = [&](int sy, int sx) { return (int)h[(size_t)sy * g.W + sx] - 128; };
+          v = update_gather(v, R, s[k].mvx, s[k].mvy, g.BY, g.BX, g.bs, g.H, g.W, g.H, g.W, a.reach, y, x, a.uf);
+        }
+      tile[(y - ty0) * UL_TW + (x - tx0)] = (uint8_t)v;
+    };
+    for (int e = 0; e < 2; e++) {  // picture rows 0 and H-1
+      const int y = e ? g.H - 1 : 0, x = tx0 + lane;
+      if (y >= ty0 && y < ty0 + UL_TH && x < g.W) border_cell(y, x);
+    }
+    for (int e = 0; e < 2; e++) {  // picture columns 0 and W-1 (corners are done)
+      const int x = e ? g.W - 1 : 0, y = ty0 + lane;
+      if (x >= tx0 && x < tx0 + UL_TW && lane < UL_TH && y > 0 && y < g.H - 1) border_cell(y, x);
+    }
+  }
+  for (int q = lane; q < UL_TH * (UL_TW / 4); q += 64) {
+    const int ly = q / (UL_TW / 4), lx = 4 * (q % (UL_TW / 4)), y = ty0 + ly, x = tx0 + lx;
+    if (y >= g.H || x >= g.W) continue;
+    const uint32_t v = *(const uint32_t*)(tile + ly * UL_TW + lx);
+    if (wide) *(uint32_t*)(dst + (size_t)y * g.W + x) = v;
+    else for (int k = 0; k < 4 && x + k < g.W; k++) dst[(size_t)y * g.W + x + k] = (uint8_t)(v >> (8 * k));
+  }
+}
+// Chroma: the targets are the up-sampled planes (update.cpp:472-503), the sources the half-resolution residue in the top-left
+// quadrant (Q3), and the stored picture is the chroma/2 analysis of the result (update.cpp:632-643).  The 20 x 80 footprint of a
+// 32x8 output tile is the LDS target tile; each of the four waves owns five of its rows for the scatter.
+__global__ void __launch_bounds__(256) k_upd_chroma_tile(UpdArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t sP[PC_FH * PC8_FW];
+  constexpr int RW = PC8_FW + 2 * UPD_STAGE_REACH, RH = PC_FH + 2 * UPD_STAGE_REACH;
+  __shared__ __attribute__((aligned(16))) uint8_t sR[2][RH * RW];
+  __shared__ int16_t sL[PC_FH][PC_TW];
+  const LevelGeom& g = a.g;
+  const int tid = threadIdx.y * 64 + threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int j = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
+  const int i0 = blockIdx.x * PC_TW, j0 = blockIdx.y * PC_TH;
+  const int cw = g.W / 2, chh = g.H / 2;
+  const int xb = 2 * i0 - 8, yb = 2 * j0 - 2;
+  const uint8_t* u = frame_c(a.frames, g, a.src_mul * j, c);
+  const size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh;
+  UpdSide s[2];
+  upd_sides(a, j, s);
+  const int ci = i0 + (tid & (PC_TW - 1)), cj = j0 + tid / PC_TW;
+  const bool untouched = (!s[0].high && !s[1].high) || yb >= chh + a.reach || 2 * i0 - 2 >= cw + a.reach;  // workgroup-uniform
+  if (untouched) {
+    if (ci < cw && cj < chh) a.low[(size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci] = u[(size_t)cj * cw + ci];
+    return;
+  }
+  constexpr int SR = PC_FH / 4;  // footprint rows per wave
+  uint8_t* tile = sP + wv * SR * PC8_FW;
+  const int ty0 = yb + wv * SR;
+  const uint8_t* up = a.cup + ((size_t)j * 2 + (c - 1)) * g.H * g.W;
+  UpdScatter<PC8_FW, SR> sc[2];
+  for (int q = 0; q < 2; q++) {
+    sc[q].n = 0;
+    if (s[q].high) sc[q].plan(ty0, xb, s[q].mvx, s[q].mvy, g.BY, g.BX, g.bs, chh, cw, a.reach, lane);
+  }
+  for (int q = lane; q < SR * (PC8_FW / 8); q += 64) {   // W % 8 == 0 on this path: runs are inside or outside as a whole
+    const int ly = q / (PC8_FW / 8), lx = 8 * (q % (PC8_FW / 8)), y = ty0 + ly, x = xb + lx;
+    uint64_t v = 0;
+    if (y >= 0 && y < g.H && x >= 0 && x < g.W) v = *(const uint64_t*)(up + (size_t)y * g.W + x);
+    *(uint64_t*)(tile + ly * PC8_FW + lx) = v;
+  }
+  const bool staged = a.reach <= UPD_STAGE_REACH;  // cw % 4 == 0 and the chroma planes are 4-byte aligned on this path
+  const int ry0 = yb - UPD_STAGE_REACH, rx0 = xb - UPD_STAGE_REACH;
+  if (staged) {
+    for (int q = 0; q < 2; q++)
+      if (s[q].high && (((uintptr_t)(s[q].high + coff)) & 3) == 0) upd_stage_region<RW, RH>(sR[q], ry0, rx0, s[q].high + coff, cw, chh, tid);
+    __syncthreads();
+  }
+  for (int q = 0; q < 2; q++)
+    if (s[q].high) {
+      const uint8_t* reg = staged && (((uintptr_t)(s[q].high + coff)) & 3) == 0 ? sR[q] : nullptr;
+      sc[q].run(tile, reg, ry0, rx0, RW, ty0, xb, s[q].high + coff, cw, s[q].mvx, s[q].mvy, g.BX, g.bs, chh, cw, g.H, g.W, a.uf, lane);
+    }
+  {
+    auto border_cell = [&](int y, int x) {
+      int v = up[(size_t)y * g.W + x];
+      for (int k = 0; k < 2; k++)
+        if (s[k].high) {
+          const uint8_t* h = s[k].high + coff;
+          auto R = [&](int sy, int sx) { return (int)h[(size_t)sy * cw + sx] - 128; };
+          v = update_gather(v, R, s[k].mvx, s[k].mvy, g.BY, g.BX, g.bs, g.H, g.W, chh, cw, a.reach, y, x, a.uf);
+        }
+      tile[(y - ty0) * PC8_FW + (x - xb)] = (uint8_t)v;
+    };
+    for (int e = 0; e < 2; e++) {  // picture rows 0 and H-1: 80 cells, two rounds of lanes
+      const int y = e ? g.H - 1 : 0;
+      if (y < ty0 || y >= ty0 + SR) continue;  // uniform
+      for (int x = xb + lane; x < xb + PC8_FW; x += 64)
+        if (x >= 0 && x < g.W) border_cell(y, x);
+    }
+    for (int e = 0; e < 2; e++) {  // picture columns 0 and W-1
+      const int x = e ? g.W - 1 : 0, y = ty0 + lane;
+      if (x >= xb && x < xb + PC8_FW && lane < SR && y > 0 && y < g.H - 1) border_cell(y, x);
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < PC_FH * PC_TW; k += 256) {
+    int ry = k / PC_TW, cx = i0 + k % PC_TW;
+    int yy = yb + ry;
+    int v = 0;
+    if (yy >= 0 && yy < g.H && cx < cw) {
+      auto row = [&](int xx) { return (int)sP[ry * PC8_FW + xx - xb]; };
+      v = a53_low(row, cx, g.W);
+    }
+    sL[ry][k % PC_TW] = (int16_t)v;
+  }
+  __syncthreads();
+  if (ci < cw && cj < chh) {
+    const int lx = tid & (PC_TW - 1);
+    auto col = [&](int yy) { return (int)sL[yy - yb][lx]; };
+    a.low[(size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci] = (uint8_t)(int16_t)a53_low(col, cj, g.H);
+  }
+}
 void launch_update(hipStream_t st, const UpdArgs& a) {
   const LevelGeom& g = a.g;
   dim3 block(64, 4);
-  hipLaunchKernelGGL(k_upd_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB + 1), block, 0, st, a);
-  hipLaunchKernelGGL(k_upd_chroma, dim3((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, (g.nB + 1) * 2), block, 0, st, a);
+  const dim3 cgrid((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, (g.nB + 1) * 2);
+  hipLaunchKernelGGL(k_upd_luma_tile, dim3((g.W + UL_TW - 1) / UL_TW, (g.H + 4 * UL_TH - 1) / (4 * UL_TH), g.nB + 1), dim3(256), 0, st, a);
+  if (a.cup && g.W % 8 == 0) hipLaunchKernelGGL(k_upd_chroma_tile, cgrid, block, 0, st, a);
+  else hipLaunchKernelGGL(k_upd_chroma, cgrid, block, 0, st, a);
 }
 
 // max |component| of a motion buffer -> *out (int, pre-zeroed)

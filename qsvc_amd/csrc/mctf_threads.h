@@ -103,6 +103,7 @@ struct PredArgs {
   // `odd_out` (= the frames buffer itself: un_update put the even pictures at 2i) is written instead.
   uint8_t* odd_out;       // nullptr = analysis
   const uint8_t* types;   // [nB] 'I' / 'B' (synthesis only)
+  const uint8_t* cup;     // [nB+1][2][H][W] u8: chroma x2 interpolation of every even picture (launch_chroma_up), or nullptr
 };
 // what correlate stores for one sample: the picture itself for 'I', clip(residue + prediction) for 'B'
 QHD int correlate_sample(int h, int p, int type) { return type == 'I' ? h : iclamp(h - 128 + p, 0, 255); }
@@ -190,6 +191,7 @@ struct UpdArgs {
   int reach;               // >= max |mv component| over every field used
   int src_mul, dst_mul;    // even picture j is frames[src_mul*j] and goes to low[dst_mul*j]: (2,1) update low_{t-1} -> low_t,
                            // (1,2) un_update low_t -> the even pictures of low_{t-1}
+  const uint8_t* cup;      // [nB+1][2][H][W] u8: chroma x2 interpolation of even picture j (launch_chroma_up), or nullptr
 };
 struct UpdSide {  // one contribution to even picture j
   const uint8_t* high;  // frame base of the B picture, or nullptr

@@ -98,7 +98,7 @@ void qsvc_destroy(qsvc_ctx* c) {
   for (auto& b : c->snap) b.release();
   c->mvtmp[0].release(); c->mvtmp[1].release();
   for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); }
-  c->margin.release();
+  c->margin.release(); c->cup.release();
   if (c->comm) qsvc_comm_destroy(c);
   c->scal.release(); c->tmp16[0].release(); c->tmp16[1].release();
   j2k_release(c);
@@ -283,6 +283,15 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   return QSVC_OK;
 }
 
+// chroma x2 planes of the even pictures frames[mul*k], k <= nB (mctf_kernels.hip: k_chroma_up)
+static int make_cup(qsvc_ctx* c, const LevelGeom& g, const uint8_t* frames, int mul, const uint8_t** out) {
+  int r = c->cup.ensure(c, (size_t)(g.nB + 1) * 2 * g.H * g.W);
+  if (r) return r;
+  launch_chroma_up(c->st, frames, g, mul, g.nB + 1, (uint8_t*)c->cup.p);
+  *out = (const uint8_t*)c->cup.p;
+  return QSVC_OK;
+}
+
 // entropy() of entropy.cpp:20-34, op for op (float accumulate, double log).
 static float entropy256(const uint32_t* count) {
   float e = 0.0f;
@@ -316,7 +325,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   PredArgs a;
   a.g = g; a.frames = (const uint8_t*)c->lv[t - 1].low.p; a.mv = (const int16_t*)lv.mv_raw.p;
   a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = (unsigned*)lv.hist.p;
-  a.margin = nullptr; a.odd_out = nullptr; a.types = nullptr;
+  a.margin = nullptr; a.odd_out = nullptr; a.types = nullptr; a.cup = nullptr;
   lv.ragged = (g.H % bs || g.W % bs);
   if (lv.ragged) {  // Q7: the chroma margins carry state from picture to picture
     if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
@@ -324,6 +333,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   }
   Prof pf;
   pf.begin(c, "predict");
+  if (!lv.ragged && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
   launch_predict(c->st, a);
   pf.end(c);
   HIPCHK(c, hipMemcpyAsync(lv.mv_filt.p, lv.mv_raw.p, mvbytes, hipMemcpyDeviceToDevice, c->st));
@@ -387,8 +397,10 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
     a.halo_mv[s] = lv.halo[s] ? (const int16_t*)((const uint8_t*)lv.halo[s] + g.F) : nullptr;
     a.halo_type[s] = lv.halo[s] ? halo_types[s][0] : 0;
   }
+  a.cup = nullptr;
   Prof pf;
   pf.begin(c, "update");
+  if ((r = make_cup(c, g, a.frames, a.src_mul, &a.cup))) return r;
   launch_update(c->st, a);
   pf.end(c);
   HIPCHK(c, hipGetLastError());
@@ -449,8 +461,10 @@ int qsvc_un_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   a.mv = (const int16_t*)lv.mv_filt.p; a.types = (const uint8_t*)c->tmp16[0].p; a.low = (uint8_t*)out.low.p;
   a.uf = -uf; a.reach = reach; a.src_mul = 1; a.dst_mul = 2;
   for (int s = 0; s < 2; s++) { a.halo_high[s] = nullptr; a.halo_mv[s] = nullptr; a.halo_type[s] = 0; }
+  a.cup = nullptr;
   Prof pf;
   pf.begin(c, "un_update");
+  if ((r = make_cup(c, g, a.frames, a.src_mul, &a.cup))) return r;
   launch_update(c->st, a);
   pf.end(c);
   HIPCHK(c, hipGetLastError());
@@ -474,13 +488,14 @@ int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   PredArgs a;
   a.g = g; a.frames = (const uint8_t*)out.low.p; a.mv = (const int16_t*)lv.mv_filt.p;
   a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = nullptr;
-  a.margin = nullptr; a.odd_out = (uint8_t*)out.low.p; a.types = (const uint8_t*)c->tmp16[0].p;
+  a.margin = nullptr; a.odd_out = (uint8_t*)out.low.p; a.types = (const uint8_t*)c->tmp16[0].p; a.cup = nullptr;
   if (g.H % bs || g.W % bs) {  // Q7 applies to the decoder's prediction planes as well
     if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
     a.margin = (int16_t*)c->margin.p;
   }
   Prof pf;
   pf.begin(c, "correlate");
+  if (!a.margin && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
   launch_predict(c->st, a);
   pf.end(c);
   HIPCHK(c, hipGetLastError());

@@ -54,6 +54,7 @@ struct qsvc_ctx {
   std::vector<Level> lv;
   std::vector<DevBuf> snap;  // ME pyramid snapshots per DWT level
   DevBuf margin;             // Q7 chroma margin state of the level being decorrelated
+  DevBuf cup;                // chroma x2 interpolation of the even pictures of the level in work: [nB+1][2][H][W] u8
   DevBuf mvtmp[2], scal, tmp16[2];
   DevBuf halo_tx[2], halo_rx[2];  // boundary records: [0] left neighbour, [1] right neighbour
   uint8_t halo_tb[2][16];

@@ -119,7 +119,7 @@ int emul_update(const uint8_t* low, int P, int W, int H, int bs, const uint8_t* 
   if ((W & 1) || (H & 1)) return -2;
   UpdArgs a;
   a.g = g; a.frames = low; a.high = high; a.mv = mv; a.types = (const uint8_t*)types; a.low = low_out; a.uf = uf; a.reach = reach;
-  a.src_mul = 2; a.dst_mul = 1;
+  a.src_mul = 2; a.dst_mul = 1; a.cup = nullptr;
   a.halo_high[0] = halo_l; a.halo_mv[0] = halo_l ? (const int16_t*)(halo_l + g.F) : nullptr; a.halo_type[0] = halo_l ? halo_l_type : 0;
   a.halo_high[1] = halo_r; a.halo_mv[1] = halo_r ? (const int16_t*)(halo_r + g.F) : nullptr; a.halo_type[1] = halo_r ? halo_r_type : 0;
   for (int j = 0; j <= g.nB; j++) {
@@ -137,7 +137,7 @@ int emul_synthesize_step(const uint8_t* low_t, int P, int W, int H, int bs, int 
   if ((W & 1) || (H & 1)) return -2;
   UpdArgs u;
   u.g = g; u.frames = low_t; u.high = high; u.mv = mv; u.types = (const uint8_t*)types; u.low = frames; u.uf = -uf; u.reach = reach;
-  u.src_mul = 1; u.dst_mul = 2;
+  u.src_mul = 1; u.dst_mul = 2; u.cup = nullptr;
   for (int s = 0; s < 2; s++) { u.halo_high[s] = nullptr; u.halo_mv[s] = nullptr; u.halo_type[s] = 0; }
   for (int j = 0; j <= g.nB; j++) {
     for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) upd_luma_thread(u, x, y, j);
