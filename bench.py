@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 W, H, TRLS, GOPS, BS, S0, SRLS = 1920, 1080, 4, 2, 8, 4, 5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = "r01_v4_pmc_hbm.json"
+PMC_FILE = "r02_pmc_hbm.json"  # tools/refresh_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, one sequence in flight
 
 
 def log(*a):
@@ -40,24 +40,24 @@ def log(*a):
 
 
 def cpu_baseline():
-    """CPU path on a bounded sample of the same workload, 1 core.  MCTF: the reference's own tools (oracle/_ref,
-    compiled from /root/reference at build time) when present, else the restatement; JPEG 2000: the T.800
-    restatement (the reference's Kakadu does not exist here)."""
-    import numpy as np
+    """The CPU path on the SAME workload as one GPU step's sequence (17 pictures, 3 MCTF levels, 17 subband pictures coded), one
+    core.  MCTF: the reference's own tools (oracle/_ref, compiled from /root/reference at build time) when present, else the
+    restatement; JPEG 2000: the T.800 restatement (the reference's Kakadu does not exist here), hence kind "port"."""
     from oracle import oracle as O
     from oracle import j2k as J
     from qsvc_amd.synth import make_clip
-    frames = 5
+    frames = 17
     clip = make_clip("pan_noise", frames, W, H, 43)
     t0 = time.perf_counter()
     if O.have_ref():
-        lv = O.ref_analyze(clip, W, H, 3, BS, S0)
+        lv = O.ref_analyze(clip, W, H, TRLS, BS, S0)
         mctf_kind = "reference tools (oracle/_ref)"
     else:
-        lv = O.analyze(clip, W, H, 3, BS, S0)
+        lv = O.analyze(clip, W, H, TRLS, BS, S0)
         mctf_kind = "restatement (oracle/mctf_oracle.c)"
     t1 = time.perf_counter()
-    pics = [lv[0]["high"][i] for i in range(2)] + [lv[1]["high"][0]] + [lv[1]["low"][i] for i in range(2)]
+    pics = [f for l in lv for f in l["high"]] + list(lv[-1]["low"])
+    assert len(pics) == frames
     ncb = 0
     for f in pics:
         for pl in (f[:W * H].reshape(H, W), f[W * H:W * H + W * H // 4].reshape(H // 2, W // 2), f[W * H + W * H // 4:].reshape(H // 2, W // 2)):
@@ -65,8 +65,8 @@ def cpu_baseline():
             ncb += st["codeblocks"]
     t2 = time.perf_counter()
     return {"value": round(frames / (t2 - t0), 4), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{frames} pictures 1920x1080, 2 MCTF levels via {mctf_kind} ({t1 - t0:.2f} s) + 5/3 DWT/EBCOT of the 5 subband "
-                      f"pictures via the T.800 restatement ({t2 - t1:.2f} s, {ncb} code-blocks); single thread",
+            "sample": f"the whole {frames}-picture sequence of one step: 3 MCTF levels via {mctf_kind} ({t1 - t0:.2f} s) + 5/3 DWT/EBCOT of "
+                      f"the {frames} subband pictures via the T.800 restatement ({t2 - t1:.2f} s, {ncb} code-blocks); single thread",
             "mctf_s": round(t1 - t0, 3), "j2k_s": round(t2 - t1, 3), "codeblocks_per_s": round(ncb / (t2 - t1), 1)}
 
 
@@ -158,6 +158,10 @@ def main():
 
     import threading
     S = max(1, args.sessions)
+    # Tier-2 worker threads per encoder context: the host's cores shared by every rank of the node and every session of a rank
+    # (8 sessions x 8 workers x 8 ranks would be 512 threads); a caller's own setting wins
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    os.environ.setdefault("QSVC_T2_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // max(1, local_world * S)))))
     dev = os.environ.get("QSVC_BENCH_DEVICE")  # test hook: several ranks on one GPU (forces the host-staged exchange)
     devno = int(dev) if dev is not None else (local if world > 1 else 0)
     engs = [hip.Engine(devno) for _ in range(S)]
@@ -228,9 +232,30 @@ def main():
     # weak scaling: rank r holds pictures [16r, 16r+16] of one long synthetic sequence (boundary picture shared)
     G = 16
     seq_local = make_clip(args.clip, G * world + 1, W, H, 43)[G * rank:G * rank + P].copy()
-    for c in comps:
+
+    def variant(clip, k):
+        """Session k's sequence: the synthetic clip mirrored (k & 1: left-right, k & 2: top-bottom) and, from the fifth session on,
+        shifted in brightness -- 8 distinct sequences of identical statistics without generating 8 clips."""
+        if k == 0:
+            return clip
+        out = np.empty_like(clip)
+        for f_in, f_out in zip(clip, out):
+            o = 0
+            for (w, h) in ((W, H), (W // 2, H // 2), (W // 2, H // 2)):
+                pl = f_in[o:o + w * h].reshape(h, w)
+                if k & 1:
+                    pl = pl[:, ::-1]
+                if k & 2:
+                    pl = pl[::-1, :]
+                f_out[o:o + w * h] = pl.reshape(-1)
+                o += w * h
+        if k >= 4:
+            out = np.clip(out.astype(np.int16) + 5 * (k // 4), 0, 255).astype(np.uint8)
+        return out
+
+    for k, c in enumerate(comps):
         c.configure()
-        c.load(seq_local)
+        c.load(variant(seq_local, k))
     low_first = 0 if rank == 0 else 1  # the shared boundary picture of low_T is coded by the left shard
     nbytes_of = [0] * S
 
@@ -262,7 +287,7 @@ def main():
             for k, ex in failures:
                 log(f"[rank {rank}] session {k} failed: {ex}")
             os._exit(1)  # no JSON line; peers blocked in a collective are reaped by the launcher
-        assert all(b == nbytes_of[0] for b in nbytes_of), f"sessions coded different byte counts: {nbytes_of}"
+        assert all(b > 0 for b in nbytes_of), f"a session produced no code-stream: {nbytes_of}"
 
     def barrier():
         for e in engs:
@@ -293,17 +318,21 @@ def main():
     stats = eng.j2k_stats()
     for e in engs:
         e.set_profiling(False)
-    serial_ms = None
-    if world == 1:  # latency of ONE sequence alone on the chip (informational)
+    serial_ms, iso = None, {}
+    if world == 1:  # ONE sequence alone on the chip: its latency, and every kernel group's ISOLATED duration (HIP events)
         if user_lanes is None:
             os.environ["QSVC_MQ_LANES"] = "16"
         step(0)
         engs[0].sync()
+        engs[0].set_profiling(True)
         t1 = time.perf_counter()
-        for _ in range(2):
+        ISO_N = 3
+        for _ in range(ISO_N):
             step(0)
         engs[0].sync()
-        serial_ms = (time.perf_counter() - t1) / 2 * 1e3
+        serial_ms = (time.perf_counter() - t1) / ISO_N * 1e3
+        iso = {k: (ms / ISO_N, n // ISO_N) for k, (ms, n) in engs[0].timings().items()}
+        engs[0].set_profiling(False)
 
     if rank == 0:
         pics_total = (G * world + 1) * S   # unique pictures per step: S independent sequences of 16*N+1 pictures
@@ -312,68 +341,95 @@ def main():
         F = W * H * 3 // 2
         ncb_frame = 921
         ncb_step = ncb_frame * 17  # per rank
-        # algorithmic bytes per launch: T1 = 8 KB of int16 coefficients per 64x64 block + bytes out
-        per = {}
-        for k, (ms, n) in timings.items():
-            per[k] = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": n // max(args.steps, 1)}
-        def gbs(bytes_per_step, key):
-            ms = timings.get(key, (0, 0))[0] / args.steps
-            return bytes_per_step / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # ---- algorithmic bytes per STEP of this rank's session 0 (F = 1.5 W H, N = W H) -----------------
         nB = [8, 4, 2]
+        N = W * H
+        t1_bytes = ncb_step * 8192 + nbytes           # EBCOT T1: 4096 x 2 B of int16 coefficients per 64x64 block + emitted bytes
         alg = {
-            "j2k_t1_encode": ncb_step * 8192 + nbytes,
-            "j2k_t1_cm": ncb_step * 8192 + int(stats["symbols"]),      # int16 coefficients in, one byte per decision out
-            "j2k_t1_mq": int(stats["symbols"]) + nbytes,               # decisions in, code bytes out
-            "j2k_t1_flags": ncb_step * 8192,
-            "predict": sum(nB) * 4 * F,
-            "update": sum(n + 1 for n in nB) * 4 * F - 3 * 2 * F,
-            "me_search_l0": sum(nB) * 3 * W * H,
-            "j2k_dwt53": int(17 * 1.5 * W * H * (3 + 4 / 3)),
+            "j2k_t1_mq": t1_bytes, "j2k_t1_cm": t1_bytes,
+            "predict": sum(nB) * 4 * F,                # per B picture: read 2 even + 1 odd, write high
+            "update": sum(n + 1 for n in nB) * 4 * F - 3 * 2 * F,   # per even picture <= 4 F (ends 3 F)
+            "me_search_l0": sum(nB) * (3 * N + 8 * (H // BS) * (W // BS)),
+            "j2k_dwt53": int(17 * 1.5 * N * (3 + 4 / 3)),  # u8 in, int16 out, L levels
         }
-        for k, b in alg.items():
-            if k in per:
-                per[k]["algorithmic_bytes_per_step"] = int(b)
-                per[k]["achieved_GBs"] = round(gbs(b, k), 2)
-        dom = max((k for k in per), key=lambda k: per[k]["ms_per_step"]) if per else None
-        roof = None
-        if dom and dom in alg:
-            launches = max(per[dom]["launches_per_step"], 1)
-            a = gbs(alg[dom], dom)
-            traffic = None
-            try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-                kname = {"j2k_t1_mq": "k_t1_mq<%s>" % (user_lanes or ("64" if S > 1 else "16")), "j2k_t1_cm": "k_t1_cm2", "j2k_t1_encode": "k_t1_encode<8>"}.get(dom)
-                if kname in pmc:
-                    traffic = pmc[kname]["hbm_bytes_per_launch_raw"]
-            except Exception:
-                pass
-            roof = {"kernel": dom, "bound": "hbm", "achieved": round(a, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 6), "traffic": traffic,
-                    "traffic_source": ("profiles/" + PMC_FILE + " (FETCH_SIZE+WRITE_SIZE, KiB->bytes, raw: FETCH_SIZE is "
-                                       "uncalibrated for this kernel's 16-byte-per-lane gathers)") if traffic else None,
-                    "launch_ms": round(per[dom]["ms_per_step"] / launches, 4),
-                    "algorithmic_bytes_per_launch": int(alg[dom] / launches),
-                    "note": "EBCOT Tier-1 is serial-dependency bound, not HBM bound (SURVEY.md H4/8d); fraction quoted for completeness"
-                    if dom.startswith("j2k_t1") else ""}
-        t1ms = sum(per.get(k, {}).get("ms_per_step", 0) for k in ("j2k_t1_encode", "j2k_t1_flags", "j2k_t1_cm", "j2k_t1_mq"))
+        per, host = {}, {}
+        for k, (ms, n) in timings.items():
+            d = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": n // max(args.steps, 1)}
+            (host if k.startswith("host_") else per)[k] = d
+        pmc = {}
+        try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        except Exception:
+            pass
+
+        def traffic_of(kernels):
+            """HBM bytes per step of a kernel group: sum of launches x (FETCH_SIZE + WRITE_SIZE) from the PMC passes.  RAW sums: none
+            of these kernels reads 16 bytes per lane in long streams (the one pattern MI355X_MICROARCH.md says FETCH_SIZE halves);
+            calibration on a known byte count in our own access widths: k_chroma_up (1-byte loads, 4-byte stores) reads
+            (nB+1) x 2 x W/2 x H/2 and writes (nB+1) x 2 x W x H bytes per launch, and both counters return exactly that."""
+            tot, seen = 0, False
+            for kn, launches in kernels:
+                e = pmc.get(kn)
+                if e:
+                    seen = True
+                    tot += launches * e["hbm_bytes_per_launch_raw"]
+            return int(tot) if seen else None
+
+        mq_lanes = user_lanes or ("64" if S > 1 else "16")
+        dom = "j2k_t1_mq"
+        a = alg[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e9 if dom in per and per[dom]["ms_per_step"] > 0 else 0.0
+        roof = {"kernel": dom, "kernel_symbol": f"k_t1_mq<{mq_lanes}>", "bound": "hbm", "achieved": round(a, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(a / HBM_PEAK_GBS, 6),
+                "traffic": traffic_of([("k_t1_mq<%s>" % mq_lanes, 1)]) or traffic_of([("k_t1_mq<16>", 1)]),
+                "traffic_source": "profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE per launch, separate passes, one sequence in flight: the "
+                                  "kernel there is k_t1_mq<16>, the same loads and stores as the 64-lane form)",
+                "launch_ms": per.get(dom, {}).get("ms_per_step"), "algorithmic_bytes_per_launch": int(alg[dom]),
+                "algorithmic_bytes": "SURVEY.md 8d: 15 657 code-blocks x 8 KB (int16 coefficients) + emitted code bytes, one launch per step",
+                "note": "the launch with the largest share of the step; EBCOT Tier-1 is serial-dependency bound, not HBM bound (SURVEY.md H4/8d): "
+                        "the fraction is quoted for completeness, the streaming kernels are in roofline_streaming"}
+        # the kernels the HBM roofline is meaningful for, ISOLATED (one sequence in flight, measured live after the timed region)
+        streaming = None
+        if iso:
+            groups = {
+                "j2k_dwt53": [("k_dwt_tile<true, true, false>", 1), ("k_dwt_tile<true, false, false>", 3), ("k_t1_nbps", 1)],
+                "predict": [("k_chroma_up", 3), ("k_pred_luma8", 3), ("k_pred_chroma8", 3), ("k_mv_hist", 3)],
+                "update": [("k_chroma_up", 3), ("k_upd_luma_tile", 3), ("k_upd_chroma_tile", 3)],
+                "me_search_l0": [("k_me_search8<unsigned char>", 3)],
+            }
+            streaming = {}
+            for k, kernels in groups.items():
+                if k not in iso or iso[k][0] <= 0:
+                    continue
+                g = alg[k] / (iso[k][0] * 1e-3) / 1e9
+                streaming[k] = {"ms_per_step_isolated": round(iso[k][0], 4), "launch_groups_per_step": iso[k][1],
+                                "algorithmic_bytes_per_step": int(alg[k]), "achieved_GBs": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4),
+                                "traffic": traffic_of(kernels)}
+            streaming["note"] = ("isolated = one sequence in flight, HIP events on the context's stream around each kernel group; traffic = HBM bytes "
+                                 "per step from profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE, raw, calibrated on k_chroma_up's known byte "
+                                 "counts; k_chroma_up launches are counted in both predict and update, which each run it); ME is ALU-bound by "
+                                 "design (SURVEY.md 8d), its fraction is quoted for completeness")
+        t1ms = sum(per.get(k, {}).get("ms_per_step", 0) for k in ("j2k_t1_cm", "j2k_t1_mq"))
         line = {
             "metric": "1080p encode fps (MCTF + 5/3 DWT + EBCOT)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int16 (int32 5/3 lifting, u16 MQ coder)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int16 (int32 5/3 lifting in LDS, u16 MQ coder)", "data": "synthetic",
             "config": {"workload": "1920x1080 4:2:0, 17 pictures per GPU (16-picture GOP window + shared boundary), TRLs=4 "
                                    "(ME+predict+update, block 8, search 4/8/16), JPEG 2000 5/3 reversible lossless, Clevels=4, "
                                    "64x64 code-blocks, SOP; clip=" + args.clip,
                        "pictures_per_step_total": pics_total, "sequences_in_flight_per_gpu": S,
-                       "parallelism": f"gop-shard x{world}", "halo_exchange": exchange_kind},
+                       "parallelism": f"gop-shard x{world}", "halo_exchange": exchange_kind,
+                       "tier2_threads_per_context": int(os.environ["QSVC_T2_THREADS"])},
             "codeblocks_per_s": round(ncb_step * world * S * args.steps / dt, 1),
             "ebcot_codeblocks_per_s_kernel": round(ncb_step / (t1ms * 1e-3), 1) if t1ms else None,
-            "codestream_bytes_per_step": int(nbytes), "mq_symbols_per_step": int(stats["symbols"]),
-            "kernels": per, "roofline": roof,
+            "codestream_bytes_per_step": int(nbytes), "codestream_bytes_per_step_all_sessions": int(sum(nbytes_of)), "mq_symbols_per_step": int(stats["symbols"]),
+            "kernels": per, "host_stages": host, "roofline": roof, "roofline_streaming": streaming,
         }
         if serial_ms is not None:
-            line["single_sequence"] = {"ms_per_encode": round(serial_ms, 3), "frames_per_s": round(17 / (serial_ms * 1e-3), 2)}
-        line["kernels_note"] = ("per-kernel times are HIP-event durations on session 0's stream; with several sessions in "
-                                "flight kernels of different sessions overlap, so they do not sum to ms_per_step")
+            line["single_sequence"] = {"ms_per_encode": round(serial_ms, 3), "frames_per_s": round(17 / (serial_ms * 1e-3), 2),
+                                       "kernels_ms_isolated": {k: round(v[0], 4) for k, v in iso.items()}}
+        line["kernels_note"] = ("kernels{} are HIP-event durations on session 0's stream inside the timed region; with several sessions in "
+                                "flight kernels of different sessions overlap, so they do not sum to ms_per_step; host_stages{} are wall-clock "
+                                "milliseconds of the CPU stages of session 0 (rate allocation, Tier-2)")
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()

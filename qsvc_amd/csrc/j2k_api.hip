@@ -11,6 +11,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "j2k_kernels.h"
@@ -192,7 +196,49 @@ struct HostCb {  // host view of one coded block
 
 }  // namespace
 
+// Persistent Tier-2 workers of one encoder context.  Their number is bounded by QSVC_T2_THREADS (default min(8, planes)): a
+// host that runs several contexts per process and several ranks per node sets it to cores / (ranks x sessions).
+struct T2Pool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  std::function<void(int)> job;
+  int gen = 0, pending = 0, nworkers = 0;
+  bool stop = false;
+  void start(int n) {
+    nworkers = n;
+    for (int t = 0; t < n; t++)
+      th.emplace_back([this, t] {
+        int seen = 0;
+        for (;;) {
+          std::function<void(int)> f;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen; f = job;
+          }
+          f(t + 1);
+          { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) done_cv.notify_all(); }
+        }
+      });
+  }
+  // run f(0) here and f(1..nworkers) on the workers; returns when all are done
+  void run(const std::function<void(int)>& f) {
+    if (nworkers) { std::lock_guard<std::mutex> lk(mu); job = f; pending = nworkers; gen++; }
+    cv.notify_all();
+    f(0);
+    if (nworkers) { std::unique_lock<std::mutex> lk(mu); done_cv.wait(lk, [&] { return pending == 0; }); }
+  }
+  ~T2Pool() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+
 struct J2kState {
+  T2Pool* pool = nullptr;
   DevBuf coefA, llA, llB, sbtab_d, planes_d, cbs_d, nbps_d, mags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
   DevBuf joboff_d, order_d, jobs_d, segs_d, cnt_d, dist_d;  // Tier-1: job list, decision segments
   std::vector<int> h_nbps, h_joboff, h_order, h_jobs;
@@ -215,6 +261,7 @@ void j2k_release(qsvc_ctx* c) {
                    &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->jobs_d, &s->segs_d, &s->cnt_d, &s->dist_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
+  delete s->pool;
   delete s;
   c->j2k = nullptr;
 }
@@ -513,6 +560,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   HIPCHK(c, hipGetLastError());
   if (err) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
   // host: rate allocation, gather offsets
+  const auto ra_begin = std::chrono::steady_clock::now();
   S.hcb.assign(ncb, HostCb());
   std::vector<unsigned long long> goffs(ncb);
   std::vector<int> glens(ncb);
@@ -548,6 +596,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
       }
     }
   }
+  c->host_time("host_rate_alloc", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ra_begin).count());
   if ((r = S.gath_d.ensure(c, gtotal ? gtotal : 16))) return r;
   if (S.gath_h_cap < gtotal) {
     if (S.gath_h) (void)hipHostFree(S.gath_h);
@@ -577,18 +626,17 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
       slot[p + 1] = slot[p] + body + 64 * (size_t)pl.ncb * layers + 16 * (size_t)layers * (pl.L + 1) + 512;
     }
     if (S.t2scratch.size() < slot[np]) S.t2scratch.resize(slot[np] + slot[np] / 8);
-    const int nthreads = std::max(1, std::min(8, np));
+    static const int t2_env = [] { const char* e = getenv("QSVC_T2_THREADS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    if (!S.pool) { S.pool = new T2Pool(); S.pool->start(t2_env - 1); }
+    const int nthreads = S.pool->nworkers + 1;
     std::vector<long> rc(np, 0);
-    auto worker = [&](int tid) {
+    const auto t2_begin = std::chrono::steady_clock::now();
+    S.pool->run([&](int tid) {
       for (int p = tid; p < np; p += nthreads)
         rc[p] = write_codestream(plans[plan_of[p]], *src[p].prm, src[p].prm->layers < 1 ? 1 : src[p].prm->layers, cbw, cbh,
                                  S.hcb.data() + first_cb[p], S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS, S.gath_h,
                                  S.t2scratch.data() + slot[p], slot[p + 1] - slot[p]);
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++) th.emplace_back(worker, t);
-    worker(0);
-    for (auto& t : th) t.join();
+    });
     size_t pos = 0;
     for (int p = 0; p < np; p++) {
       if (rc[p] < 0) return c->fail(QSVC_ERR_NOMEM, "internal Tier-2 scratch too small");
@@ -596,13 +644,10 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     }
     offs[np] = pos;
     if (pos > cap) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes needed, %zu given)", pos, cap);
-    auto copier = [&](int tid) {
+    S.pool->run([&](int tid) {
       for (int p = tid; p < np; p += nthreads) memcpy(out + offs[p], S.t2scratch.data() + slot[p], (size_t)rc[p]);
-    };
-    th.clear();
-    for (int t = 1; t < nthreads; t++) th.emplace_back(copier, t);
-    copier(0);
-    for (auto& t : th) t.join();
+    });
+    c->host_time("host_tier2", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2_begin).count());
   }
   return QSVC_OK;
 }

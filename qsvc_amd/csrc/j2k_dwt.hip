@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
   // ---- stage the tile: rows [gr0, gr0 + NR) x columns [gc0, gc0 + DT_NC), zero outside the signal -----------------------
   {
     const uint8_t* u = pd.src;
-    const LLT* lin = (const LLT*)a.llin + pd.ll[(a.lev - 1) & 1];
+    const LLT* lin = (const LLT*)a.llin + (((a.lev - 1) & 1) ? pd.ll[1] : pd.ll[0]);  // (a dynamic index would send pd to scratch)
     const int sstr = FROM_U8 ? pd.u8stride : dwt_ll_stride(w);
     const bool wide = FROM_U8 ? ((((uintptr_t)u) & 3) == 0 && (sstr & 3) == 0) : true;
     // all of a thread's wide loads are issued before the first one is unpacked (memory-level parallelism: ~10 per thread)
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int idx = tid + it * 256, lr = idx / (DT_NC / 4), q = idx % (DT_NC / 4), gr = gr0 + lr, gc = gc0 + 4 * q;
-      if (idx >= NQ) break;
+      if (idx >= NQ) continue;  // (no `break`: the loop must unroll completely so that raw[] stays in registers)
       TT v[4] = {0, 0, 0, 0};
       if (fast & (1u << it)) {
         if constexpr (FROM_U8) {
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
   }
   // ---- LL -> next level's input (compact, 4 samples per thread-store) ----------------------------------------------------
   if (!last) {
-    LLT* lout = (LLT*)a.llout + pd.ll[a.lev & 1];
+    LLT* lout = (LLT*)a.llout + ((a.lev & 1) ? pd.ll[1] : pd.ll[0]);
     const int ostr = dwt_ll_stride(lw);
     for (int idx = tid; idx < DT_TH * (DT_TW / 4); idx += 256) {
       const int ky = idx / (DT_TW / 4), kx = 4 * (idx % (DT_TW / 4)), y = ty0 + ky, x = tx0 + kx;

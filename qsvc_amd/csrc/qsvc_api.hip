@@ -47,6 +47,12 @@ void DevBuf::release() {
   p = nullptr; cap = 0;
 }
 
+void qsvc_ctx::host_time(const char* name, double ms) {
+  if (!profiling) return;
+  for (auto& h : hsegs) if (h.name == name) { h.ms += ms; h.n++; return; }
+  hsegs.push_back(HostSeg());
+  hsegs.back().name = name; hsegs.back().ms = ms; hsegs.back().n = 1;
+}
 void Prof::begin(qsvc_ctx* c, const char* name) {
   if (!c->profiling) return;
   Seg* s = nullptr;
@@ -673,6 +679,7 @@ int qsvc_set_profiling(qsvc_ctx* c, int on) {
   (void)hipStreamSynchronize(c->st);
   for (auto& s : c->segs) for (auto& p : s.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   c->segs.clear();
+  c->hsegs.clear();
   c->profiling = on;
   return QSVC_OK;
 }
@@ -685,6 +692,11 @@ int qsvc_get_timings(qsvc_ctx* c, const char** names, float* ms, int* launches, 
     float tot = 0;
     for (auto& p : s.ev) { float m = 0; if (hipEventElapsedTime(&m, p.first, p.second) == hipSuccess) tot += m; }
     names[n] = s.name.c_str(); ms[n] = tot; if (launches) launches[n] = (int)s.ev.size();
+    n++;
+  }
+  for (auto& h : c->hsegs) {  // host wall time of the stages that run on the CPU (names start with "host_")
+    if (n >= cap) break;
+    names[n] = h.name.c_str(); ms[n] = (float)h.ms; if (launches) launches[n] = h.n;
     n++;
   }
   return n;

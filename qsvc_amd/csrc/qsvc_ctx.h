@@ -43,6 +43,12 @@ struct Prof {
   void end(qsvc_ctx* c);
 };
 
+struct HostSeg {  // host-side wall time of a named stage (profiling on): reported next to the kernel segments as "host_<name>"
+  std::string name;
+  double ms = 0;
+  int n = 0;
+};
+
 struct J2kState;
 
 struct qsvc_ctx {
@@ -64,6 +70,8 @@ struct qsvc_ctx {
   std::string err;
   int profiling = 0;
   std::vector<Seg> segs;
+  std::vector<HostSeg> hsegs;
+  void host_time(const char* name, double ms);
   J2kState* j2k = nullptr;
   int fail(int code, const char* fmt, ...);
   int hipfail(hipError_t e, const char* what);
