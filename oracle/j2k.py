@@ -34,6 +34,7 @@ def _lib():
         L.qo_j2k_norm.argtypes = [C.c_int, C.c_int, C.c_int]
         L.qo_j2k_slope_to_lambda.restype = C.c_double
         L.qo_j2k_slope_to_lambda.argtypes = [C.c_int]
+        L.qo_j2k_decode_plane.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _ready = True
     return L
 
@@ -103,6 +104,21 @@ def t1_block(vals: np.ndarray, orient: int):
     pl = np.zeros(128, dtype=np.int32)
     n = _lib().qo_j2k_t1_block(v.ctypes.data, w, h, orient, out.ctypes.data, C.byref(npasses), C.byref(nbps), pl.ctypes.data)
     return out[:n].tobytes(), npasses.value, nbps.value, pl[:npasses.value].copy()
+
+
+def own_decode(codestream: bytes, layers=0) -> np.ndarray:
+    """The restatement's own decoder (T.800 Annex B parse, C.3 MQ decoder, D, E.1.1, F.3): uint8, or int16 for 16-bit signed."""
+    cs = bytes(codestream)
+    W, H, prec, sg = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    # geometry first (SIZ is at a fixed place: SOC, SIZ marker, Lsiz, Rsiz, Xsiz, Ysiz)
+    w, h = int.from_bytes(cs[8:12], "big"), int.from_bytes(cs[12:16], "big")
+    p16 = (cs[42] & 0x7F) + 1 > 8
+    out = np.empty((h, w), dtype=np.int16 if p16 else np.uint8)
+    r = _lib().qo_j2k_decode_plane(cs, len(cs), layers, out.ctypes.data, C.byref(W), C.byref(H), C.byref(prec), C.byref(sg))
+    if r != 0:
+        raise RuntimeError(f"qo_j2k_decode_plane failed: {r}")
+    assert (W.value, H.value) == (w, h)
+    return out
 
 
 def decode(codestream: bytes, layers=None, reduce=0) -> np.ndarray:

@@ -832,3 +832,361 @@ int qo_mq_encode_bits(const uint8_t *bits, int n, uint8_t *out) {
   free(buf);
   return len;
 }
+
+/* ============================================================================================== */
+/* DECODER restatement (the reference decodes with the external `kdu_expand`,     */
+/* trunk/src/texture_expand_fb_j2k.py:153-162).  T.800 Annex B (packet parsing), C.3 (MQ decoder), */
+/* D (bit modelling, decoding direction), E.1.1 (dequantisation, midpoint reconstruction) and F.3   */
+/* (inverse DWT).  Pinned by an independent decoder: OpenJPEG through Pillow decodes the same       */
+/* streams to the same samples (bit-exact for 5/3, within 1 LSB for 9/7: tests/test_j2k_decoder.py).*/
+
+typedef struct { const uint8_t *d; size_t n, p; int acc, nb, last; } bitr;
+static void br_init(bitr *b, const uint8_t *d, size_t n, size_t p) { b->d = d; b->n = n; b->p = p; b->acc = 0; b->nb = 0; b->last = 0; }
+static int br_bit(bitr *b) {
+  if (b->nb == 0) {
+    int v = b->p < b->n ? b->d[b->p] : 0;
+    b->p++;
+    b->nb = b->last == 0xFF ? 7 : 8;
+    b->acc = v; b->last = v;
+  }
+  b->nb--;
+  return (b->acc >> b->nb) & 1;
+}
+static unsigned br_bits(bitr *b, int k) { unsigned v = 0; while (k-- > 0) v = (v << 1) | (unsigned)br_bit(b); return v; }
+static size_t br_align(bitr *b) { b->nb = 0; if (b->last == 0xFF) { b->p++; b->last = 0; } return b->p; }
+
+/* tag tree decoder (B.10.2): val = current lower bound, known = value established */
+static int tt_decode(tagtree *t, bitr *b, int lx, int ly, int threshold) {
+  int lo = 0;
+  for (int k = t->nlev - 1; k >= 0; k--) {
+    int nd = t->off[k] + (ly >> k) * t->lw[k] + (lx >> k);
+    if (t->val[nd] < lo) t->val[nd] = lo;
+    while (!t->known[nd] && t->val[nd] < threshold) {
+      if (br_bit(b)) t->known[nd] = 1; else t->val[nd]++;
+    }
+    lo = t->val[nd];
+    if (!t->known[nd]) return 0;
+  }
+  return t->val[t->off[0] + ly * t->lw[0] + lx] < threshold;
+}
+static int get_npasses(bitr *b) { /* Table B.4 */
+  if (!br_bit(b)) return 1;
+  if (!br_bit(b)) return 2;
+  unsigned v = br_bits(b, 2);
+  if (v != 3) return 3 + (int)v;
+  v = br_bits(b, 5);
+  if (v != 31) return 6 + (int)v;
+  return 37 + (int)br_bits(b, 7);
+}
+
+/* MQ decoder (C.3) */
+typedef struct {
+  uint32_t A, C; int CT;
+  const uint8_t *bp, *end;
+  uint8_t I[NCTX], MPS[NCTX];
+} mqdec;
+static void mqd_bytein(mqdec *m) {
+  if (m->bp < m->end) {
+    if (*m->bp == 0xFF) {
+      int nx = m->bp + 1 < m->end ? m->bp[1] : 0xFF;
+      if (nx > 0x8F) { m->C += 0xFF00; m->CT = 8; }
+      else { m->bp++; m->C += (uint32_t)nx << 9; m->CT = 7; }
+    } else {
+      m->bp++;
+      m->C += (uint32_t)(m->bp < m->end ? *m->bp : 0xFF) << 8; m->CT = 8;
+    }
+  } else { m->C += 0xFF00; m->CT = 8; }
+}
+static void mqd_init(mqdec *m, const uint8_t *data, int len) {
+  memset(m->I, 0, sizeof m->I); memset(m->MPS, 0, sizeof m->MPS);
+  m->I[0] = 4; m->I[CTX_RUN] = 3; m->I[CTX_UNI] = 46;
+  m->bp = data; m->end = data + len;
+  m->C = (uint32_t)(len > 0 ? data[0] : 0xFF) << 16;
+  mqd_bytein(m);
+  m->C <<= 7; m->CT -= 7; m->A = 0x8000;
+}
+static int mqd_decode(mqdec *m, int cx) {
+  uint32_t qe = MQ_QE[m->I[cx]];
+  int d;
+  m->A -= qe;
+  if ((m->C >> 16) < qe) {           /* LPS exchange (C.3.2, Figure C.17) */
+    if (m->A < qe) { d = m->MPS[cx]; m->I[cx] = MQ_NMPS[m->I[cx]]; }
+    else { d = 1 - m->MPS[cx]; if (MQ_SW[m->I[cx]]) m->MPS[cx] = 1 - m->MPS[cx]; m->I[cx] = MQ_NLPS[m->I[cx]]; }
+    m->A = qe;
+  } else {
+    m->C -= qe << 16;
+    if (m->A & 0x8000) return m->MPS[cx];
+    if (m->A < qe) { d = 1 - m->MPS[cx]; if (MQ_SW[m->I[cx]]) m->MPS[cx] = 1 - m->MPS[cx]; m->I[cx] = MQ_NLPS[m->I[cx]]; }
+    else { d = m->MPS[cx]; m->I[cx] = MQ_NMPS[m->I[cx]]; }
+  }
+  do { if (m->CT == 0) mqd_bytein(m); m->A <<= 1; m->C <<= 1; m->CT--; } while ((m->A & 0x8000) == 0);
+  return d;
+}
+
+/* one code-block: `npasses` coding passes of the segment -> magnitudes (with the bit-plane each sample was last coded in) */
+static void t1_decode_block(const uint8_t *seg, int len, int npasses, int nbps, int w, int h, int orient, uint32_t *mag /*64x64*/,
+                            uint8_t *lastp /*64x64*/, uint8_t *neg /*64x64*/) {
+  static t1blk blk;
+  t1blk *b = &blk;
+  b->w = w; b->h = h;
+  memset(b->fl, 0, sizeof b->fl);
+  memset(mag, 0, sizeof(uint32_t) * 64 * 64); memset(lastp, 0, 64 * 64); memset(neg, 0, 64 * 64);
+  if (nbps <= 0 || npasses <= 0) return;
+  mqdec m;
+  mqd_init(&m, seg, len);
+  int np = 0;
+#define DEC_SIGN(y, x) do { int xb_, cx_ = sc_ctx(b, (y), (x), &xb_); int s_ = mqd_decode(&m, cx_) ^ xb_; \
+                            if (s_) { FL(b, (y), (x)) |= F_NEG; neg[(y) * 64 + (x)] = 1; } FL(b, (y), (x)) |= F_SIG; } while (0)
+  for (int p = nbps - 1; p >= 0 && np < npasses; p--) {
+    if (p != nbps - 1) {
+      for (int y0 = 0; y0 < h; y0 += 4)
+        for (int x = 0; x < w; x++)
+          for (int y = y0; y < y0 + 4 && y < h; y++) {
+            uint8_t f = FL(b, y, x);
+            if ((f & F_SIG) || !any_sig_neighbour(b, y, x)) continue;
+            int bit = mqd_decode(&m, zc_ctx(b, y, x, orient));
+            if (bit) { mag[y * 64 + x] |= 1u << p; DEC_SIGN(y, x); }
+            lastp[y * 64 + x] = (uint8_t)p;
+            FL(b, y, x) |= F_VISIT;
+          }
+      if (++np >= npasses) break;
+      for (int y0 = 0; y0 < h; y0 += 4)
+        for (int x = 0; x < w; x++)
+          for (int y = y0; y < y0 + 4 && y < h; y++) {
+            uint8_t f = FL(b, y, x);
+            if (!(f & F_SIG) || (f & F_VISIT)) continue;
+            int cx = (f & F_REFINED) ? 16 : (any_sig_neighbour(b, y, x) ? 15 : 14);
+            if (mqd_decode(&m, cx)) mag[y * 64 + x] |= 1u << p;
+            lastp[y * 64 + x] = (uint8_t)p;
+            FL(b, y, x) |= F_REFINED;
+          }
+      if (++np >= npasses) break;
+    }
+    for (int y0 = 0; y0 < h; y0 += 4)
+      for (int x = 0; x < w; x++) {
+        int y = y0;
+        if (y0 + 3 < h) {
+          int run = 1;
+          for (int k = 0; k < 4; k++)
+            if ((FL(b, y0 + k, x) & (F_SIG | F_VISIT)) || any_sig_neighbour(b, y0 + k, x)) { run = 0; break; }
+          if (run) {
+            if (!mqd_decode(&m, CTX_RUN)) { for (int k = 0; k < 4; k++) lastp[(y0 + k) * 64 + x] = (uint8_t)p; continue; }
+            int first = mqd_decode(&m, CTX_UNI) << 1;
+            first |= mqd_decode(&m, CTX_UNI);
+            for (int k = 0; k < first; k++) lastp[(y0 + k) * 64 + x] = (uint8_t)p;
+            y = y0 + first;
+            mag[y * 64 + x] |= 1u << p; lastp[y * 64 + x] = (uint8_t)p;
+            DEC_SIGN(y, x);
+            y++;
+          }
+        }
+        for (; y < y0 + 4 && y < h; y++) {
+          uint8_t f = FL(b, y, x);
+          if (f & (F_SIG | F_VISIT)) continue;
+          int bit = mqd_decode(&m, zc_ctx(b, y, x, orient));
+          if (bit) { mag[y * 64 + x] |= 1u << p; DEC_SIGN(y, x); }
+          lastp[y * 64 + x] = (uint8_t)p;
+        }
+      }
+    np++;
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) FL(b, y, x) &= ~F_VISIT;
+  }
+#undef DEC_SIGN
+}
+
+/* inverse 1-D transforms on n samples of the Mallat layout (low half first), stride s */
+static void idwt53_1d(int32_t *x, int n, ptrdiff_t s, int32_t *tmp) {
+  if (n < 2) return;
+  int nl = (n + 1) >> 1, nh = n >> 1;
+  int32_t *lo = tmp, *hi = tmp + nl, *out = tmp + n;
+  for (int i = 0; i < nl; i++) lo[i] = x[i * s];
+  for (int i = 0; i < nh; i++) hi[i] = x[(nl + i) * s];
+  for (int i = 0; i < nl; i++) {  /* X(2n) = Y(2n) - floor((Y(2n-1) + Y(2n+1) + 2) / 4) */
+    int32_t a = (i > 0) ? hi[i - 1] : hi[0], b = (i < nh) ? hi[i] : hi[nh - 1];
+    out[2 * i] = lo[i] - ((a + b + 2) >> 2);
+  }
+  for (int i = 0; i < nh; i++) {  /* X(2n+1) = Y(2n+1) + floor((X(2n) + X(2n+2)) / 2) */
+    int32_t a = out[2 * i], b = (2 * i + 2 < n) ? out[2 * i + 2] : out[2 * i];
+    out[2 * i + 1] = hi[i] + ((a + b) >> 1);
+  }
+  for (int i = 0; i < n; i++) x[i * s] = out[i];
+}
+static void idwt97_1d(float *x, int n, ptrdiff_t s, float *tmp) {
+  if (n < 2) return;
+  int nl = (n + 1) >> 1, nh = n >> 1;
+  float *v = tmp;  /* interleaved working signal */
+  const float invK = 1.0f / F97_K;
+  for (int i = 0; i < nl; i++) v[2 * i] = x[i * s] * F97_K;          /* undo low * 1/K */
+  for (int i = 0; i < nh; i++) v[2 * i + 1] = x[(nl + i) * s] * invK; /* undo high * K */
+#define NB(i, par) /* neighbours of position i: the other one when outside */ \
+  float lo_ = (i) - 1 >= 0 ? v[(i) - 1] : v[(i) + 1], hi_ = (i) + 1 < n ? v[(i) + 1] : v[(i) - 1]
+  for (int i = 0; i < n; i += 2) { NB(i, 0); v[i] = v[i] - F97_DELTA * (lo_ + hi_); }
+  for (int i = 1; i < n; i += 2) { NB(i, 1); v[i] = v[i] - F97_GAMMA * (lo_ + hi_); }
+  for (int i = 0; i < n; i += 2) { NB(i, 0); v[i] = v[i] - F97_BETA * (lo_ + hi_); }
+  for (int i = 1; i < n; i += 2) { NB(i, 1); v[i] = v[i] - F97_ALPHA * (lo_ + hi_); }
+#undef NB
+  for (int i = 0; i < n; i++) x[i * s] = v[i];
+}
+
+/* Decode a single-tile, single-component code-stream as this path writes them (LRCP, no precincts, style 0).
+ * max_layers <= 0: all layers.  out: W*H uint8 (8-bit unsigned) or int16 (16-bit signed) samples.  Returns 0, or < 0. */
+int qo_j2k_decode_plane(const uint8_t *cs, size_t n, int max_layers, void *out, int *Wo, int *Ho, int *preco, int *sgndo) {
+  if (n < 4 || cs[0] != 0xFF || cs[1] != 0x4F) return -1;
+  size_t p = 2;
+  const uint8_t *siz = NULL, *cod = NULL, *qcd = NULL;
+  while (p + 4 <= n) {
+    int mk = (cs[p] << 8) | cs[p + 1];
+    if (mk == 0xFF90) break;
+    int ln = (cs[p + 2] << 8) | cs[p + 3];
+    if (mk == 0xFF51) siz = cs + p + 4; else if (mk == 0xFF52) cod = cs + p + 4; else if (mk == 0xFF5C) qcd = cs + p + 4;
+    p += 2 + (size_t)ln;
+  }
+  if (!siz || !cod || !qcd) return -2;
+#define U32(q) (((uint32_t)(q)[0] << 24) | ((uint32_t)(q)[1] << 16) | ((uint32_t)(q)[2] << 8) | (q)[3])
+  int W = (int)U32(siz + 2), H = (int)U32(siz + 6);
+  int prec = (siz[36] & 0x7F) + 1, sgnd = siz[36] >> 7;
+  int scod = cod[0], layers = (cod[2] << 8) | cod[3], L = cod[5], cbw = 1 << (cod[6] + 2), cbh = 1 << (cod[7] + 2), rev = cod[9] == 1;
+  if (cod[1] != 0 || cod[8] != 0 || cbw > 64 || cbh > 64 || L > MAX_LEVELS) return -3;
+  int guard = qcd[0] >> 5, qstyle = qcd[0] & 31;
+  subband sb[3 * MAX_LEVELS + 1];
+  int nsb = subbands_prec(W, H, L, 1, 1.0f, prec, sb);   /* geometry; eps / mant / delta / Mb from QCD below */
+  for (int s = 0; s < nsb; s++) {
+    int gain = sb[s].orient == 0 ? 0 : (sb[s].orient == 3 ? 2 : 1), Rb = prec + gain;
+    if (qstyle == 0) { sb[s].eps = qcd[1 + s] >> 3; sb[s].mant = 0; sb[s].delta = 1.0f; }
+    else if (qstyle == 2) {
+      int v = (qcd[1 + 2 * s] << 8) | qcd[2 + 2 * s];
+      sb[s].eps = v >> 11; sb[s].mant = v & 0x7FF;
+      sb[s].delta = (float)(ldexp(1.0, Rb - sb[s].eps) * (1.0 + sb[s].mant / 2048.0));
+    } else return -4;
+    sb[s].Mb = guard + sb[s].eps - 1;
+  }
+  if (Wo) *Wo = W;
+  if (Ho) *Ho = H;
+  if (preco) *preco = prec;
+  if (sgndo) *sgndo = sgnd;
+  /* tile-part */
+  uint32_t psot = U32(cs + p + 6);
+  size_t end = psot ? p + psot : n - 2;
+  p += 12;
+  while (p + 2 <= n && !(cs[p] == 0xFF && cs[p + 1] == 0x93)) p += 2 + (size_t)((cs[p + 2] << 8) | cs[p + 3]);
+  p += 2;
+  /* code-blocks */
+  int ncb = 0, first_cb[3 * MAX_LEVELS + 2];
+  for (int s = 0; s < nsb; s++) { first_cb[s] = ncb; ncb += ((sb[s].w + cbw - 1) / cbw) * ((sb[s].h + cbh - 1) / cbh); }
+  first_cb[nsb] = ncb;
+  typedef struct { int zbp, npasses, len, lblock, incl; uint8_t *data; size_t cap; } dblk;
+  dblk *cb = (dblk *)calloc(ncb ? ncb : 1, sizeof(dblk));
+  for (int i = 0; i < ncb; i++) cb[i].lblock = 3;
+  tagtree *incl = (tagtree *)calloc(nsb, sizeof(tagtree)), *zbpt = (tagtree *)calloc(nsb, sizeof(tagtree));
+  for (int s = 0; s < nsb; s++) {
+    int gx = (sb[s].w + cbw - 1) / cbw, gy = (sb[s].h + cbh - 1) / cbh;
+    if (gx * gy > 0) { tt_init(&incl[s], gx, gy); tt_init(&zbpt[s], gx, gy); }
+  }
+  int use_layers = (max_layers > 0 && max_layers < layers) ? max_layers : layers, ret = 0;
+  for (int l = 0; l < layers && ret == 0; l++)
+    for (int r = 0; r <= L; r++) {
+      if (p + 6 <= n && cs[p] == 0xFF && cs[p + 1] == 0x91) p += 6;  /* SOP */
+      int s0 = r == 0 ? 0 : 1 + 3 * (r - 1), s1 = r == 0 ? 1 : s0 + 3;
+      bitr br; br_init(&br, cs, n, p);
+      int *plen = (int *)calloc(ncb ? ncb : 1, sizeof(int));
+      if (br_bit(&br)) {
+        for (int s = s0; s < s1; s++) {
+          int gx = (sb[s].w + cbw - 1) / cbw;
+          for (int i = first_cb[s]; i < first_cb[s + 1]; i++) {
+            dblk *c = &cb[i];
+            int bx = (i - first_cb[s]) % gx, by = (i - first_cb[s]) / gx;
+            if (!c->incl) {
+              if (!tt_decode(&incl[s], &br, bx, by, l + 1)) continue;
+              int t = 1;
+              while (!tt_decode(&zbpt[s], &br, bx, by, t)) t++;
+              c->zbp = zbpt[s].val[zbpt[s].off[0] + by * zbpt[s].lw[0] + bx];
+              c->incl = 1;
+            } else if (!br_bit(&br)) continue;
+            int np = get_npasses(&br);
+            while (br_bit(&br)) c->lblock++;
+            int ln = (int)br_bits(&br, c->lblock + ilog2f_(np));
+            plen[i] = ln;
+            if (l < use_layers) c->npasses += np;
+            else plen[i] = -ln;  /* skipped layer: bytes are stepped over */
+          }
+        }
+      }
+      p = br_align(&br);
+      if ((scod & 4) && p + 2 <= n && cs[p] == 0xFF && cs[p + 1] == 0x92) p += 2;  /* EPH */
+      for (int s = s0; s < s1; s++)
+        for (int i = first_cb[s]; i < first_cb[s + 1]; i++) {
+          int ln = plen[i];
+          if (ln > 0) {
+            dblk *c = &cb[i];
+            if ((size_t)(c->len + ln) > c->cap) { c->cap = (size_t)(c->len + ln) * 2 + 64; c->data = (uint8_t *)realloc(c->data, c->cap); }
+            if (p + (size_t)ln > n) { ret = -5; break; }
+            memcpy(c->data + c->len, cs + p, (size_t)ln); c->len += ln;
+          }
+          p += (size_t)(ln < 0 ? -ln : ln);
+        }
+      free(plen);
+    }
+  (void)end;
+  /* Tier-1 + dequantisation into the Mallat plane */
+  size_t N = (size_t)W * H;
+  int32_t *ip = rev ? (int32_t *)calloc(N, sizeof(int32_t)) : NULL;
+  float *fp = rev ? NULL : (float *)calloc(N, sizeof(float));
+  uint32_t *mag = (uint32_t *)malloc(sizeof(uint32_t) * 64 * 64);
+  uint8_t *lastp = (uint8_t *)malloc(64 * 64), *neg = (uint8_t *)malloc(64 * 64);
+  for (int s = 0; s < nsb && ret == 0; s++) {
+    int gx = (sb[s].w + cbw - 1) / cbw;
+    for (int i = first_cb[s]; i < first_cb[s + 1]; i++) {
+      dblk *c = &cb[i];
+      if (!c->incl || c->npasses == 0) continue;
+      int bx = (i - first_cb[s]) % gx, by = (i - first_cb[s]) / gx;
+      int w = (bx + 1) * cbw <= sb[s].w ? cbw : sb[s].w - bx * cbw, h = (by + 1) * cbh <= sb[s].h ? cbh : sb[s].h - by * cbh;
+      int nbps = sb[s].Mb - c->zbp;
+      t1_decode_block(c->data, c->len, c->npasses, nbps, w, h, sb[s].orient, mag, lastp, neg);
+      for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+          uint32_t m = mag[y * 64 + x];
+          size_t o = (size_t)(sb[s].y0 + by * cbh + y) * W + sb[s].x0 + bx * cbw + x;
+          if (!m) continue;
+          int pl = lastp[y * 64 + x];
+          if (rev) {  /* bits below the last decoded plane: midpoint (none left when every pass was decoded) */
+            int32_t v = (int32_t)m + (pl > 0 ? (1 << (pl - 1)) : 0);
+            ip[o] = neg[y * 64 + x] ? -v : v;
+          } else {    /* E.1.1.2 with r = 1/2 */
+            float v = ((float)m + (pl > 0 ? (float)(1 << (pl - 1)) : 0.5f)) * sb[s].delta;
+            fp[o] = neg[y * 64 + x] ? -v : v;
+          }
+        }
+    }
+  }
+  /* inverse DWT: levels L .. 1, horizontal then vertical (the reverse of F.4.2's order) */
+  if (ret == 0) {
+    int ws[MAX_LEVELS + 1], hs[MAX_LEVELS + 1];
+    ws[0] = W; hs[0] = H;
+    for (int d = 1; d <= L; d++) { ws[d] = (ws[d - 1] + 1) >> 1; hs[d] = (hs[d - 1] + 1) >> 1; }
+    void *tmp = malloc(sizeof(float) * 3 * (size_t)((W > H ? W : H) + 8));
+    for (int d = L; d >= 1; d--) {
+      int w = ws[d - 1], h = hs[d - 1];
+      if (rev) {
+        for (int y = 0; y < h; y++) idwt53_1d(ip + (size_t)y * W, w, 1, (int32_t *)tmp);
+        for (int x = 0; x < w; x++) idwt53_1d(ip + x, h, W, (int32_t *)tmp);
+      } else {
+        for (int y = 0; y < h; y++) idwt97_1d(fp + (size_t)y * W, w, 1, (float *)tmp);
+        for (int x = 0; x < w; x++) idwt97_1d(fp + x, h, W, (float *)tmp);
+      }
+    }
+    free(tmp);
+    int shift = sgnd ? 0 : 1 << (prec - 1), lo = sgnd ? -(1 << (prec - 1)) : 0, hi = sgnd ? (1 << (prec - 1)) - 1 : (1 << prec) - 1;
+    for (size_t i = 0; i < N; i++) {
+      long v = rev ? (long)ip[i] : lrintf(fp[i]);
+      v += shift;
+      v = v < lo ? lo : (v > hi ? hi : v);
+      if (prec <= 8) ((uint8_t *)out)[i] = (uint8_t)v; else ((int16_t *)out)[i] = (int16_t)v;
+    }
+  }
+  for (int s = 0; s < nsb; s++) if (incl[s].val) { tt_free(&incl[s]); tt_free(&zbpt[s]); }
+  for (int i = 0; i < ncb; i++) free(cb[i].data);
+  free(incl); free(zbpt); free(cb); free(ip); free(fp); free(mag); free(lastp); free(neg);
+  return ret;
+#undef U32
+}

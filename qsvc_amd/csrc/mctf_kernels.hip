@@ -410,11 +410,6 @@ __global__ void __launch_bounds__(256) k_pred_chroma8(PredArgs a) {
     if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;
   }
 }
-// Q7: the chroma margin state picture i leaves behind (one launch per picture, in order)
-__global__ void __launch_bounds__(256) k_pred_margin(PredArgs a, int i) {
-  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (k < margin_geom(a.g).count()) pred_margin_thread(a, k, i, 1 + (int)blockIdx.y);
-}
 // histogram of the motion components + 128 (decorrelate.cpp:805-812)
 __global__ void __launch_bounds__(256) k_mv_hist(const int16_t* mv, size_t per_pic, unsigned* hist) {
   __shared__ unsigned h[256];
@@ -431,11 +426,7 @@ void launch_predict(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
   if (!a.odd_out) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
   dim3 block(64, 4);
-  if (a.margin) {
-    size_t cnt = margin_geom(g).count();
-    for (int i = 0; i + 1 < g.nB; i++)  // the last picture's state has no reader
-      hipLaunchKernelGGL(k_pred_margin, dim3((unsigned)((cnt + 255) / 256), 2), dim3(256), 0, st, a, i);
-  }
+  if (a.margin) launch_pred_margin(st, a);  // mctf_margin.hip
   if (g.bs % 8 == 0) hipLaunchKernelGGL(k_pred_luma8, dim3((g.W + 511) / 512, (g.H + 3) / 4, g.nB), block, 0, st, a);
   else hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);
   const dim3 cgrid((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, g.nB * 2);
