@@ -169,6 +169,14 @@ int qsvc_j2k_encode_planes_s16(qsvc_ctx* ctx, const int16_t* planes, int nplanes
 /* Unit-testable transform: level shift + `levels` of forward DWT of a host 8-bit plane, Mallat layout.
  * out receives H*W int32 (reversible 5/3) or H*W float32 (irreversible 9/7, before quantisation). */
 int qsvc_j2k_dwt(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, int reversible, int levels, void* out);
+/* ---- JPEG 2000 decoding (replaces the external `kdu_expand` call,
+ *      texture_expand_fb_j2k.py:153-162 and motion_expand_j2k.py) -------------------------- */
+/* `nstreams` single-component code-streams (host memory) -> their sample planes, back to back in `out` (host): W*H bytes for
+ * 8-bit unsigned streams, W*H int16 for 16-bit signed ones; offs[nstreams+1] receives the byte offsets, widths / heights
+ * (optional) the geometry read from each SIZ marker.  max_layers <= 0 decodes every quality layer.  All streams of one call
+ * share the transform (5/3 or 9/7).  Scope: one tile, LRCP, no precinct partition, code-block style 0. */
+int qsvc_j2k_decode_planes(qsvc_ctx* ctx, int nstreams, const uint8_t* const* streams, const size_t* lens, int max_layers,
+                           void* out, size_t cap, size_t* offs, int* widths, int* heights);
 /* Statistics of the last qsvc_j2k_encode_* call: code-blocks coded, coding passes, MQ symbols. */
 int qsvc_j2k_stats(qsvc_ctx* ctx, uint64_t* codeblocks, uint64_t* passes, uint64_t* symbols);
 

@@ -108,6 +108,7 @@ void qsvc_destroy(qsvc_ctx* c) {
   if (c->comm) qsvc_comm_destroy(c);
   c->scal.release(); c->tmp16[0].release(); c->tmp16[1].release();
   j2k_release(c);
+  j2k_decode_release(c);
   for (auto& s : c->segs) for (auto& p : s.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->st);
   delete c;

@@ -50,6 +50,7 @@ struct HostSeg {  // host-side wall time of a named stage (profiling on): report
 };
 
 struct J2kState;
+struct J2kDecState;
 
 struct qsvc_ctx {
   int dev = 0;
@@ -73,8 +74,10 @@ struct qsvc_ctx {
   std::vector<HostSeg> hsegs;
   void host_time(const char* name, double ms);
   J2kState* j2k = nullptr;
+  J2kDecState* j2kdec = nullptr;
   int fail(int code, const char* fmt, ...);
   int hipfail(hipError_t e, const char* what);
 };
 
 void j2k_release(qsvc_ctx* c);
+void j2k_decode_release(qsvc_ctx* c);

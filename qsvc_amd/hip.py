@@ -22,7 +22,7 @@ SYMBOLS = [
     "qsvc_get_frame_types", "qsvc_get_histograms", "qsvc_motion_estimate", "qsvc_decorrelate", "qsvc_update",
     "qsvc_analyze_step", "qsvc_un_update", "qsvc_correlate", "qsvc_synthesize_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_dwt53_trunc",
-    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_j2k_dwt", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
 ]
 
 
@@ -83,6 +83,8 @@ def load_library() -> C.CDLL:
     L.qsvc_j2k_encode_plane.argtypes = [vp, u8p, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_encode_planes_s16.argtypes = [vp, i16p, i, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_dwt.argtypes = [vp, u8p, i, i, i, i, vp]
+    L.qsvc_j2k_decode_planes.argtypes = [vp, i, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i, vp, C.c_size_t, C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.qsvc_j2k_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qsvc_set_profiling.argtypes = [vp, i]
     L.qsvc_get_timings.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), i]
@@ -294,6 +296,30 @@ class Engine:
         out = np.empty((H, W), dtype=np.int32 if reversible else np.float32)
         self._chk(self.L.qsvc_j2k_dwt(self.h, p.ctypes.data, H, W, int(reversible), levels, out.ctypes.data))
         return out
+
+    def j2k_decode_planes(self, streams, max_layers=0):
+        """Code-streams (bytes) -> list of sample planes: uint8 (8-bit unsigned) or int16 (16-bit signed)."""
+        streams = [bytes(s) for s in streams]
+        n = len(streams)
+        if n == 0:
+            return []
+        geo = []
+        for cs in streams:  # SOC, SIZ marker, Lsiz, Rsiz, Xsiz, Ysiz ... Ssiz at byte 42
+            if len(cs) < 44 or cs[:4] != b"\xff\x4f\xff\x51":
+                raise QsvcError(-1, "not a JPEG 2000 code-stream (SOC/SIZ missing)")
+            geo.append((int.from_bytes(cs[8:12], "big"), int.from_bytes(cs[12:16], "big"), (cs[42] & 0x7F) + 1 > 8))
+        cap = sum(w * h * (2 if p16 else 1) + 2 for (w, h, p16) in geo) + 64
+        out = np.empty(cap, dtype=np.uint8)
+        ptrs = (C.c_char_p * n)(*streams)
+        lens = (C.c_size_t * n)(*[len(s) for s in streams])
+        offs = (C.c_size_t * (n + 1))()
+        Ws, Hs = (C.c_int * n)(), (C.c_int * n)()
+        self._chk(self.L.qsvc_j2k_decode_planes(self.h, n, ptrs, lens, int(max_layers), out.ctypes.data, cap, offs, Ws, Hs))
+        res = []
+        for k, (w, h, p16) in enumerate(geo):
+            a = out[offs[k]:offs[k] + w * h * (2 if p16 else 1)]
+            res.append(a.view(np.int16).reshape(h, w).copy() if p16 else a.reshape(h, w).copy())
+        return res
 
     def j2k_stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
