@@ -82,6 +82,12 @@ int qsvc_get_frame_types(qsvc_ctx* ctx, int t, int b_pictures, char* types);
  * (decorrelate.cpp:798-819,945-950) -- what the I/B decision is made from. */
 int qsvc_get_histograms(qsvc_ctx* ctx, int t, int b_pictures, uint32_t* hist);
 
+/* Options the reference's stage tools take as flags; they apply to the stage calls that follow.
+ *   block_overlaping : decorrelate / correlate --block_overlaping (decorrelate.cpp:84-172): 0, 1 or a power of two
+ *   border_size      : motion_estimate --border_size (motion_estimate.cpp:213-217,714): the SAD window grows by it
+ *   subpixel_accuracy: only 0 (QSVC_ERR_UNSUPPORTED otherwise) */
+int qsvc_set_mctf_options(qsvc_ctx* ctx, int block_overlaping, int border_size, int subpixel_accuracy);
+
 /* ---- MCTF stages: one call = one reference executable over one temporal level -------------- */
 /* replaces `motion_estimate` (motion_estimate.cpp:490-912; me_for_image :260-412):
  * low_{t-1} -> motion_t.  pictures = number of pictures in low_{t-1}. */

@@ -235,8 +235,10 @@ static int desp(int x, int l) { /* motion_estimate.cpp:232-236 */
 typedef struct { int BY, BX; int16_t *f[4]; } mvfield; /* f[0]=PREV-X f[1]=PREV-Y f[2]=NEXT-X f[3]=NEXT-Y */
 #define MV(m, k, by, bx) ((m)->f[k][(size_t)(by) * (m)->BX + (bx)])
 
-/* local_me_for_block (motion_estimate.cpp:70-184), border_size = 0. */
-static void me_block(mvfield *mv, const bplane *r0, const bplane *r1, const bplane *pr, int bs, int by, int bx) {
+/* local_me_for_block (motion_estimate.cpp:70-184); `bord` = border_size: the SAD window grows by it on every side
+ * (local_me_for_image, :213-217).  The predicted plane's own border is never filled by the reference (:792-796 read the
+ * interior only): it reads as the zeros of a fresh heap there, which is what calloc gives here. */
+static void me_block(mvfield *mv, const bplane *r0, const bplane *r1, const bplane *pr, int bs, int bord, int by, int bx) {
   static const int cand[9][2] = {{-1, -1}, {-1, 1}, {1, -1}, {1, 1}, {-1, 0}, {1, 0}, {0, 1}, {0, -1}, {0, 0}};
   int pvy = MV(mv, 1, by, bx), pvx = MV(mv, 0, by, bx), nvy = MV(mv, 3, by, bx), nvx = MV(mv, 2, by, bx);
   int best[2] = {0, 0}, vy[2] = {0, 0}, vx[2] = {0, 0};
@@ -246,8 +248,8 @@ static void me_block(mvfield *mv, const bplane *r0, const bplane *r1, const bpla
     int16_t yy[2] = {(int16_t)(pvy + dy), (int16_t)(nvy - dy)};
     int16_t xx[2] = {(int16_t)(pvx + dx), (int16_t)(nvx - dx)};
     int err[2] = {0, 0};
-    for (int py = y0; py < y0 + bs; py++)
-      for (int px = x0; px < x0 + bs; px++) {
+    for (int py = y0 - bord; py < y0 + bs + bord; py++)
+      for (int px = x0 - bord; px < x0 + bs + bord; px++) {
         int pv = BP(pr, py, px);
         err[0] += abs(pv - BP(r0, py + yy[0], px + xx[0]));
         err[1] += abs(pv - BP(r1, py + yy[1], px + xx[1]));
@@ -258,23 +260,23 @@ static void me_block(mvfield *mv, const bplane *r0, const bplane *r1, const bpla
   MV(mv, 1, by, bx) = (int16_t)vy[0]; MV(mv, 0, by, bx) = (int16_t)vx[0];
   MV(mv, 3, by, bx) = (int16_t)vy[1]; MV(mv, 2, by, bx) = (int16_t)vx[1];
 }
-static void me_search(mvfield *mv, const bplane *r0, const bplane *r1, const bplane *pr, int bs, int nby, int nbx) {
+static void me_search(mvfield *mv, const bplane *r0, const bplane *r1, const bplane *pr, int bs, int bord, int nby, int nbx) {
   for (int by = 0; by < nby; by++) /* local_me_for_image, motion_estimate.cpp:196-225 */
-    for (int bx = 0; bx < nbx; bx++) me_block(mv, r0, r1, pr, bs, by, bx);
+    for (int bx = 0; bx < nbx; bx++) me_block(mv, r0, r1, pr, bs, bord, by, bx);
 }
 
 static int ilog2_rint(int s) { return (int)rint(log((double)s) / log(2.0)); }
 
 /* me_for_image (motion_estimate.cpp:260-412), FAST_SEARCH path, subpixel_accuracy = 0:
  * literal replay (analyse L levels, search, then per level synthesise / expand MVs / search). */
-static void me_picture(mvfield *mv, bplane *r0, bplane *r1, bplane *pr, int H, int W, int bs, int S) {
+static void me_picture(mvfield *mv, bplane *r0, bplane *r1, bplane *pr, int H, int W, int bs, int S, int bord) {
   int L = ilog2_rint(S) - 1;
   int BY = mv->BY, BX = mv->BX;
   int La = L < 0 ? 0 : L;
   qo_dwt53t_analyze(r0->px, r0->stride, H, W, L);
   qo_dwt53t_analyze(r1->px, r1->stride, H, W, L);
   qo_dwt53t_analyze(pr->px, pr->stride, H, W, L);
-  me_search(mv, r0, r1, pr, bs, desp(BY, La), desp(BX, La));
+  me_search(mv, r0, r1, pr, bs, bord, desp(BY, La), desp(BX, La));
   for (int l = L - 1; l >= 0; --l) {
     int Yl = desp(H, l), Xl = desp(W, l), byl = desp(BY, l), bxl = desp(BX, l);
     qo_dwt53t_synthesize(r0->px, r0->stride, Yl, Xl, 1);
@@ -289,7 +291,7 @@ static void me_picture(mvfield *mv, bplane *r0, bplane *r1, bplane *pr, int H, i
           if (v < -S) v = (int16_t)-S;
           MV(mv, k, by, bx) = v;
         }
-    me_search(mv, r0, r1, pr, bs, byl, bxl);
+    me_search(mv, r0, r1, pr, bs, bord, byl, bxl);
   }
 }
 
@@ -297,12 +299,12 @@ static size_t frame_bytes(int W, int H) { return (size_t)W * H + 2 * (size_t)(W 
 
 /* motion_estimate main loop (motion_estimate.cpp:714-907).  `low` holds P pictures; even[i] is
  * picture 2i, odd[i] picture 2i+1 (split.cpp:226-341).  mv_out: [P/2][4][BY][BX]. */
-int qo_motion_estimate(const uint8_t *low, int P, int W, int H, int bs, int S, int16_t *mv_out) {
-  if (bs <= 0 || S <= 0 || W < 2 || H < 2) return QO_EINVAL;
+int qo_motion_estimate_b(const uint8_t *low, int P, int W, int H, int bs, int S, int bord, int16_t *mv_out) {
+  if (bs <= 0 || S <= 0 || W < 2 || H < 2 || bord < 0) return QO_EINVAL;
   int BY = H / bs, BX = W / bs, nB = P / 2;
   size_t F = frame_bytes(W, H), fld = (size_t)BY * BX;
   bplane r[2], pr;
-  if (bplane_alloc(&r[0], H, W, S) || bplane_alloc(&r[1], H, W, S) || bplane_alloc(&pr, H, W, S)) return QO_EINVAL;
+  if (bplane_alloc(&r[0], H, W, S + bord) || bplane_alloc(&r[1], H, W, S + bord) || bplane_alloc(&pr, H, W, S + bord)) return QO_EINVAL;
   mvfield mv; mv.BY = BY; mv.BX = BX;
   int a = 0;
   bplane_load_u8(&r[a], low, H, W);
@@ -312,11 +314,15 @@ int qo_motion_estimate(const uint8_t *low, int P, int W, int H, int bs, int S, i
     bplane_load_u8(&r[1 - a], low + (size_t)(2 * i + 2) * F, H, W);
     bplane_fill_border(&r[1 - a]);
     for (int k = 0; k < 4; k++) { mv.f[k] = mv_out + ((size_t)i * 4 + k) * fld; memset(mv.f[k], 0, fld * sizeof(int16_t)); }
-    me_picture(&mv, &r[a], &r[1 - a], &pr, H, W, bs, S);
+    me_picture(&mv, &r[a], &r[1 - a], &pr, H, W, bs, S, bord);
     a = 1 - a; /* swap (:902-906): the new PREV reference keeps whatever state the replay left */
   }
   bplane_free(&r[0]); bplane_free(&r[1]); bplane_free(&pr);
   return QO_OK;
+}
+
+int qo_motion_estimate(const uint8_t *low, int P, int W, int H, int bs, int S, int16_t *mv_out) {
+  return qo_motion_estimate_b(low, P, W, H, bs, S, 0, mv_out);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -373,9 +379,15 @@ static void chroma_up(int16_t *px, int stride, const uint8_t *src, int H, int W)
  * (decorrelate.cpp:1029-1068). */
 static int decor_run(int synth, const uint8_t *ev_base, size_t ev_step, const uint8_t *od_base, size_t od_step, int P,
                      int W, int H, int bs, int S, int always_B, const int16_t *mv_in, uint8_t *high, char *types,
-                     int16_t *mv_out, uint8_t *prediction, int *hists, uint8_t *odd_out) {
-  if (bs <= 0 || S <= 0 || W < 4 || H < 4) return QO_EINVAL;
-  int BY = H / bs, BX = W / bs, nB = P / 2, b = 4 * S;
+                     int16_t *mv_out, uint8_t *prediction, int *hists, uint8_t *odd_out, int ov) {
+  if (bs <= 0 || S <= 0 || W < 4 || H < 4 || ov < 0) return QO_EINVAL;
+  int BY = H / bs, BX = W / bs, nB = P / 2, b = 4 * S + ov; /* decorrelate.cpp:539 */
+  /* --block_overlaping (predict(), decorrelate.cpp:84-172): every block's prediction is taken with a margin of `ov` samples,
+   * analysed `levels` = rint(log2 ov) levels (truncating 5/3, in place), its subbands are copied without their margin into
+   * the picture's Mallat layout, and the picture is synthesised back.  ov = 1 gives levels = 0: the plain block copy. */
+  int levels = ov > 0 ? (int)rint(log((double)ov) / log(2.0)) : 0;
+  int nb_ = bs + 2 * ov;
+  int16_t *blk = (int16_t *)calloc((size_t)nb_ * nb_, sizeof(int16_t));
   int cw = W / 2, ch = H / 2;
   size_t F = frame_bytes(W, H), fld = (size_t)BY * BX;
   bplane ref[2][3];
@@ -411,17 +423,33 @@ static int decor_run(int synth, const uint8_t *ev_base, size_t ev_step, const ui
         hmv[(mvy0[k] + 128) & 255]++; hmv[(mvx0[k] + 128) & 255]++;
         hmv[(mvy1[k] + 128) & 255]++; hmv[(mvx1[k] + 128) & 255]++;
       }
-    /* predict(): decorrelate.cpp:86-108,153-167 */
-    for (int c = 0; c < 3; c++)
+    /* predict(): decorrelate.cpp:86-172 */
+    for (int c = 0; c < 3; c++) {
       for (int by = 0; by < BY; by++)
         for (int bx = 0; bx < BX; bx++) {
           size_t k = (size_t)by * BX + bx;
           int y0 = mvy0[k] + by * bs, y1 = mvy1[k] + by * bs, x0 = mvx0[k] + bx * bs, x1 = mvx1[k] + bx * bs;
-          for (int y = 0; y < bs; y++)
-            for (int x = 0; x < bs; x++)
-              pred[c][(size_t)(by * bs + y) * W + bx * bs + x] =
-                  (int16_t)((BP(&ref[a][c], y0 + y, x0 + x) + BP(&ref[n][c], y1 + y, x1 + x)) / 2);
+          for (int y = -ov; y < bs + ov; y++)
+            for (int x = -ov; x < bs + ov; x++)
+              blk[(size_t)(y + ov) * nb_ + x + ov] = (int16_t)((BP(&ref[a][c], y0 + y, x0 + x) + BP(&ref[n][c], y1 + y, x1 + x)) / 2);
+          qo_dwt53t_analyze(blk, nb_, nb_, nb_, levels); /* :110-113 */
+          for (int l = 1; l <= levels; l++) { /* :116-146: names as the reference's comments */
+            int bsl = bs >> l, o1 = ov >> l, o3 = (bs + ov * 3) >> l;
+            for (int y = 0; y < bsl; y++)
+              for (int x = 0; x < bsl; x++) {
+                pred[c][(size_t)(by * bsl + y) * W + (W >> l) + bx * bsl + x] = blk[(size_t)(o1 + y) * nb_ + o3 + x];
+                pred[c][(size_t)((H >> l) + by * bsl + y) * W + bx * bsl + x] = blk[(size_t)(o3 + y) * nb_ + o1 + x];
+                pred[c][(size_t)((H >> l) + by * bsl + y) * W + (W >> l) + bx * bsl + x] = blk[(size_t)(o3 + y) * nb_ + o3 + x];
+              }
+          }
+          {
+            int bsl = bs >> levels, o1 = ov >> levels;
+            for (int y = 0; y < bsl; y++)
+              for (int x = 0; x < bsl; x++) pred[c][(size_t)(by * bsl + y) * W + bx * bsl + x] = blk[(size_t)(o1 + y) * nb_ + o1 + x];
+          }
         }
+      qo_dwt53t_synthesize(pred[c], W, H, W, levels); /* :172 */
+    }
     for (int c = 0; c < 3; c++) /* clip, decorrelate.cpp:841-848 */
       for (size_t k = 0; k < (size_t)H * W; k++) {
         if (pred[c][k] < 0) pred[c][k] = 0; else if (pred[c][k] > 255) pred[c][k] = 255;
@@ -487,20 +515,29 @@ static int decor_run(int synth, const uint8_t *ev_base, size_t ev_step, const ui
   for (int i = 0; i < 2; i++)
     for (int c = 0; c < 3; c++) bplane_free(&ref[i][c]);
   for (int c = 0; c < 3; c++) free(pred[c]);
+  free(blk);
   return QO_OK;
 }
 
+int qo_decorrelate_ov(const uint8_t *low, int P, int W, int H, int bs, int S, int always_B, const int16_t *mv_in,
+                      uint8_t *high, char *types, int16_t *mv_out, uint8_t *prediction, int *hists, int ov) {
+  size_t F = frame_bytes(W, H);
+  return decor_run(0, low, 2 * F, low + F, 2 * F, P, W, H, bs, S, always_B, mv_in, high, types, mv_out, prediction, hists, 0, ov);
+}
 int qo_decorrelate(const uint8_t *low, int P, int W, int H, int bs, int S, int always_B, const int16_t *mv_in,
                    uint8_t *high, char *types, int16_t *mv_out, uint8_t *prediction, int *hists) {
-  size_t F = frame_bytes(W, H);
-  return decor_run(0, low, 2 * F, low + F, 2 * F, P, W, H, bs, S, always_B, mv_in, high, types, mv_out, prediction, hists, 0);
+  return qo_decorrelate_ov(low, P, W, H, bs, S, always_B, mv_in, high, types, mv_out, prediction, hists, 0);
 }
 /* correlate (decorrelate.cpp without ANALYZE; synthesize_step.py:117-136): even [P/2+1] frames (what un_update wrote),
  * high/types/mv as decoded -> odd_out [P/2] frames. */
+int qo_correlate_ov(const uint8_t *even, int P, int W, int H, int bs, int S, const int16_t *mv, const uint8_t *high,
+                    const char *types, uint8_t *odd_out, uint8_t *prediction, int ov) {
+  return decor_run(1, even, frame_bytes(W, H), 0, 0, P, W, H, bs, S, 1, mv, (uint8_t *)high, (char *)types, 0, prediction, 0,
+                   odd_out, ov);
+}
 int qo_correlate(const uint8_t *even, int P, int W, int H, int bs, int S, const int16_t *mv, const uint8_t *high,
                  const char *types, uint8_t *odd_out, uint8_t *prediction) {
-  return decor_run(1, even, frame_bytes(W, H), 0, 0, P, W, H, bs, S, 1, mv, (uint8_t *)high, (char *)types, 0, prediction, 0,
-                   odd_out);
+  return qo_correlate_ov(even, P, W, H, bs, S, mv, high, types, odd_out, prediction, 0);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -88,3 +88,17 @@ def interleave(even: np.ndarray, odd: np.ndarray) -> np.ndarray:
     low[0::2] = even[:nB + 1]
     low[1::2] = odd
     return low
+
+
+def apply_mctf_options(e, a):
+    """--block_overlaping / --border_size / --subpixel_accuracy of the reference's tools -> the engine.
+    subpixel_accuracy other than 0 is refused by the library (QSVC_ERR_UNSUPPORTED), with the drivers' exit status."""
+    from .. import hip
+    sp = a.get("subpixel_accuracy", 0)
+    if isinstance(sp, str):  # synthesize takes a comma list, one entry per level
+        vals = {int(x) for x in sp.split(",") if x != ""}
+        sp = max(vals) if vals else 0
+    try:
+        e.set_mctf_options(int(a.get("block_overlaping", 0) or 0), int(a.get("border_size", 0) or 0), int(sp or 0))
+    except hip.QsvcError as ex:
+        die(str(ex))

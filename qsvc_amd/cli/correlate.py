@@ -8,8 +8,6 @@ def main(argv=None):
         "block_overlaping": (0, int), "block_size": (16, int), "even_fn": ("even", str), "frame_types_fn": ("frame_types", str),
         "high_fn": ("high", str), "motion_in_fn": ("motion_in", str), "odd_fn": ("odd", str), "pictures": (33, int),
         "pixels_in_x": (352, int), "pixels_in_y": (288, int), "search_range": (4, int), "subpixel_accuracy": (0, int)}, argv)
-    if a["block_overlaping"] or a["subpixel_accuracy"]:
-        C.die("block_overlaping / subpixel_accuracy other than 0 are not implemented on this path (SURVEY.md N4)")
     from .. import hip
     import numpy as np
     W, H, bs, nB = a["pixels_in_x"], a["pixels_in_y"], a["block_size"], a["pictures"] // 2
@@ -23,6 +21,7 @@ def main(argv=None):
     e = C.engine()
     try:
         e.seq_config(W, H)
+        C.apply_mctf_options(e, a)
         e.put_frames(hip.LOW, 0, C.interleave(even, np.zeros((nB, even.shape[1]), dtype=np.uint8)))
         e.put_frames(hip.HIGH, 1, high)
         e.put_motion(hip.MOTION_FILTERED, 1, mv, bs)

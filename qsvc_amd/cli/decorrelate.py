@@ -9,8 +9,6 @@ def main(argv=None):
         "frame_types_fn": ("frame_types", str), "high_fn": ("high", str), "motion_in_fn": ("motion_in", str),
         "motion_out_fn": ("motion_out", str), "odd_fn": ("odd", str), "pictures": (33, int), "pixels_in_x": (352, int),
         "pixels_in_y": (288, int), "search_range": (4, int), "subpixel_accuracy": (0, int), "always_B": (0, int)}, argv)
-    if a["block_overlaping"] or a["subpixel_accuracy"]:
-        C.die("block_overlaping / subpixel_accuracy other than 0 are not implemented on this path")
     from .. import hip
     W, H, bs, nB = a["pixels_in_x"], a["pixels_in_y"], a["block_size"], a["pictures"] // 2
     low = C.interleave(C.read_frames(a["even_fn"], W, H, nB + 1), C.read_frames(a["odd_fn"], W, H, nB))
@@ -18,6 +16,7 @@ def main(argv=None):
     e = C.engine()
     try:
         e.seq_config(W, H, keep_prediction=True)
+        C.apply_mctf_options(e, a)
         e.put_frames(hip.LOW, 0, low)
         e.put_motion(hip.MOTION_RAW, 1, mv, bs)
         e.decorrelate(1, low.shape[0], bs, a["search_range"], a["always_B"])

@@ -25,8 +25,11 @@ EXT = {"reversible": (0, int), "lossless": (0, int), "base_step": (1.0 / 256, fl
 
 
 def _refuse_deferred(a):
-    if a.get("block_overlaping") or a.get("subpixel_accuracy") or a.get("border_size"):
-        C.die("block_overlaping / subpixel_accuracy / border_size other than 0 are not implemented on this path (SURVEY.md N4)")
+    """--subpixel_accuracy > 0 (motion_estimate.cpp:361-412, decorrelate.cpp:656-686) is the one deferred MCTF option left: refused
+    before any work (the library refuses it too).  --block_overlaping and --border_size go to the engine (C.apply_mctf_options)."""
+    sp = a.get("subpixel_accuracy", 0)
+    if (any(int(x) for x in sp.split(",") if x != "") if isinstance(sp, str) else sp):
+        C.die("subpixel_accuracy other than 0 is not implemented on this path (SURVEY.md N4)")
 
 
 def _write_level(e, t, P, bs, W, H, low_prev, want_pred=True):
@@ -57,6 +60,7 @@ def analyze_step(argv=None):
     e = C.engine()
     try:
         e.seq_config(W, H, keep_prediction=True)
+        C.apply_mctf_options(e, a)
         e.put_frames(hip.LOW, t - 1, low_prev)
         e.analyze_step(t, low_prev.shape[0], bs, a["search_range"], a["always_B"], a["update_factor"])
         _write_level(e, t, low_prev.shape[0], bs, W, H, low_prev)
@@ -100,6 +104,7 @@ def synthesize_step(argv=None):
     e = C.engine()
     try:
         e.seq_config(W, H)
+        C.apply_mctf_options(e, a)
         _load_subband(e, t, nB, bs, W, H, with_low=True)
         e.synthesize_step(t, 2 * nB + 1, bs, a["search_range"], a["update_factor"])
         _write_synth_level(e, t, 2 * nB + 1)
@@ -116,8 +121,7 @@ def synthesize(argv=None):
         "GOPs": (1, int), "TRLs": (4, int), "block_size": ("16,16,16,16", str), "pixels_in_x": ("352,352,352,352,352", str),
         "pixels_in_y": ("288,288,288,288,288", str), "subpixel_accuracy": ("0,0,0,0", str), "border_size": (0, int),
         "block_overlaping": (0, int), "search_range": (4, int), "update_factor": (1.0 / 4, float)}, argv)
-    if a["block_overlaping"] or a["border_size"] or any(int(x) for x in a["subpixel_accuracy"].split(",")):
-        C.die("block_overlaping / subpixel_accuracy / border_size other than 0 are not implemented on this path (SURVEY.md N4)")
+    _refuse_deferred(a)
     from .. import hip
     TRLs = a["TRLs"]
     if TRLs < 2:
@@ -135,6 +139,7 @@ def synthesize(argv=None):
     e = C.engine()
     try:
         e.seq_config(W, H)
+        C.apply_mctf_options(e, a)
         for t in range(TRLs - 1, 0, -1):
             P, S = P0, a["search_range"]
             for _ in range(1, t):  # synthesize.py:118-124,160-168
@@ -188,6 +193,7 @@ def analyze(argv=None):
     e = C.engine()
     try:
         e.seq_config(W, H, keep_prediction=True)
+        C.apply_mctf_options(e, a)
         _run_analyze(e, a, low0)
     except hip.QsvcError as ex:
         C.die(str(ex))
@@ -267,6 +273,7 @@ def compress(argv=None):
     e = C.engine()
     try:
         e.seq_config(W, H, keep_prediction=bool(a["keep_intermediates"]))
+        C.apply_mctf_options(e, a)
         e.put_frames(hip.LOW, 0, low0)
         if a["TRLs"] > 1:  # compress.py:176-212
             _run_analyze(e, a, low0, keep=bool(a["keep_intermediates"]))

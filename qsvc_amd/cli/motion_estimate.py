@@ -1,7 +1,6 @@
 """`mctf motion_estimate` (trunk/src/motion_estimate.cpp:490-912): even_t, odd_t -> motion_t on the GPU.
 Flags as motion_estimate.cpp:516-530.  Differences, both deliberate: an existing motion file is
-overwritten (the reference exits 1, which aborts the pipeline); border_size/subpixel_accuracy other than 0 are
-refused (deferred options)."""
+overwritten (the reference exits 1, which aborts the pipeline); subpixel_accuracy other than 0 is refused."""
 from . import common as C
 
 
@@ -10,14 +9,13 @@ def main(argv=None):
         "block_size": (32, int), "border_size": (0, int), "even_fn": ("even", str), "imotion_fn": ("imotion", str),
         "motion_fn": ("motion", str), "odd_fn": ("odd", str), "pictures": (9, int), "pixels_in_x": (352, int),
         "pixels_in_y": (288, int), "search_range": (4, int), "subpixel_accuracy": (0, int)}, argv)
-    if a["border_size"] or a["subpixel_accuracy"]:
-        C.die("border_size / subpixel_accuracy other than 0 are not implemented on this path")
     from .. import hip
     W, H, bs, nB = a["pixels_in_x"], a["pixels_in_y"], a["block_size"], a["pictures"] // 2
     low = C.interleave(C.read_frames(a["even_fn"], W, H, nB + 1), C.read_frames(a["odd_fn"], W, H, nB))
     e = C.engine()
     try:
         e.seq_config(W, H)
+        C.apply_mctf_options(e, a)
         e.put_frames(hip.LOW, 0, low)
         e.motion_estimate(1, low.shape[0], bs, a["search_range"])
         C.write_motion(a["motion_fn"], e.get_motion(hip.MOTION_RAW, 1, nB, bs))

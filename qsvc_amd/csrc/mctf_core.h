@@ -240,19 +240,24 @@ struct MePlane {
 // candidate order of local_me_for_block (motion_estimate.cpp:124-174): {dy,dx}
 #define QSVC_ME_CANDS {{-1, -1}, {-1, 1}, {1, -1}, {1, 1}, {-1, 0}, {1, 0}, {0, 1}, {0, -1}, {0, 0}}
 // Partial SADs of one block over the pixels idx = lane, lane+nlanes, ...   sad[2*c+d], d: 0 PREV 1 NEXT.
+// bord = --border_size: the compared window is the block grown by bord on every side (local_me_for_image,
+// motion_estimate.cpp:213-217).  The PREDICTED plane is never border-filled by the reference (:792-796 read its interior only):
+// outside the picture it reads as the zeros of a fresh heap, at every pyramid level (the in-place transforms touch the interior).
 template <class T>
 QHD void me_block_sads(const MePlane<T>& r0, const MePlane<T>& r1, const MePlane<T>& pr, int bs, int by, int bx, int pvy,
-                       int pvx, int nvy, int nvx, int lane, int nlanes, int* sad) {
+                       int pvx, int nvy, int nvx, int lane, int nlanes, int* sad, int bord = 0) {
   const int cand[9][2] = QSVC_ME_CANDS;
   for (int k = 0; k < 18; k++) sad[k] = 0;
-  int y0 = by * bs, x0 = bx * bs;
-  // whole 3x3 neighbourhood of both displaced blocks interior -> unchecked reads
-  bool inner = y0 + pvy - 1 >= 0 && y0 + pvy + bs + 1 <= r0.g.H && x0 + pvx - 1 >= 0 && x0 + pvx + bs + 1 <= r0.g.W &&
-               y0 + nvy - 1 >= 0 && y0 + nvy + bs + 1 <= r0.g.H && x0 + nvx - 1 >= 0 && x0 + nvx + bs + 1 <= r0.g.W;
-  for (int idx = lane; idx < bs * bs; idx += nlanes) {
-    int py = y0 + idx / bs, px = x0 + idx % bs;
-    int pv = pr.in(py, px);
+  const int win = bs + 2 * bord;
+  int y0 = by * bs - bord, x0 = bx * bs - bord;
+  // the window and the whole 3x3 neighbourhood of both displaced windows interior -> unchecked reads
+  bool inner = y0 >= 0 && y0 + win <= r0.g.H && x0 >= 0 && x0 + win <= r0.g.W &&
+               y0 + pvy - 1 >= 0 && y0 + pvy + win + 1 <= r0.g.H && x0 + pvx - 1 >= 0 && x0 + pvx + win + 1 <= r0.g.W &&
+               y0 + nvy - 1 >= 0 && y0 + nvy + win + 1 <= r0.g.H && x0 + nvx - 1 >= 0 && x0 + nvx + win + 1 <= r0.g.W;
+  for (int idx = lane; idx < win * win; idx += nlanes) {
+    int py = y0 + idx / win, px = x0 + idx % win;
     if (inner) {
+      int pv = pr.in(py, px);
       for (int c = 0; c < 9; c++) {
         int a = pv - r0.in(py + pvy + cand[c][0], px + pvx + cand[c][1]);
         int b = pv - r1.in(py + nvy - cand[c][0], px + nvx - cand[c][1]);
@@ -260,6 +265,7 @@ QHD void me_block_sads(const MePlane<T>& r0, const MePlane<T>& r1, const MePlane
         sad[2 * c + 1] += b < 0 ? -b : b;
       }
     } else {
+      int pv = ((unsigned)py < (unsigned)pr.g.H && (unsigned)px < (unsigned)pr.g.W) ? pr.in(py, px) : 0;
       for (int c = 0; c < 9; c++) {
         int a = pv - r0.at(py + pvy + cand[c][0], px + pvx + cand[c][1]);
         int b = pv - r1.at(py + nvy - cand[c][0], px + nvx - cand[c][1]);

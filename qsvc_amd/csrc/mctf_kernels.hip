@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(64) k_me_search(MeArgs a) {
   int sad[18];
   if (live) {
     me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
-    me_block_sads<T>(r0, r1, pr, a.g.bs, by, bx, pvy, pvx, nvy, nvx, lane, LPB, sad);
+    me_block_sads<T>(r0, r1, pr, a.g.bs, by, bx, pvy, pvx, nvy, nvx, lane, LPB, sad, a.g.bord);
   } else {
 #pragma unroll
     for (int k = 0; k < 18; k++) sad[k] = 0;
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64) k_me_search8(MeArgs a) {
 }
 void launch_me_search(hipStream_t st, const MeArgs& a) {
   dim3 block(64);
-  if (a.g.bs == 8) {
+  if (a.g.bs == 8 && a.g.bord == 0) {
     dim3 grid((a.nbx + 7) / 8, a.nby, a.g.nB);
     if (a.l == 0) hipLaunchKernelGGL(k_me_search8<uint8_t>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_me_search8<int16_t>, grid, block, 0, st, a);
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_pred_luma8(PredArgs a) {
       uint64_t v = ld8u(r0 + (size_t)y0 * g.W + x0);
       __builtin_memcpy(p0, &v, 8);
     } else {
-      BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+      BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);
       for (int k = 0; k < 8; k++) p0[k] = (uint8_t)luma_b(r0, bg, y0, x0 + k);
     }
     if (!predicted) {
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) k_pred_luma8(PredArgs a) {
       uint64_t v = ld8u(r1 + (size_t)y1 * g.W + x1);
       __builtin_memcpy(p1, &v, 8);
     } else {
-      BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+      BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);
       for (int k = 0; k < 8; k++) p1[k] = (uint8_t)luma_b(r1, bg, y1, x1 + k);
     }
     const size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) k_pred_chroma(PredArgs a) {
   const int i0 = blockIdx.x * PC_TW, j0 = blockIdx.y * PC_TH;
   const int cw = g.W / 2, chh = g.H / 2;
   const int xb = 2 * i0 - 2, yb = 2 * j0 - 2;  // full-resolution origin of the footprint (may be -2)
-  BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+  BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);
   MvField mv = {a.mv + (size_t)i * 4 * g.BY * g.BX, g.BY, g.BX};
   const uint8_t* u0 = frame_c(a.frames, g, 2 * i, c);
   const uint8_t* u1 = frame_c(a.frames, g, 2 * i + 2, c);
@@ -347,7 +347,7 @@ void launch_chroma_up(hipStream_t st, const uint8_t* frames, const LevelGeom& g,
 // lies inside the picture, the per-sample border rule (Q1/Q2) otherwise
 __device__ __forceinline__ uint64_t ref_run8(const uint8_t* r, const LevelGeom& g, int y, int x) {
   if (y >= 0 && y < g.H && x >= 0 && x + 8 <= g.W) return ld8u(r + (size_t)y * g.W + x);
-  const BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+  const BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);
   uint64_t v = 0;
   for (int k = 0; k < 8; k++) v |= (uint64_t)luma_b(r, bg, y, x + k) << (8 * k);
   return v;
@@ -422,6 +422,134 @@ __global__ void __launch_bounds__(256) k_mv_hist(const int16_t* mv, size_t per_p
   __syncthreads();
   if (h[threadIdx.x]) atomicAdd(&hist[((size_t)i * 3 + 2) * 256 + threadIdx.x], h[threadIdx.x]);
 }
+// ---------------------------------------------------------------------------------------------
+// --block_overlaping >= 2 (predict(), decorrelate.cpp:84-172): every block's bidirectional prediction is taken with a margin of
+// `ov` samples, analysed `levels` = log2(ov) levels in place (truncating 5/3), its subbands -- without the margin -- are copied
+// into the picture's Mallat layout, and the picture is synthesised back (the blocks blend through the synthesis filters).
+// One workgroup per (block, component, B picture): the (bs + 2 ov)^2 block lives in LDS.  Chroma from the up-sampled planes.
+#define OVL_MAXN 96
+__global__ void __launch_bounds__(256) k_ovl_block(PredArgs a, int levels, int16_t* ppl) {
+  __shared__ int16_t sA[OVL_MAXN * OVL_MAXN];
+  __shared__ int16_t sB[OVL_MAXN * OVL_MAXN];
+  const LevelGeom& g = a.g;
+  const int tid = threadIdx.x, bx = blockIdx.x, by = blockIdx.y, i = blockIdx.z / 3, c = blockIdx.z % 3;
+  const int ov = g.ov, bs = g.bs, n = bs + 2 * ov;
+  const size_t plane = (size_t)g.H * g.W, fld = (size_t)g.BY * g.BX;
+  const uint8_t* r0 = c == 0 ? frame_y(a.frames, g, 2 * i) : a.cup + ((size_t)i * 2 + (c - 1)) * plane;
+  const uint8_t* r1 = c == 0 ? frame_y(a.frames, g, 2 * i + 2) : a.cup + ((size_t)(i + 1) * 2 + (c - 1)) * plane;
+  const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)by * g.BX + bx;
+  const int y0 = by * bs + m[fld], x0 = bx * bs + m[0], y1 = by * bs + m[3 * fld], x1 = bx * bs + m[2 * fld];
+  const BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);
+  for (int k = tid; k < n * n; k += 256) {
+    const int y = k / n - ov, x = k % n - ov;
+    sA[k] = (int16_t)((luma_b(r0, bg, y0 + y, x0 + x) + luma_b(r1, bg, y1 + y, x1 + x)) / 2);  // decorrelate.cpp:99-107
+  }
+  __syncthreads();
+  for (int l = 0; l < levels; l++) {  // dwt2d::analyze on the block (dwt2d.cpp:76-119): region (n >> l)^2
+    const int mreg = n >> l;
+    auto P = [&](int yy, int xx) { return (int)sA[yy * n + xx]; };
+    for (int k = tid; k < mreg * mreg; k += 256) sB[(k / mreg) * n + k % mreg] = (int16_t)analyze2d_coef(P, k / mreg, k % mreg, mreg, mreg);
+    __syncthreads();
+    for (int k = tid; k < mreg * mreg; k += 256) sA[(k / mreg) * n + k % mreg] = sB[(k / mreg) * n + k % mreg];
+    __syncthreads();
+  }
+  int16_t* out = ppl + ((size_t)i * 3 + c) * plane;
+  for (int l = 1; l <= levels; l++) {  // decorrelate.cpp:116-146
+    const int bsl = bs >> l, o1 = ov >> l, o3 = (bs + 3 * ov) >> l;
+    for (int k = tid; k < bsl * bsl; k += 256) {
+      const int y = k / bsl, x = k % bsl;
+      out[(size_t)(by * bsl + y) * g.W + (g.W >> l) + bx * bsl + x] = sA[(o1 + y) * n + o3 + x];
+      out[(size_t)((g.H >> l) + by * bsl + y) * g.W + bx * bsl + x] = sA[(o3 + y) * n + o1 + x];
+      out[(size_t)((g.H >> l) + by * bsl + y) * g.W + (g.W >> l) + bx * bsl + x] = sA[(o3 + y) * n + o3 + x];
+    }
+  }
+  {
+    const int bsl = bs >> levels, o1 = ov >> levels;
+    for (int k = tid; k < bsl * bsl; k += 256) out[(size_t)(by * bsl + k / bsl) * g.W + bx * bsl + k % bsl] = sA[(o1 + k / bsl) * n + o1 + k % bsl];
+  }
+}
+// one synthesis level of the truncating 5/3 over the top-left ny x nx of every plane: src -> dst
+__global__ void __launch_bounds__(256) k_dwt53t_synth_planes(const int16_t* src, int16_t* dst, size_t plane, int stride, int ny, int nx) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= nx || y >= ny) return;
+  const int16_t* s = src + (size_t)blockIdx.z * plane;
+  auto P = [&](int yy, int xx) { return (int)s[(size_t)yy * stride + xx]; };
+  dst[(size_t)blockIdx.z * plane + (size_t)y * stride + x] = (int16_t)synthesize2d_sample(P, y, x, ny, nx);
+}
+__global__ void __launch_bounds__(256) k_copy_region_planes(const int16_t* src, int16_t* dst, size_t plane, int stride, int ny, int nx) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x < nx && y < ny) dst[(size_t)blockIdx.z * plane + (size_t)y * stride + x] = src[(size_t)blockIdx.z * plane + (size_t)y * stride + x];
+}
+// residue / correlate from the synthesised prediction planes: luma (thread per sample) ...
+__global__ void __launch_bounds__(256) k_ovl_finish_luma(PredArgs a, const int16_t* ppl) {
+  __shared__ unsigned h[2][256];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  h[0][tid] = 0; h[1][tid] = 0;
+  __syncthreads();
+  const LevelGeom& g = a.g;
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+  if (x < g.W && y < g.H) {
+    const int p = iclamp(ppl[((size_t)i * 3) * g.H * g.W + (size_t)y * g.W + x], 0, 255);  // decorrelate.cpp:841-848
+    const size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
+    if (a.odd_out) a.odd_out[(size_t)(2 * i + 1) * g.F + (size_t)y * g.W + x] = (uint8_t)correlate_sample(a.high[off], p, a.types[i]);
+    else {
+      const int o = frame_y(a.frames, g, 2 * i + 1)[(size_t)y * g.W + x];
+      const int val = iclamp(o - p, -128, 127);
+      a.high[off] = (uint8_t)(val + 128);
+      atomicAdd(&h[0][o], 1u); atomicAdd(&h[1][val + 128], 1u);
+    }
+    if (a.pred_dump) a.pred_dump[off] = (uint8_t)p;
+  }
+  if (a.odd_out) return;
+  __syncthreads();
+  unsigned* gh = a.hist + (size_t)i * 3 * 256;
+  if (h[0][tid]) atomicAdd(&gh[tid], h[0][tid]);
+  if (h[1][tid]) atomicAdd(&gh[256 + tid], h[1][tid]);
+}
+// ... and chroma: clip, chroma/2 (LL of a 1-level analysis, decorrelate.cpp:860-861), residue
+__global__ void __launch_bounds__(256) k_ovl_finish_chroma(PredArgs a, const int16_t* ppl) {
+  const LevelGeom& g = a.g;
+  const int cw = g.W / 2, chh = g.H / 2;
+  const int ci = blockIdx.x * 64 + threadIdx.x, cj = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
+  if (ci >= cw || cj >= chh) return;
+  const int16_t* pp = ppl + ((size_t)i * 3 + c) * g.H * g.W;
+  auto P = [&](int yy, int xx) { return iclamp(pp[(size_t)yy * g.W + xx], 0, 255); };
+  const int ll = analyze_ll(P, cj, ci, g.H, g.W);
+  const size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh + (size_t)cj * cw + ci, off = (size_t)i * g.F + coff;
+  if (a.odd_out) a.odd_out[(size_t)(2 * i + 1) * g.F + coff] = (uint8_t)correlate_sample(a.high[off], ll, a.types[i]);
+  else {
+    const int o = frame_c(a.frames, g, 2 * i + 1, c)[(size_t)cj * cw + ci];
+    a.high[off] = (uint8_t)(iclamp(o - ll, -128, 127) + 128);
+  }
+  if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;
+}
+// ppl0 / ppl1: two [nB][3][H][W] int16 buffers.  Returns false when the geometry is outside this path.
+bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, int16_t* ppl1) {
+  const LevelGeom& g = a.g;
+  int levels = 0;
+  while ((1 << (levels + 1)) <= g.ov) levels++;
+  if ((1 << levels) != g.ov || levels < 1 || g.bs + 2 * g.ov > OVL_MAXN || (g.bs & (g.ov - 1)) || !a.cup || a.margin) return false;
+  if (!a.odd_out) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
+  const size_t plane = (size_t)g.H * g.W;
+  hipLaunchKernelGGL(k_ovl_block, dim3(g.BX, g.BY, g.nB * 3), dim3(256), 0, st, a, levels, ppl0);
+  for (int lv = levels - 1; lv >= 0; lv--) {  // dwt2d::synthesize (dwt2d.cpp:128-175)
+    const int ny = g.H >> lv, nx = g.W >> lv;
+    dim3 grid((nx + 63) / 64, (ny + 3) / 4, g.nB * 3), block(64, 4);
+    hipLaunchKernelGGL(k_dwt53t_synth_planes, grid, block, 0, st, ppl0, ppl1, plane, g.W, ny, nx);
+    hipLaunchKernelGGL(k_copy_region_planes, grid, block, 0, st, ppl1, ppl0, plane, g.W, ny, nx);
+  }
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_ovl_finish_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a, ppl0);
+  hipLaunchKernelGGL(k_ovl_finish_chroma, dim3((g.W / 2 + 63) / 64, (g.H / 2 + 3) / 4, g.nB * 2), block, 0, st, a, ppl0);
+  if (!a.odd_out) {
+    size_t per_pic = (size_t)4 * g.BY * g.BX;
+    int nblk = (int)((per_pic + 255) / 256);
+    if (nblk > 64) nblk = 64;
+    hipLaunchKernelGGL(k_mv_hist, dim3(nblk, g.nB), dim3(256), 0, st, a.mv, per_pic, a.hist);
+  }
+  return true;
+}
+
 void launch_predict(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
   if (!a.odd_out) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);

@@ -20,6 +20,8 @@ struct LevelGeom {
   int P;         // pictures in low_{t-1}
   int nB;        // P/2 B pictures
   size_t F;      // bytes per I420 frame
+  int ov;        // --block_overlaping (decorrelate.cpp:539: the reference planes' border is 4*S + ov)
+  int bord;      // --border_size of the motion search (motion_estimate.cpp:213-217,714)
 };
 
 QHD const uint8_t* frame_y(const uint8_t* frames, const LevelGeom& g, int pic) { return frames + (size_t)pic * g.F; }
@@ -58,7 +60,7 @@ struct MeArgs {
 };
 template <class T>
 QHD void me_block_setup(const MeArgs& a, int i, MePlane<T>& r0, MePlane<T>& r1, MePlane<T>& pr) {
-  BorderGeom bg = make_border(a.g.H, a.g.W, a.g.S);
+  BorderGeom bg = make_border(a.g.H, a.g.W, a.g.S + a.g.bord);  // motion_estimate.cpp:714
   const uint8_t* y0 = frame_y(a.frames, a.g, 2 * i);
   const uint8_t* y1 = frame_y(a.frames, a.g, 2 * i + 2);
   const uint8_t* yp = frame_y(a.frames, a.g, 2 * i + 1);
@@ -111,7 +113,7 @@ QHD MarginGeom margin_geom(const LevelGeom& g) { return {g.H, g.W, g.BY * g.bs, 
 // luma: returns the two histogram bins through odd_bin / res_bin
 QHD void pred_luma_thread(const PredArgs& a, int x, int y, int i, int& odd_bin, int& res_bin) {
   const LevelGeom& g = a.g;
-  BorderGeom bg = make_border(g.H, g.W, 4 * g.S);  // decorrelate.cpp:539
+  BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);  // decorrelate.cpp:539
   MvField mv = {a.mv + (size_t)i * 4 * g.BY * g.BX, g.BY, g.BX};
   int p = 0;  // Q7: the unpredicted margin of the luma plane stays zero
   if (y < g.BY * g.bs && x < g.BX * g.bs)
@@ -141,7 +143,7 @@ QHD int pred_chroma_sample(const PredArgs& a, const uint8_t* u0, const uint8_t* 
 // Q7: margin position k of picture i's analysed plane = the state picture i+1 starts from.  Pictures in order.
 QHD void pred_margin_thread(const PredArgs& a, size_t k, int i, int c /*1|2*/) {
   const LevelGeom& g = a.g;
-  BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+  BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);
   MvField mv = {a.mv + (size_t)i * 4 * g.BY * g.BX, g.BY, g.BX};
   const uint8_t* u0 = frame_c(a.frames, g, 2 * i, c);
   const uint8_t* u1 = frame_c(a.frames, g, 2 * i + 2, c);
@@ -153,7 +155,7 @@ QHD void pred_margin_thread(const PredArgs& a, size_t k, int i, int c /*1|2*/) {
 }
 QHD void pred_chroma_thread(const PredArgs& a, int ci, int cj, int i, int c /*1|2*/) {
   const LevelGeom& g = a.g;
-  BorderGeom bg = make_border(g.H, g.W, 4 * g.S);
+  BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);
   MvField mv = {a.mv + (size_t)i * 4 * g.BY * g.BX, g.BY, g.BX};
   const uint8_t* u0 = frame_c(a.frames, g, 2 * i, c);
   const uint8_t* u1 = frame_c(a.frames, g, 2 * i + 2, c);

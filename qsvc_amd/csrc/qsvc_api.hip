@@ -104,7 +104,7 @@ void qsvc_destroy(qsvc_ctx* c) {
   for (auto& b : c->snap) b.release();
   c->mvtmp[0].release(); c->mvtmp[1].release();
   for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); }
-  c->margin.release(); c->cup.release();
+  c->margin.release(); c->cup.release(); c->ovl[0].release(); c->ovl[1].release();
   if (c->comm) qsvc_comm_destroy(c);
   c->scal.release(); c->tmp16[0].release(); c->tmp16[1].release();
   j2k_release(c);
@@ -238,6 +238,19 @@ static int level_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g) {
   // Q7, reproduced by the margin state of PredArgs (mctf_threads.h)
   if (c->H < bs || c->W < bs) return c->fail(QSVC_ERR_INVALID, "picture %dx%d smaller than block_size %d", c->W, c->H, bs);
   g->W = c->W; g->H = c->H; g->bs = bs; g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
+  g->ov = c->opt_ov; g->bord = c->opt_bord;
+  return QSVC_OK;
+}
+
+int qsvc_set_mctf_options(qsvc_ctx* c, int block_overlaping, int border_size, int subpixel_accuracy) {
+  if (!c) return QSVC_ERR_INVALID;
+  if (block_overlaping < 0 || border_size < 0 || subpixel_accuracy < 0) return c->fail(QSVC_ERR_INVALID, "negative MCTF option");
+  if (subpixel_accuracy != 0)
+    return c->fail(QSVC_ERR_UNSUPPORTED, "subpixel_accuracy %d: sub-pixel motion (motion_estimate.cpp:361-412, decorrelate.cpp:656-686) is not implemented on this path", subpixel_accuracy);
+  if (block_overlaping > 1 && (block_overlaping & (block_overlaping - 1)))
+    return c->fail(QSVC_ERR_UNSUPPORTED, "block_overlaping %d is not a power of two", block_overlaping);
+  if (border_size > 64) return c->fail(QSVC_ERR_UNSUPPORTED, "border_size %d", border_size);
+  c->opt_ov = block_overlaping; c->opt_bord = border_size;
   return QSVC_OK;
 }
 
@@ -253,7 +266,7 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   // the level-l search state equals the l-level analysis only while every intermediate size is even (Q5)
   if ((g.H % (1 << L)) || (g.W % (1 << L)))
     return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d not divisible by 2^%d (search_range %d)", g.W, g.H, L, S);
-  if (desp(g.BY, L) * bs + S > 32767) return c->fail(QSVC_ERR_UNSUPPORTED, "picture too large");
+  if (desp(g.BY, L) * bs + S + g.bord > 32767) return c->fail(QSVC_ERR_UNSUPPORTED, "picture too large");
   Level& lv = c->lv[t];
   size_t fld = (size_t)g.BY * g.BX, mvbytes = (size_t)g.nB * 4 * fld * sizeof(int16_t);
   if ((r = lv.mv_raw.ensure(c, mvbytes ? mvbytes : 16))) return r;
@@ -266,7 +279,7 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   pf.begin(c, "me_pyramid");
   for (int l = 1; l <= L; l++) {
     if ((r = c->snap[l].ensure(c, (size_t)P * N * sizeof(int16_t)))) return r;
-    int R = imin(g.H, imax(desp(g.BY, l) * bs + S, g.H >> l)), C = imin(g.W, imax(desp(g.BX, l) * bs + S, g.W >> l));
+    int R = imin(g.H, imax(desp(g.BY, l) * bs + S + g.bord, g.H >> l)), C = imin(g.W, imax(desp(g.BX, l) * bs + S + g.bord, g.W >> l));
     if (l == 1) launch_pyr_level_u8(c->st, frames, g.F, g.W, g.H, (int16_t*)c->snap[1].p, P, R, C);
     else launch_pyr_level_s16(c->st, (const int16_t*)c->snap[l - 1].p, (int16_t*)c->snap[l].p, g.W, g.H, P, l, R, C);
   }
@@ -296,6 +309,17 @@ static int make_cup(qsvc_ctx* c, const LevelGeom& g, const uint8_t* frames, int 
   if (r) return r;
   launch_chroma_up(c->st, frames, g, mul, g.nB + 1, (uint8_t*)c->cup.p);
   *out = (const uint8_t*)c->cup.p;
+  return QSVC_OK;
+}
+
+static int predict_overlapped(qsvc_ctx* c, const LevelGeom& g, const PredArgs& a) {
+  const size_t bytes = (size_t)g.nB * 3 * g.H * g.W * sizeof(int16_t);
+  int r;
+  if ((r = c->ovl[0].ensure(c, bytes))) return r;
+  if ((r = c->ovl[1].ensure(c, bytes))) return r;
+  if (!launch_predict_overlap(c->st, a, (int16_t*)c->ovl[0].p, (int16_t*)c->ovl[1].p))
+    return c->fail(QSVC_ERR_UNSUPPORTED, "block_overlaping %d with block size %d on a %dx%d picture is outside this path (power of two dividing "
+                   "the block size, block + 2 x overlap <= %d, picture tiled by the block grid)", g.ov, g.bs, g.W, g.H, 96);
   return QSVC_OK;
 }
 
@@ -341,7 +365,9 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   Prof pf;
   pf.begin(c, "predict");
   if (!lv.ragged && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
-  launch_predict(c->st, a);
+  if (g.ov >= 2) {
+    if ((r = predict_overlapped(c, g, a))) return r;
+  } else launch_predict(c->st, a);
   pf.end(c);
   HIPCHK(c, hipMemcpyAsync(lv.mv_filt.p, lv.mv_raw.p, mvbytes, hipMemcpyDeviceToDevice, c->st));
   if (!always_B) {
@@ -431,6 +457,7 @@ static int synth_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g, bo
   if (P < 1) return c->fail(QSVC_ERR_INVALID, "pictures %d", P);
   if (c->H < bs || c->W < bs) return c->fail(QSVC_ERR_INVALID, "picture %dx%d smaller than block_size %d", c->W, c->H, bs);
   g->W = c->W; g->H = c->H; g->bs = bs; g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
+  g->ov = c->opt_ov; g->bord = 0;
   Level& lv = c->lv[t];
   if (need_low && lv.low_n < g->nB + 1) return c->fail(QSVC_ERR_STATE, "low_%d holds %d pictures, %d needed", t, lv.low_n, g->nB + 1);
   if (lv.high_n < g->nB || lv.mv_filt_n < g->nB || (int)lv.types.size() < g->nB || (g->nB && lv.mv_bs != bs))
@@ -503,7 +530,9 @@ int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   Prof pf;
   pf.begin(c, "correlate");
   if (!a.margin && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
-  launch_predict(c->st, a);
+  if (g.ov >= 2) {
+    if ((r = predict_overlapped(c, g, a))) return r;
+  } else launch_predict(c->st, a);
   pf.end(c);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->st));

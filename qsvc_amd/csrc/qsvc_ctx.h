@@ -58,9 +58,11 @@ struct qsvc_ctx {
   int W = 0, H = 0;
   size_t F = 0;
   int keep_pred = 0;
+  int opt_ov = 0, opt_bord = 0;  // --block_overlaping, --border_size (qsvc_set_mctf_options)
   std::vector<Level> lv;
   std::vector<DevBuf> snap;  // ME pyramid snapshots per DWT level
   DevBuf margin;             // Q7 chroma margin state of the level being decorrelated
+  DevBuf ovl[2];             // --block_overlaping: prediction planes in the Mallat layout, [nB][3][H][W] int16 each
   DevBuf cup;                // chroma x2 interpolation of the even pictures of the level in work: [nB+1][2][H][W] u8
   DevBuf mvtmp[2], scal, tmp16[2];
   DevBuf halo_tx[2], halo_rx[2];  // boundary records: [0] left neighbour, [1] right neighbour

@@ -18,7 +18,7 @@ MOTION_RAW, MOTION_FILTERED = 0, 1
 # every symbol include/qsvc_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "qsvc_init", "qsvc_destroy", "qsvc_last_error", "qsvc_stream", "qsvc_sync", "qsvc_seq_config",
-    "qsvc_put_frames", "qsvc_get_frames", "qsvc_put_motion", "qsvc_get_motion", "qsvc_put_frame_types",
+    "qsvc_set_mctf_options", "qsvc_put_frames", "qsvc_get_frames", "qsvc_put_motion", "qsvc_get_motion", "qsvc_put_frame_types",
     "qsvc_get_frame_types", "qsvc_get_histograms", "qsvc_motion_estimate", "qsvc_decorrelate", "qsvc_update",
     "qsvc_analyze_step", "qsvc_un_update", "qsvc_correlate", "qsvc_synthesize_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_dwt53_trunc",
@@ -55,6 +55,7 @@ def load_library() -> C.CDLL:
     L.qsvc_stream.argtypes = [vp]; L.qsvc_stream.restype = vp
     L.qsvc_sync.argtypes = [vp]
     L.qsvc_seq_config.argtypes = [vp, i, i, i]
+    L.qsvc_set_mctf_options.argtypes = [vp, i, i, i]
     L.qsvc_put_frames.argtypes = [vp, i, i, i, i, i, u8p]
     L.qsvc_get_frames.argtypes = [vp, i, i, i, i, u8p]
     L.qsvc_put_motion.argtypes = [vp, i, i, i, i, i16p]
@@ -136,6 +137,9 @@ class Engine:
     def seq_config(self, W, H, keep_prediction=False):
         self._chk(self.L.qsvc_seq_config(self.h, W, H, int(keep_prediction)))
         self.W, self.H, self.F = W, H, frame_bytes(W, H)
+
+    def set_mctf_options(self, block_overlaping=0, border_size=0, subpixel_accuracy=0):
+        self._chk(self.L.qsvc_set_mctf_options(self.h, block_overlaping, border_size, subpixel_accuracy))
 
     def put_frames(self, kind, t, frames: np.ndarray, first=0, total=None):
         a = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, self.F)

@@ -18,6 +18,8 @@ class CompressParams:  # defaults of compress.py:57-106
     pixels_in_x: int = 352
     pixels_in_y: int = 288
     always_B: int = 0
+    block_overlaping: int = 0      # decorrelate.cpp:84-172 (0, 1 or a power of two)
+    border_size: int = 0           # motion_estimate.cpp:213-217
     block_size: int | None = None
     block_size_min: int | None = None
     GOPs: int = 1
@@ -53,6 +55,7 @@ class Compressor:
 
     def configure(self, keep_prediction=False):
         self.e.seq_config(self.p.pixels_in_x, self.p.pixels_in_y, keep_prediction)
+        self.e.set_mctf_options(self.p.block_overlaping, self.p.border_size, 0)
 
     def load(self, low0):
         self.e.put_frames(LOW, 0, low0)

@@ -17,6 +17,9 @@ class FakeEngine:
     def seq_config(self, W, H, keep_prediction=False):
         self.W, self.H, self.F = W, H, O.frame_bytes(W, H)
 
+    def set_mctf_options(self, block_overlaping=0, border_size=0, subpixel_accuracy=0):
+        assert (block_overlaping, border_size, subpixel_accuracy) == (0, 0, 0)
+
     def put_frames(self, kind, t, frames, first=0, total=None):
         self.seq[(kind, t)] = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, self.F).copy()
 

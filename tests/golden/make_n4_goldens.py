@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Goldens for the reference's optional MCTF flags, from the REFERENCE's own tools (build container
+only): --block_overlaping (decorrelate / correlate, decorrelate.cpp:84-172) and --border_size (motion_estimate,
+motion_estimate.cpp:213-217,714).  Same recipe as make_goldens.py: oracle/_ref binaries on seeded synthetic clips, default glibc
+malloc (with --border_size the reference reads the never-filled border of its predicted plane: zeros of a fresh heap), data only.
+
+    python tests/golden/make_n4_goldens.py        # rewrites tests/golden/n4_*.npz
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from qsvc_amd.synth import make_clip  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name, kind, seed, W, H, TRLs, block_size, search_range, block_overlaping, border_size, full_dump
+CASES = [
+    ("ov2_tiny", "pan_noise", 3, 128, 96, 3, 16, 4, 2, 0, True),
+    ("ov4_tiny_edge", "edge", 47, 96, 64, 3, 16, 4, 4, 0, True),
+    ("ov1_sat", "saturating", 45, 64, 48, 3, 8, 4, 1, 0, True),
+    ("bord2_tiny", "edge", 47, 96, 64, 3, 16, 8, 0, 2, True),
+    ("ov2_bord2_cif", "pan_noise", 43, 352, 288, 3, 32, 4, 2, 2, False),
+    ("ov2_bord2_q1_360x200", "edge", 49, 360, 200, 4, 8, 4, 2, 2, False),
+    ("ov4_bord1_360x200", "edge", 49, 360, 200, 3, 8, 4, 4, 1, False),
+    ("ov8_binary", "binary", 48, 64, 64, 2, 16, 4, 8, 0, False),
+    ("bord8_cif", "pan_noise", 43, 352, 288, 2, 32, 4, 0, 8, False),
+]
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    assert O.have_ref(), "oracle/_ref missing: run `make -C oracle` in the build container"
+    for name, kind, seed, W, H, TRLs, bs, S, ov, bord, full in CASES:
+        frames = 2 ** (TRLs - 1) + 1
+        clip = make_clip(kind, frames, W, H, seed)
+        levels = O.ref_analyze(clip, W, H, TRLs, bs, S, block_overlaping=ov, border_size=bord)
+        out = dict(meta=np.array([frames, W, H, TRLs, bs, S, seed, ov, bord], dtype=np.int64), kind=np.array(kind), input_sha=np.array(sha(clip)))
+        if full:
+            out["input"] = clip
+        for t, lv in enumerate(levels, 1):
+            out[f"motion_{t}"] = lv["motion"]
+            out[f"motion_filtered_{t}"] = lv["motion_filtered"]
+            out[f"frame_types_{t}"] = np.frombuffer(lv["frame_types"], dtype=np.uint8)
+            for k in ("high", "low", "prediction"):
+                out[f"{k}_{t}_sha"] = np.array(sha(lv[k]))
+                if full:
+                    out[f"{k}_{t}"] = lv[k]
+        low = levels[-1]["low"]
+        for t in range(len(levels), 0, -1):  # the inverse chain with the reference's correlate --block_overlaping
+            lv = levels[t - 1]
+            r = O.ref_synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], W, H, bs, min(S * 2 ** (t - 1), 128), t=t,
+                                      block_overlaping=ov)
+            low = r["low"]
+            out[f"synth_low_{t - 1}_sha"] = np.array(sha(low))
+        np.savez_compressed(os.path.join(HERE, f"n4_{name}.npz"), **out)
+        print(name, [lv["frame_types"] for lv in levels])
+
+
+if __name__ == "__main__":
+    main()

@@ -43,3 +43,14 @@ def check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "f
                 assert sha(lv[k]) == str(z[f"{k}_{t}_sha"]), f"{k}_{t} digest"
                 if f"{k}_{t}" in z.files:
                     np.testing.assert_array_equal(lv[k], z[f"{k}_{t}"], err_msg=f"{k}_{t}")
+
+
+def n4_cases():
+    return sorted(os.path.basename(p)[3:-4] for p in glob.glob(os.path.join(GOLDEN, "n4_*.npz")))
+
+
+def load_n4(name):
+    """Goldens of the optional MCTF flags (tests/golden/make_n4_goldens.py): meta also holds block_overlaping and border_size."""
+    z = np.load(os.path.join(GOLDEN, f"n4_{name}.npz"), allow_pickle=False)
+    frames, W, H, TRLs, bs, S, seed, ov, bord = (int(v) for v in z["meta"])
+    return z, dict(frames=frames, W=W, H=H, TRLs=TRLs, bs=bs, S=S, seed=seed, ov=ov, bord=bord, kind=str(z["kind"]))

@@ -140,8 +140,45 @@ def test_synthesize_chain_tools(oracle, tmp_path):
 
 def test_unsupported_requests_exit_nonzero(tmp_path):
     make_clip("pan", 5, 64, 64, 1).tofile(tmp_path / "low_0")
-    r = subprocess.run([MCTF, "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=3", "--block_overlaping=2"],
+    r = subprocess.run([MCTF, "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=3", "--subpixel_accuracy=2"],
                        cwd=tmp_path, capture_output=True)
     assert r.returncode != 0
+    r = subprocess.run([MCTF, "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=3", "--block_overlaping=3"],
+                       cwd=tmp_path, capture_output=True)  # not a power of two: the library refuses
+    assert r.returncode == 255
     r = subprocess.run([MCTF, "transcode"], cwd=tmp_path, capture_output=True)
     assert r.returncode != 0
+
+
+def test_compress_and_synthesize_with_overlap_and_border(oracle, tmp_path):
+    """`mctf compress --block_overlaping=2 --border_size=2` against the restatement with the same options (itself
+    pinned by the compiled reference tools, tests/golden/n4_*.npz), then `mctf synthesize` back from the written subbands."""
+    W, H, TRLs, GOPs, bs = 128, 96, 3, 1, 16
+    P = GOPs * 2 ** (TRLs - 1) + 1
+    clip = make_clip("pan_noise", P, W, H, 6)
+    clip.tofile(tmp_path / "low_0")
+    opts = ("--block_overlaping=2", "--border_size=2")
+    run(tmp_path, "compress", f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", f"--GOPs={GOPs}", f"--block_size={bs}",
+        f"--block_size_min={bs}", "--SRLs=4", "--lossless=1", *opts)
+    want = oracle.analyze(clip, W, H, TRLs, bs, 4, block_overlaping=2, border_size=2)
+    plain = oracle.analyze(clip, W, H, TRLs, bs, 4)
+    assert not np.array_equal(want[0]["high"], plain[0]["high"])
+    for t, lv in enumerate(want, 1):
+        assert rd(tmp_path, f"frame_types_{t}").tobytes() == lv["frame_types"]
+        np.testing.assert_array_equal(rd(tmp_path, f"motion_{t}", np.int16), lv["motion"].reshape(-1))
+        np.testing.assert_array_equal(rd(tmp_path, f"high_{t}"), lv["high"].reshape(-1))
+        np.testing.assert_array_equal(rd(tmp_path, f"low_{t}"), lv["low"].reshape(-1))
+    # the decoder side reads motion_t: the filtered fields are what the code-stream carries
+    for t in (1, 2):
+        os.replace(tmp_path / f"motion_filtered_{t}", tmp_path / f"motion_{t}")
+    os.remove(tmp_path / "low_0")
+    run(tmp_path, "synthesize", f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", f"--GOPs={GOPs}", f"--block_size={bs}",
+        "--block_overlaping=2")
+    low = want[-1]["low"]
+    for t in (2, 1):
+        lv = want[t - 1]
+        low = oracle.synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], W, H, bs, 4 * 2 ** (t - 1), block_overlaping=2)["low"]
+    np.testing.assert_array_equal(rd(tmp_path, "low_0"), low.reshape(-1))
+    # the one deferred option left is refused with the drivers' exit status
+    r = subprocess.run([MCTF, "analyze", f"--pixels_in_x={W}", f"--pixels_in_y={H}", "--subpixel_accuracy=1"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 255 and "subpixel_accuracy" in r.stderr

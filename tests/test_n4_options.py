@@ -1,0 +1,70 @@
+"""SURVEY.md 8f N4 -- the reference's optional MCTF flags, pinned by goldens the compiled reference tools produced
+(tests/golden/n4_*.npz): --block_overlaping (decorrelate.cpp:84-172) and --border_size (motion_estimate.cpp:213-217,714).
+CPU: the restatement; GPU: the HIP path through the C ABI (forward levels and the inverse chain)."""
+import numpy as np
+import pytest
+
+from helpers import check_levels_against_golden, golden_input, load_n4, n4_cases, sha
+
+
+@pytest.mark.parametrize("name", n4_cases())
+def test_restatement_matches_reference_goldens(oracle, name):
+    z, m = load_n4(name)
+    clip = golden_input(z, m)
+    levels = oracle.analyze(clip, m["W"], m["H"], m["TRLs"], m["bs"], m["S"], block_overlaping=m["ov"], border_size=m["bord"])
+    for t, lv in enumerate(levels, 1):
+        d = oracle.decorrelate(clip if t == 1 else levels[t - 2]["low"], m["W"], m["H"], m["bs"], min(m["S"] * 2 ** (t - 1), 128), lv["motion"],
+                               want_prediction=True, block_overlaping=m["ov"])
+        lv["prediction"] = d["prediction"]
+    check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "frame_types", "high", "low", "prediction"))
+    low = levels[-1]["low"]
+    for t in range(len(levels), 0, -1):
+        lv = levels[t - 1]
+        low = oracle.synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], m["W"], m["H"], m["bs"],
+                                     min(m["S"] * 2 ** (t - 1), 128), block_overlaping=m["ov"])["low"]
+        assert sha(low) == str(z[f"synth_low_{t - 1}_sha"]), f"synth_low_{t - 1}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", n4_cases())
+def test_hip_matches_reference_goldens(name):
+    from qsvc_amd import hip
+    z, m = load_n4(name)
+    clip = golden_input(z, m)
+    W, H, bs = m["W"], m["H"], m["bs"]
+    e = hip.Engine(0)
+    try:
+        e.seq_config(W, H, keep_prediction=True)
+        e.set_mctf_options(block_overlaping=m["ov"], border_size=m["bord"])
+        e.put_frames(hip.LOW, 0, clip)
+        P, S, levels = m["frames"], m["S"], []
+        for t in range(1, m["TRLs"]):
+            e.analyze_step(t, P, bs, S)
+            nB = P // 2
+            levels.append(dict(motion=e.get_motion(hip.MOTION_RAW, t, nB, bs), motion_filtered=e.get_motion(hip.MOTION_FILTERED, t, nB, bs),
+                               frame_types=e.get_frame_types(t, nB), high=e.get_frames(hip.HIGH, t, 0, nB), low=e.get_frames(hip.LOW, t, 0, nB + 1),
+                               prediction=e.get_frames(hip.PRED, t, 0, nB), P=P, S=S))
+            P, S = (P + 1) // 2, min(2 * S, 128)
+        check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "frame_types", "high", "low", "prediction"))
+        # inverse chain on the device (un_update + correlate with the same --block_overlaping)
+        for t in range(len(levels), 0, -1):
+            lv = levels[t - 1]
+            e.synthesize_step(t, 2 * (lv["P"] // 2) + 1, bs, lv["S"])
+            assert sha(e.get_frames(hip.LOW, t - 1, 0, 2 * (lv["P"] // 2) + 1)) == str(z[f"synth_low_{t - 1}_sha"]), f"synth_low_{t - 1}"
+    finally:
+        e.close()
+
+
+@pytest.mark.gpu
+def test_unsupported_options_are_refused():
+    from qsvc_amd import hip
+    e = hip.Engine(0)
+    try:
+        e.seq_config(128, 96)
+        with pytest.raises(hip.QsvcError) as ei:
+            e.set_mctf_options(subpixel_accuracy=1)
+        assert ei.value.code == -2
+        with pytest.raises(hip.QsvcError):
+            e.set_mctf_options(block_overlaping=3)
+    finally:
+        e.close()
