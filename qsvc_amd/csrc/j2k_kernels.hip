@@ -277,16 +277,32 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   const bool first = p == nb - 1;
   const int pass0 = first ? 2 : 0;
   // count the three passes' decisions of this lane's 16 stripe columns (one neighbourhood assembly per column)
+  // a lane walks 16 consecutive columns of ONE stripe (s = lane / 4, x from 16 (lane % 4)): the 3 x 3 neighbourhood slides, only
+  // the new right-hand column's three words are read and taken apart per step (cm2_gather_slide)
+  const int ls = lane >> 2, lx0 = (lane & 3) * 16;
+  const bool lane_live = ls < nstr && lx0 < w;
+  auto slide_begin = [&](Cm2Col& c, uint32_t& own) {
+    const uint32_t u2[2] = {s_cw[ls][lx0], s_cw[ls][lx0 + 1]}, m2[2] = {s_cw[ls + 1][lx0], s_cw[ls + 1][lx0 + 1]},
+                   d2[2] = {s_cw[ls + 2][lx0], s_cw[ls + 2][lx0 + 1]};
+    cm2_gather_first(c, u2, m2, d2);
+    own = m2[1];
+  };
   int n3[3] = {0, 0, 0};
-  for (int i = lane * 16; i < lane * 16 + 16; i++) {
-    const int s = i >> 6, x = i & 63;
-    if (s >= nstr || x >= w) continue;
-    Cm2Col c;
-    cm2_gather(c, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x]);
-    int n[3];
-    cm2_counts(c, n);
-    if (!first) { n3[0] += n[0]; n3[1] += n[1]; }
-    n3[2] += n[2];
+  if (lane_live) {
+    Cm2Col c; uint32_t own;
+    slide_begin(c, own);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t nm = s_cw[ls + 1][lx0 + j + 2];
+      cm2_gather_slide(c, own, s_cw[ls][lx0 + j + 2], nm, s_cw[ls + 2][lx0 + j + 2]);
+      own = nm;
+      if (lx0 + j < w) {
+        int n[3];
+        cm2_counts(c, n);
+        if (!first) { n3[0] += n[0]; n3[1] += n[1]; }
+        n3[2] += n[2];
+      }
+    }
   }
   int off3[3], tot3[3];
   for (int pass = 0; pass < 3; pass++) {
@@ -304,14 +320,20 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
     B0.out = s_out + off3[0]; B0.n = 0;
     B1.out = s_out + base1 + off3[1]; B1.n = 0;
     B2.out = s_out + base2 + off3[2]; B2.n = 0;
-    for (int i = lane * 16; i < lane * 16 + 16; i++) {
-      const int s = i >> 6, x = i & 63;
-      if (s >= nstr || x >= w) continue;
-      Cm2Col c;
-      cm2_gather(c, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x]);
-      const uint64_t mag = want_dist ? mg[i] : 0ull;
-      if (!first) { cm2_pass(B0, cx, 0, c, mag, d3[0]); cm2_pass(B1, cx, 1, c, mag, d3[1]); }
-      cm2_pass(B2, cx, 2, c, mag, d3[2]);
+    if (lane_live) {
+      Cm2Col c; uint32_t own;
+      slide_begin(c, own);
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t nm = s_cw[ls + 1][lx0 + j + 2];
+        cm2_gather_slide(c, own, s_cw[ls][lx0 + j + 2], nm, s_cw[ls + 2][lx0 + j + 2]);
+        own = nm;
+        if (lx0 + j < w) {
+          const uint64_t mag = want_dist ? mg[lane * 16 + j] : 0ull;
+          if (!first) { cm2_pass(B0, cx, 0, c, mag, d3[0]); cm2_pass(B1, cx, 1, c, mag, d3[1]); }
+          cm2_pass(B2, cx, 2, c, mag, d3[2]);
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
     for (int pass = pass0; pass < 3; pass++) {

@@ -699,11 +699,18 @@ struct UpdScatter {
 // residues of rows [ry0, ry0+RH) x columns [rx0, rx0+RW) of a B picture's plane into LDS, 4 bytes per thread-load (all threads)
 template <int RW, int RH>
 __device__ __forceinline__ void upd_stage_region(uint8_t* reg, int ry0, int rx0, const uint8_t* h, int hstride, int Hs, int tid) {
-  for (int q = tid; q < RH * (RW / 4); q += 256) {
-    const int ly = q / (RW / 4), lx = 4 * (q % (RW / 4)), y = ry0 + ly, x = rx0 + lx;
-    uint32_t v = 0x80808080u;
-    if (y >= 0 && y < Hs && x >= 0 && x + 3 < hstride) v = *(const uint32_t*)(h + (size_t)y * hstride + x);
-    *(uint32_t*)(reg + ly * RW + lx) = v;
+  constexpr int NQ = RH * (RW / 4), NIT = (NQ + 255) / 256;
+  uint32_t v[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {  // every load of the thread is issued before the first store waits for one
+    const int q = tid + it * 256, ly = q / (RW / 4), lx = 4 * (q % (RW / 4)), y = ry0 + ly, x = rx0 + lx;
+    v[it] = 0x80808080u;
+    if (q < NQ && y >= 0 && y < Hs && x >= 0 && x + 3 < hstride) v[it] = *(const uint32_t*)(h + (size_t)y * hstride + x);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int q = tid + it * 256, ly = q / (RW / 4), lx = 4 * (q % (RW / 4));
+    if (q < NQ) *(uint32_t*)(reg + ly * RW + lx) = v[it];
   }
 }
 #define UL_TW 64
@@ -782,6 +789,16 @@ __global__ void __launch_bounds__(256) k_upd_luma_tile(UpdArgs a) {
     else for (int k = 0; k < 4 && x + k < g.W; k++) dst[(size_t)y * g.W + x + k] = (uint8_t)(v >> (8 * k));
   }
 }
+// both chroma planes of every even picture, as stored: 16 bytes per thread (the tile kernel then rewrites what an update reaches)
+__global__ void __launch_bounds__(256) k_upd_chroma_copy(UpdArgs a) {
+  const LevelGeom& g = a.g;
+  const size_t n = (size_t)2 * (g.W / 2) * (g.H / 2), k = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  if (k >= n) return;
+  const uint8_t* src = a.frames + (size_t)(a.src_mul * blockIdx.y) * g.F + (size_t)g.W * g.H + k;
+  uint8_t* dst = a.low + (size_t)(a.dst_mul * blockIdx.y) * g.F + (size_t)g.W * g.H + k;
+  if (k + 16 <= n && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) *(uint4*)dst = *(const uint4*)src;
+  else for (size_t q = 0; q < 16 && k + q < n; q++) dst[q] = src[q];
+}
 // Chroma: the targets are the up-sampled planes (update.cpp:472-503), the sources the half-resolution residue in the top-left
 // quadrant (Q3), and the stored picture is the chroma/2 analysis of the result (update.cpp:632-643).  The 20 x 80 footprint of a
 // 32x8 output tile is the LDS target tile; each of the four waves owns five of its rows for the scatter.
@@ -796,16 +813,13 @@ __global__ void __launch_bounds__(256) k_upd_chroma_tile(UpdArgs a) {
   const int i0 = blockIdx.x * PC_TW, j0 = blockIdx.y * PC_TH;
   const int cw = g.W / 2, chh = g.H / 2;
   const int xb = 2 * i0 - 8, yb = 2 * j0 - 2;
-  const uint8_t* u = frame_c(a.frames, g, a.src_mul * j, c);
   const size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh;
   UpdSide s[2];
   upd_sides(a, j, s);
   const int ci = i0 + (tid & (PC_TW - 1)), cj = j0 + tid / PC_TW;
-  const bool untouched = (!s[0].high && !s[1].high) || yb >= chh + a.reach || 2 * i0 - 2 >= cw + a.reach;  // workgroup-uniform
-  if (untouched) {
-    if (ci < cw && cj < chh) a.low[(size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci] = u[(size_t)cj * cw + ci];
-    return;
-  }
+  // tiles out of reach of the top-left quadrant (Q3), and pictures without a contributing B picture, keep the stored chroma:
+  // k_upd_chroma_copy has already written it (analysis(synthesis(u)) == u exactly)
+  if ((!s[0].high && !s[1].high) || yb >= chh + a.reach || 2 * i0 - 2 >= cw + a.reach) return;  // workgroup-uniform
   constexpr int SR = PC_FH / 4;  // footprint rows per wave
   uint8_t* tile = sP + wv * SR * PC8_FW;
   const int ty0 = yb + wv * SR;
@@ -878,8 +892,14 @@ void launch_update(hipStream_t st, const UpdArgs& a) {
   dim3 block(64, 4);
   const dim3 cgrid((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, (g.nB + 1) * 2);
   hipLaunchKernelGGL(k_upd_luma_tile, dim3((g.W + UL_TW - 1) / UL_TW, (g.H + 4 * UL_TH - 1) / (4 * UL_TH), g.nB + 1), dim3(256), 0, st, a);
-  if (a.cup && g.W % 8 == 0) hipLaunchKernelGGL(k_upd_chroma_tile, cgrid, block, 0, st, a);
-  else hipLaunchKernelGGL(k_upd_chroma, cgrid, block, 0, st, a);
+  if (a.cup && g.W % 8 == 0) {
+    const size_t n = (size_t)2 * (g.W / 2) * (g.H / 2);
+    hipLaunchKernelGGL(k_upd_chroma_copy, dim3((unsigned)((n / 16 + 256) / 256), g.nB + 1), dim3(256), 0, st, a);
+    // only the tiles an update can reach: output columns < (cw + reach + 2) / 2, rows < (chh + reach + 2) / 2 (Q3)
+    const int cw = g.W / 2, chh = g.H / 2;
+    const int tx = imin((int)cgrid.x, ((cw + a.reach + 2) / 2 + PC_TW - 1) / PC_TW + 1), ty = imin((int)cgrid.y, ((chh + a.reach + 2) / 2 + PC_TH - 1) / PC_TH + 1);
+    hipLaunchKernelGGL(k_upd_chroma_tile, dim3(tx, ty, cgrid.z), block, 0, st, a);
+  } else hipLaunchKernelGGL(k_upd_chroma, cgrid, block, 0, st, a);
 }
 
 // max |component| of a motion buffer -> *out (int, pre-zeroed)

@@ -71,6 +71,7 @@ void Prof::end(qsvc_ctx* c) {
 }
 
 static void free_seq(qsvc_ctx* c) {
+  c->cup_src = nullptr;
   for (auto& l : c->lv) {
     l.low.release(); l.high.release(); l.pred.release(); l.mv_raw.release(); l.mv_filt.release(); l.hist.release();
     l.low_n = l.high_n = l.pred_n = 0; l.mv_raw_n = l.mv_filt_n = 0; l.mv_bs = 0; l.types.clear();
@@ -154,6 +155,7 @@ int qsvc_put_frames(qsvc_ctx* c, int kind, int t, int first, int count, int tota
   if (first < 0 || count < 0 || first + count > total) return c->fail(QSVC_ERR_INVALID, "bad frame range");
   if ((r = b->ensure(c, (size_t)total * c->F))) return r;
   *n = total;
+  c->cup_src = nullptr;  // pictures change: the interpolated chroma planes are stale
   HIPCHK(c, hipMemcpyAsync((uint8_t*)b->p + (size_t)first * c->F, src, (size_t)count * c->F, hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   return QSVC_OK;
@@ -307,7 +309,11 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
 static int make_cup(qsvc_ctx* c, const LevelGeom& g, const uint8_t* frames, int mul, const uint8_t** out) {
   int r = c->cup.ensure(c, (size_t)(g.nB + 1) * 2 * g.H * g.W);
   if (r) return r;
-  launch_chroma_up(c->st, frames, g, mul, g.nB + 1, (uint8_t*)c->cup.p);
+  // decorrelate and update of one level interpolate the same even pictures: the second call finds the planes in place
+  if (!(c->cup_src == frames && c->cup_mul == mul && c->cup_n == g.nB + 1)) {
+    launch_chroma_up(c->st, frames, g, mul, g.nB + 1, (uint8_t*)c->cup.p);
+    c->cup_src = frames; c->cup_mul = mul; c->cup_n = g.nB + 1;
+  }
   *out = (const uint8_t*)c->cup.p;
   return QSVC_OK;
 }
@@ -436,6 +442,7 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   if ((r = make_cup(c, g, a.frames, a.src_mul, &a.cup))) return r;
   launch_update(c->st, a);
   pf.end(c);
+  c->cup_src = nullptr;  // low_t was written: nothing interpolated from pictures may be reused across this point
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->st));  // lv.types / halo buffers may be changed by the caller next
   return QSVC_OK;
@@ -501,6 +508,7 @@ int qsvc_un_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   if ((r = make_cup(c, g, a.frames, a.src_mul, &a.cup))) return r;
   launch_update(c->st, a);
   pf.end(c);
+  c->cup_src = nullptr;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->st));
   return QSVC_OK;
@@ -529,6 +537,7 @@ int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   }
   Prof pf;
   pf.begin(c, "correlate");
+  c->cup_src = nullptr;  // un_update has just rewritten the even pictures
   if (!a.margin && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
   if (g.ov >= 2) {
     if ((r = predict_overlapped(c, g, a))) return r;

@@ -63,6 +63,7 @@ struct qsvc_ctx {
   std::vector<DevBuf> snap;  // ME pyramid snapshots per DWT level
   DevBuf margin;             // Q7 chroma margin state of the level being decorrelated
   DevBuf ovl[2];             // --block_overlaping: prediction planes in the Mallat layout, [nB][3][H][W] int16 each
+  const void* cup_src = nullptr; int cup_mul = 0, cup_n = 0;  // what `cup` currently holds (reset by anything that writes pictures)
   DevBuf cup;                // chroma x2 interpolation of the even pictures of the level in work: [nB+1][2][H][W] u8
   DevBuf mvtmp[2], scal, tmp16[2];
   DevBuf halo_tx[2], halo_rx[2];  // boundary records: [0] left neighbour, [1] right neighbour

@@ -23,4 +23,4 @@ python3 bench.py --sessions 1 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_ou
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_s1_prof -o b --output-format csv -- python3 bench.py --sessions 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_s1_prof.log 2>&1
 cp $(find gpurun_out/${tag}_s1_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_s1_kernel_stats.csv
 rm -rf gpurun_out/${tag}_prof gpurun_out/${tag}_s1_prof gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w
-python3 tools/kstats.py gpurun_out/${tag}_s1_kernel_stats.csv 7 | head -24
+python3 tools/kstats.py gpurun_out/${tag}_s1_kernel_stats.csv 8 | head -24
