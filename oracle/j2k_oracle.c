@@ -10,10 +10,14 @@
  * F (5/3 reversible and 9/7 irreversible DWT) -- anchored on the reference's call site and the
  * parameters it pins there: single component, Sprecision=8 Ssigned=no, Clevels=SRLs-1, Clayers=nLayers,
  * Cuse_sop=yes, one tile, 64x64 code-blocks, LRCP, Creversible=no (9/7) with reversible 5/3 as the
- * build's extension.  What pins it instead of Kakadu: every code-stream it writes is decoded by an
+ * build's extension.  What pins it instead of Kakadu: (1) every code-stream it writes is decoded by an
  * independent JPEG 2000 decoder (OpenJPEG 2.5 via Pillow) in tests/test_j2k_oracle.py -- bit-exact
- * reconstruction for 5/3, PSNR bound for 9/7 -- and the MQ state table was checked against
- * libopenjp2's.
+ * reconstruction for 5/3, PSNR bound for 9/7; (2) a SECOND ENCODER agrees byte for byte: OpenJPEG's
+ * code-streams of the same planes hold, per code-block, the same zero bit-planes, coding passes and MQ
+ * segments, and the same packet sequence (tests/test_j2k_vs_openjpeg.py through the independent parser
+ * tests/j2k_t2parse.py); (3) the decoder at the end of this file returns OpenJPEG's samples
+ * (tests/test_j2k_decoder.py); (4) the published T.88 H.2 MQ test sequence; the MQ state table was
+ * checked against libopenjp2's.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
  */
