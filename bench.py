@@ -295,11 +295,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # MQ lanes per wave (read by the library at every launch): 64 when several encodes share the GPU (fewest issue slots per
-    # decision), 16 for one sequence alone (shortest chain).  A caller's own QSVC_MQ_LANES wins.
-    user_lanes = os.environ.get("QSVC_MQ_LANES")
-    if user_lanes is None:
-        os.environ["QSVC_MQ_LANES"] = "64" if S > 1 else "16"
+    # code-blocks per MQ wave: the library's default (64; the coder has no divergent path, so a wave costs the same with 16 or 64
+    # lanes in work and the widest form is best for one sequence and for many).  QSVC_MQ_LANES overrides it.
+    mq_lanes = os.environ.get("QSVC_MQ_LANES", "64")
     run_steps(args.warmup)
     for e in engs:
         e.set_profiling(True)
@@ -320,8 +318,6 @@ def main():
         e.set_profiling(False)
     serial_ms, iso = None, {}
     if world == 1:  # ONE sequence alone on the chip: its latency, and every kernel group's ISOLATED duration (HIP events)
-        if user_lanes is None:
-            os.environ["QSVC_MQ_LANES"] = "16"
         step(0)
         engs[0].sync()
         engs[0].set_profiling(True)
@@ -375,7 +371,6 @@ def main():
                     tot += launches * e["hbm_bytes_per_launch_raw"]
             return int(tot) if seen else None
 
-        mq_lanes = user_lanes or ("64" if S > 1 else "16")
         dom = "j2k_t1_mq"
         a = alg[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e9 if dom in per and per[dom]["ms_per_step"] > 0 else 0.0
         roof = {"kernel": dom, "kernel_symbol": f"k_t1_mq<{mq_lanes}>", "bound": "hbm", "achieved": round(a, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

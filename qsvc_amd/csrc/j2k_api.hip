@@ -488,40 +488,22 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     S.h_joboff.resize(ncb);
     size_t njobs = 0;
     for (int b = 0; b < ncb; b++) { S.h_joboff[b] = (int)njobs; njobs += S.h_nbps[b] > 15 ? 15 : S.h_nbps[b]; }
-    // MQ slot table: slot k of the MQ launch codes block order[k] (ncb = idle lane).  The blocks with the longest expected
-    // chains (bit-planes x area) can be set apart in waves of few lanes, whose lock-step costs less per decision; the others
-    // keep their natural order, 16 to a wave.  QSVC_MQ_NARROW="<fraction>,<lanes>" (default off = "0,16").
-    static const double narrow_frac = [] { const char* e = getenv("QSVC_MQ_NARROW"); return e ? atof(e) : 0.0; }();
-    static const int narrow_lanes = [] { const char* e = getenv("QSVC_MQ_NARROW"); const char* q = e ? strchr(e, ',') : nullptr; int v = q ? atoi(q + 1) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
-    const int MQW = 16;
-    const bool mq_sort = [] { const char* e = getenv("QSVC_MQ_SORT"); return e && atoi(e) != 0; }();
+    // MQ slot table: slot k of the MQ launch codes block order[k] (ncb = idle lane).  A wave runs until its longest block is
+    // coded, so blocks of similar expected length (bit-planes x area) share a wave, the longest first (counting sort);
+    // QSVC_MQ_SORT=0 keeps the natural order.
+    const int MQW = 64;
+    const bool mq_sort = [] { const char* e = getenv("QSVC_MQ_SORT"); return !e || atoi(e) != 0; }();
     int nslots = 0;
     {
       std::vector<int>& ord = S.h_order;
-      ord.clear();
-      int nn = (int)(narrow_frac * ncb);
-      if (nn > 0) {
+      ord.resize(ncb);
+      if (mq_sort) {
         int hist[15 * 64 + 2] = {0};
         auto key = [&](int b) { int nb = S.h_nbps[b] > 15 ? 15 : S.h_nbps[b]; return 15 * 64 - nb * (((int)S.cbs[b].w * S.cbs[b].h + 63) >> 6); };
         for (int b = 0; b < ncb; b++) hist[key(b) + 1]++;
         for (int k = 1; k <= 15 * 64; k++) hist[k] += hist[k - 1];
-        std::vector<int> sorted(ncb);
-        for (int b = 0; b < ncb; b++) sorted[hist[key(b)]++] = b;
-        std::vector<char> taken(ncb, 0);
-        for (int i = 0; i < nn; i += narrow_lanes) {
-          for (int l = 0; l < MQW; l++) ord.push_back(l < narrow_lanes && i + l < nn ? sorted[i + l] : ncb);
-          for (int l = 0; l < narrow_lanes && i + l < nn; l++) taken[sorted[i + l]] = 1;
-        }
-        for (int b = 0; b < ncb; b++) if (!taken[b]) ord.push_back(b);
-      } else if (mq_sort) {  // blocks of similar expected chain length (bit-planes x area) share a wave: fewer idle lane-steps
-        int hist[15 * 64 + 2] = {0};
-        auto key = [&](int b) { int nb = S.h_nbps[b] > 15 ? 15 : S.h_nbps[b]; return 15 * 64 - nb * (((int)S.cbs[b].w * S.cbs[b].h + 63) >> 6); };
-        for (int b = 0; b < ncb; b++) hist[key(b) + 1]++;
-        for (int k = 1; k <= 15 * 64; k++) hist[k] += hist[k - 1];
-        ord.resize(ncb);
         for (int b = 0; b < ncb; b++) ord[hist[key(b)]++] = b;
       } else {
-        ord.resize(ncb);
         for (int b = 0; b < ncb; b++) ord[b] = b;
       }
       while (ord.size() % MQW) ord.push_back(ncb);

@@ -51,60 +51,87 @@ void launch_t1_nbps(hipStream_t st, const CbDesc* cbs, int ncb, int* nbps, int* 
 // segments (k_t1_mq, t1_core.h: one code-block per lane).
 __constant__ uint32_t c_mqtab[47] = T1_MQ_TABLE_INIT;
 
+// Every lane walks ITS block's coding passes on its own: the wave runs until the last lane has coded its last chunk, i.e. for
+// max over lanes of the block's decisions -- not for the sum over the passes of the per-pass maxima, which a pass-synchronous
+// loop costs (measured on config 3: 51 200 steps for the slowest wave against 38 048 decisions of its longest block).  The
+// decisions-per-pass table of the block sits in LDS; the first chunk of the next non-empty pass is prefetched while the last
+// chunk of the current one is coded.
+#define MQ_CNT_STRIDE 50  // u16 entries per lane (>= T1_MAXPASS; 25 words: odd)
 template <int T1_MQ_LANES>
 __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
                                                         const int* order, int nslots, const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf,
                                                         int outcap, CbOut* res, int* pass_len, long long* pass_dist) {
-  __shared__ uint32_t s_cx[19 * T1_MQ_LANES];
+  __shared__ uint32_t s_cx[21 * T1_MQ_LANES];  // 20 context words per lane, odd stride
+  __shared__ uint32_t s_stage[(T1_STAGE / 4) * T1_MQ_LANES];
+  __shared__ uint16_t s_cnt[MQ_CNT_STRIDE * T1_MQ_LANES];
   __shared__ uint32_t s_mq[64];
   __shared__ uint64_t s_mq2[94];
+  static_assert(T1_MAXPASS <= MQ_CNT_STRIDE, "pass table");
   // order[]: the host's slot table (block index, or ncb for an idle lane)
   int lane = threadIdx.x, slot = blockIdx.x * T1_MQ_LANES + lane, b = slot < nslots ? order[slot] : ncb;
   for (int i = lane; i < 47; i += T1_MQ_LANES) s_mq[i] = c_mqtab[i];
   for (int i = lane; i < 94; i += T1_MQ_LANES) s_mq2[i] = mq2_pair(c_mqtab, i);
   __syncthreads();
   T1Lane t;
-  t.cx = s_cx + lane; t.cs = T1_MQ_LANES; t.mqtab = s_mq; t.mq2 = s_mq2; t.zclut = nullptr;
+  t.cx = s_cx + 21 * lane; t.cs = 1; t.mqtab = s_mq; t.mq2 = s_mq2; t.zclut = nullptr;
+  t.stg = (uint8_t*)(s_stage + (T1_STAGE / 4) * lane);
   t.w = t.h = t.orient = 0; t.nbps = 0; t.out = outbuf; t.cap = 0;
   size_t job0 = 0;
   if (b < ncb) { t.nbps = nbps_in[b] > 15 ? 15 : nbps_in[b]; t.out = outbuf + (size_t)b * outcap; t.cap = outcap; job0 = (size_t)joboff[b]; }
-  int top = t.nbps - 1;
-  for (int o = T1_MQ_LANES / 2; o >= 1; o >>= 1) { int a = __shfl_xor(top, o, 64); top = a > top ? a : top; }
-  top = __builtin_amdgcn_readfirstlane(top);
   int bb = b < ncb ? b : 0;
   int* pl = pass_len + (size_t)bb * T1_MAXPASS;
   long long* pd = pass_dist ? pass_dist + (size_t)bb * T1_MAXPASS : nullptr;
   mq2_lane_init(t);
-  int np = 0;
-  for (int p = top; p >= 0; p--) {
-    const bool active = p < t.nbps, first = p == t.nbps - 1;
-    const size_t job = job0 + (active ? p : 0);
-    for (int pass = 0; pass < 3; pass++) {
-      if (pass < 2 && p == top) continue;
-      const bool lane_pass = active && (pass == 2 || !first);
-      const int n = lane_pass ? cnt[job * 3 + pass] : 0;
-      int nmax = n;
-      for (int o = T1_MQ_LANES / 2; o >= 1; o >>= 1) { int a = __shfl_xor(nmax, o, 64); nmax = a > nmax ? a : nmax; }
-      nmax = __builtin_amdgcn_readfirstlane(nmax);
-      const uint4* sg = (const uint4*)(segs + job * T1_SEG_BYTES + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2)));
-      uint4 cur = make_uint4(0, 0, 0, 0);
-      if (n > 0) cur = sg[0];
-      for (int i = 0; i < nmax; i += 16) {
-        // `cur` must have LANDED before the next chunk's load is issued: otherwise hipcc, which cannot count the
-        // divergent stores in between, waits vmcnt(0) at the first use of `cur` and so also for the prefetch.
-        asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w)::"memory");
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (i + 16 < n) nxt = sg[(i >> 4) + 1];  // next 16 decisions in flight while these are coded
-        mq2_chunk16(t, cur.x, cur.y, cur.z, cur.w, n - i);
-        cur = nxt;
-      }
-      t.nsym += (uint32_t)n;
-      if (lane_pass && np < T1_MAXPASS) { pl[np] = t.n + 4; if (pd) pd[np] = dist[job * 3 + pass]; np++; }
-    }
+  // coding pass q of the block: q = 0 is the clean-up pass of the top bit-plane, then three passes per plane
+  const int nbps = t.nbps, npass = nbps ? 3 * nbps - 2 : 0;
+  auto plane_of = [&](int q) { return q ? nbps - 2 - (((q - 1) * 43) >> 7) : nbps - 1; };   // (q - 1) / 3 for q - 1 < 128
+  auto kind_of = [&](int q) { return q ? (q - 1) - 3 * (((q - 1) * 43) >> 7) : 2; };
+  uint16_t* mycnt = s_cnt + MQ_CNT_STRIDE * lane;
+  for (int q = 0; q < npass; q++) {
+    const size_t e = (job0 + plane_of(q)) * 3 + kind_of(q);
+    mycnt[q] = (uint16_t)cnt[e];
+    if (pd) pd[q] = dist[e];
+  }
+  auto seg_of = [&](int q) {
+    const int k = kind_of(q);
+    return (const uint4*)(segs + (job0 + plane_of(q)) * T1_SEG_BYTES + (k == 0 ? 0 : (k == 1 ? T1_SEG1 : T1_SEG2)));
+  };
+  // (q, n, sg): the pass being coded; (q2, n2, sg2): the next pass that has decisions (q2 == npass: none)
+  int q = -1, n = 0, i = 0, q2 = 0, n2 = 0;
+  const uint4 *sg = nullptr, *sg2 = nullptr;
+  auto look_ahead = [&]() {
+    q2 = q + 1; n2 = 0;
+    while (q2 < npass && (n2 = mycnt[q2]) == 0) q2++;
+    sg2 = q2 < npass ? seg_of(q2) : nullptr;
+  };
+  auto enter_next = [&]() {   // passes q .. q2-1 are complete (all but q without a decision): their lengths, then pass q2 becomes current
+    const int c4 = mq2_count(t) + 4;
+    for (int k = q < 0 ? 0 : q; k < q2; k++) pl[k] = c4;
+    q = q2; n = n2; sg = sg2; i = 0;
+    look_ahead();
+  };
+  look_ahead();
+  enter_next();
+  const uint4 pad = make_uint4(T1_PAD4, T1_PAD4, T1_PAD4, T1_PAD4);  // a lane that is done codes the idle context
+  uint4 cur = pad;
+  if (q < npass) cur = sg[0];
+  while (__any(q < npass)) {
+    // `cur` must have LANDED before the next chunk's load is issued: otherwise hipcc, which cannot count the
+    // divergent stores in between, waits vmcnt(0) at the first use of `cur` and so also for the prefetch.
+    asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w)::"memory");
+    const bool more = i + 16 < n;
+    const uint4* pa = more ? sg + (i >> 4) + 1 : sg2;
+    uint4 nxt = pad;
+    if (more || (q < npass && q2 < npass)) nxt = *pa;  // next 16 decisions in flight while these are coded
+    mq2_chunk16(t, cur.x, cur.y, cur.z, cur.w);
+    if (t.sp - t.stg >= T1_STAGE_FLUSH) mq2_stage_flush(t);
+    cur = nxt;
+    i += 16;
+    if (q < npass && i >= n) { t.nsym += (uint32_t)n; enter_next(); }
   }
   T1Result r;
   r.pass_len = pl; r.pass_dist = pd;
-  t1_lane_finish<true>(t, np, r);
+  t1_lane_finish<true>(t, npass, r);
   if (b < ncb) {
     CbOut o;
     o.len = r.len; o.npasses = r.npasses; o.nbps = r.nbps; o.overflow = r.overflow; o.nsym = r.nsym;
@@ -115,12 +142,13 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
 void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int nslots,
                   const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf, int outcap, CbOut* res, int* pass_len,
                   long long* pass_dist, int want_dist) {
-  // lanes (code-blocks) per MQ wave: 16 gives the shortest chain for one sequence alone, 64 the best throughput when several
-  // encodes share the GPU (fewer issue slots per decision).  Read at every launch so a host can switch between the two.
-  const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 16; return (v == 4 || v == 8 || v == 32 || v == 64) ? v : 16; }();
+  // lanes (code-blocks) per MQ wave: the coder is straight-line (no divergent path in a decision), so a wave costs the same
+  // whatever the number of lanes in work; 64 is best for one sequence (245 waves, one per CU) and for many.  QSVC_MQ_LANES
+  // (4, 8, 16, 32; read at every launch) is kept for experiments.
+  const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 64; return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 64; }();
   long long* pdp = want_dist ? pass_dist : nullptr;
 #define MQ_LAUNCH(N) hipLaunchKernelGGL(k_t1_mq<N>, dim3((nslots + N - 1) / N), dim3(N), 0, st, cbs, ncb, nbps, joboff, order, nslots, segs, cnt, dist, outbuf, outcap, res, pass_len, pdp)
-  switch (ml) { case 4: MQ_LAUNCH(4); break; case 8: MQ_LAUNCH(8); break; case 32: MQ_LAUNCH(32); break; case 64: MQ_LAUNCH(64); break; default: MQ_LAUNCH(16); }
+  switch (ml) { case 4: MQ_LAUNCH(4); break; case 8: MQ_LAUNCH(8); break; case 16: MQ_LAUNCH(16); break; case 32: MQ_LAUNCH(32); break; default: MQ_LAUNCH(64); }
 #undef MQ_LAUNCH
 }
 
@@ -335,6 +363,11 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
         }
       }
     }
+    if (lane < 16)  // the tails of the last 16-byte chunks: the idle decision (t1_core.h, T1_PAD)
+      for (int pass = pass0; pass < 3; pass++) {
+        const int i = tot3[pass] + lane;
+        if (i < ((tot3[pass] + 15) & ~15)) s_out[(pass == 0 ? 0 : (pass == 1 ? base1 : base2)) + i] = (uint8_t)T1_PAD;
+      }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
     for (int pass = pass0; pass < 3; pass++) {
       const uint8_t* src = s_out + (pass == 0 ? 0 : (pass == 1 ? base1 : base2));
@@ -350,6 +383,7 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
         if (s < nstr && x < w)
           cm2_column(B, cx, pass, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x], want_dist ? mg[i] : 0ull, d3[pass]);
       }
+      if (lane < 16 && tot3[pass] + lane < ((tot3[pass] + 15) & ~15)) s_out[tot3[pass] + lane] = (uint8_t)T1_PAD;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
       uint8_t* dst = seg + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
       for (int o = lane * 16; o < tot3[pass]; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(s_out + o);

@@ -97,7 +97,7 @@ struct T1Result {  // per code-block outputs besides the bytes
 //   void pass_begin(int nstripes) / stripe_begin(int s, int nstripes) / stripe_end(int s) / pass_end(int nstripes)
 //        wave-uniform window management (no-ops on the host)
 struct T1Lane {
-  uint32_t* cx;           // this lane's context states, one packed word each: the state's table entry
+  uint32_t* cx;           // this lane's context states (19; 20 in the second coder form), one packed word each: the state's table entry
                           // (qe | nmps<<16 | nlps<<22 | switch<<28) | mps<<29; context c at cx[c*cs]
   const uint32_t* mqtab;  // [47]
   const uint64_t* mq2;    // [94] successor pairs of the second coder form (mq2_*), or nullptr
@@ -110,6 +110,9 @@ struct T1Lane {
   uint32_t A, C;
   int CT, B, n;           // B: byte register (not yet in memory), n: bytes emitted incl. the scratch byte
   uint32_t ob;            // emitted bytes not yet stored (stores go out one aligned u32 at a time)
+  uint8_t* stg;           // second coder form: this lane's staging area (T1_STAGE bytes, 4-byte aligned), cursor, bytes already in out
+  uint8_t* sp;
+  int nfl;
   uint32_t nsym;
 };
 
@@ -187,40 +190,70 @@ T1HD int mq_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment lengt
 }
 
 // ---------------------------------------------------------------------------------------------
-// Second coder form (the split MQ kernel): straight-line, 16 decisions per call.
-// A context word describes itself: qe | 8*(2*state + mps) << 16.  mq2[2*state + mps] holds the two possible successors
+// Second coder form (the split MQ kernel): straight-line, 16 decisions per call, no branch on the common path.
+// A context word describes itself: qe | 8*(2*state + mps) << 16 | mps << 31.  mq2[2*state + mps] holds the two possible successors
 // (low half: after an MPS renormalisation; high half: after an LPS, MPS flipped where SWITCH is set), so a decision needs
 // one context read and one table read, both issued ahead of their use: the context of decision j+1 is fetched while
 // decision j is coded and replaced by j's result when both use the same context.
 // With addc = "C += Qe", seta = "A = Qe" (T.800 C.2.4/C.2.5): seta == (ismps == (A - Qe < Qe)) and addc == !seta, because
 // A - Qe < Qe implies A - Qe < 0x8000.
+// Context T1_CTX_PAD (word 0: Qe = 0, MPS 0) codes nothing: decision byte T1_PAD fills the tails of the 16-byte chunks and
+// the chunks of idle lanes, so no decision needs a validity test.
+// Bytes leave through a per-lane staging area (t.stg, LDS on the GPU): BYTEOUT (C.2.7) is computed for every decision with
+// selects, its byte is written to the staging slot unconditionally and the slot only advances when the byte was due (a slot
+// is rewritten until then).  A lane's staged bytes go to its output buffer 16 at a time (mq2_stage_flush), checked once per
+// chunk: the measured cost of the branchy byte-per-store form was 43 % of the kernel (in a 16-lane wave 85 % of the decisions
+// see some lane emit a byte, and on gfx9 stores share vmcnt with the prefetched decision loads).
+#define T1_CTX_PAD 19
+#define T1_PAD 19u                   // cx = T1_CTX_PAD, d = 0
+#define T1_PAD4 0x13131313u
+#define T1_STAGE 196                 // bytes per lane (49 words: odd stride, conflict-free across lanes)
+#define T1_STAGE_FLUSH 144           // flush once a lane holds this many: + 16 decisions x 3 bytes + FLUSH's 3 stays below T1_STAGE - 1
 T1HD uint32_t mq2_word(const uint32_t* mqtab, int state, int mps) {
-  return (mqtab[state] & 0xFFFF) | (uint32_t)(8 * (2 * state + mps)) << 16;
+  return (mqtab[state] & 0xFFFF) | (uint32_t)(8 * (2 * state + mps)) << 16 | (uint32_t)mps << 31;
 }
 T1HD uint64_t mq2_pair(const uint32_t* mqtab, int idx) {  // idx = 2*state + mps
   const uint32_t e = mqtab[idx >> 1];
   const int mps = idx & 1, sw = (int)((e >> 28) & 1);
   return (uint64_t)mq2_word(mqtab, (int)((e >> 16) & 63), mps) | (uint64_t)mq2_word(mqtab, (int)((e >> 22) & 63), mps ^ sw) << 32;
 }
-T1HD void mq2_lane_init(T1Lane& t) {  // as t1_lane_init, context words in the second form
+T1HD void mq2_lane_init(T1Lane& t) {  // as t1_lane_init, context words in the second form; t.stg must be set
   for (int c = 0; c < 19; c++) t.cx[c * t.cs] = mq2_word(t.mqtab, 0, 0);
   t.cx[0 * t.cs] = mq2_word(t.mqtab, 4, 0); t.cx[T1_CTX_RUN * t.cs] = mq2_word(t.mqtab, 3, 0);
   t.cx[T1_CTX_UNI * t.cs] = mq2_word(t.mqtab, 46, 0);
+  t.cx[T1_CTX_PAD * t.cs] = 0;
   t.A = 0x8000; t.C = 0; t.CT = 12; t.B = 0; t.n = 0; t.ob = 0; t.nsym = 0;
+  t.sp = t.stg; t.nfl = 0;
 }
-T1HD int mq2_clz(uint32_t v) {  // v != 0
+T1HD int mq2_clz(uint32_t v) { return __builtin_clz(v); }  // v != 0
+T1HD int mq2_count(const T1Lane& t) { return t.nfl + (int)(t.sp - t.stg); }  // bytes emitted so far, incl. the scratch byte
+// whole 16-byte groups of the staged bytes -> out (skipped, but counted, past the capacity: -> overflow); the rest moves to the front
+T1HD void mq2_stage_copy(T1Lane& t, int nbytes) {  // nbytes: multiple of 16, or the last bytes of the segment rounded up
+  for (int i = 0; i < nbytes; i += 16) {
+    const uint32_t* s = (const uint32_t*)(t.stg + i);
+    const uint32_t a = s[0], b = s[1], c = s[2], d = s[3];
+    if (t.nfl + i + 16 <= t.cap) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_clz(v);
+      *(uint4*)(t.out + t.nfl + i) = make_uint4(a, b, c, d);
 #else
-  return __builtin_clz(v);
+      const uint32_t v[4] = {a, b, c, d};
+      memcpy(t.out + t.nfl + i, v, 16);
 #endif
+    }
+  }
 }
-// BYTEOUT with a plain byte store per byte (no word packing: nothing but the store depends on the lane's byte count).
-T1HD void mq2_emit(T1Lane& t) {
-  t.out[t.n < t.cap ? t.n : t.cap - 1] = (uint8_t)t.B;  // past the capacity only `n` keeps counting (-> overflow)
-  t.n++;
+T1HD void mq2_stage_flush(T1Lane& t) {
+  const int sn = (int)(t.sp - t.stg), k = sn & ~15;
+  if (k == 0) return;
+  mq2_stage_copy(t, k);
+  const uint32_t* s = (const uint32_t*)(t.stg + k);
+  const uint32_t a = s[0], b = s[1], c = s[2], d = s[3];
+  uint32_t* f = (uint32_t*)t.stg;
+  f[0] = a; f[1] = b; f[2] = c; f[3] = d;
+  t.nfl += k; t.sp = t.stg + (sn - k);
 }
-T1HD void mq2_byteout(T1Lane& t) {
+T1HD void mq2_emit(T1Lane& t) { *t.sp++ = (uint8_t)t.B; }
+T1HD void mq2_byteout(T1Lane& t) {  // the branchy form: FLUSH and the rare second / third byte of one renormalisation
   uint32_t carry = (t.C >> 27) & (uint32_t)(t.B != 0xFF);
   t.B += (int)carry;
   const bool ff = t.B == 0xFF;
@@ -230,46 +263,98 @@ T1HD void mq2_byteout(T1Lane& t) {
   t.C &= ff ? 0xFFFFFu : 0x7FFFFu;
   t.CT = ff ? 7 : 8;
 }
-T1HD int mq2_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment length
+T1HD int mq2_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9, then the staged bytes; returns the segment length
+  mq2_stage_flush(t);
   uint32_t tempc = t.C + t.A;
   t.C |= 0xFFFF;
   if (t.C >= tempc) t.C -= 0x8000;
   t.C <<= t.CT; mq2_byteout(t);
   t.C <<= t.CT; mq2_byteout(t);
   if (t.B != 0xFF) mq2_emit(t);
+  mq2_stage_flush(t);
+  const int sn = (int)(t.sp - t.stg);  // < 16
+  mq2_stage_copy(t, (sn + 15) & ~15);
+  t.n = t.nfl + sn;
   return t.n - 1;
 }
-// decisions: bytes cx | d << 5, little-endian in w0..w3; only the first nvalid (<= 16, may be <= 0) are coded.
-T1HD void mq2_chunk16(T1Lane& t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int nvalid) {
+// decisions: bytes cx | d << 5, little-endian in w0..w3, T1_PAD where there is none
+// Selects are written as bit-field inserts under sign-extended masks (v_bfi_b32): a compare + v_cndmask pair pays wait states
+// for the SGPR it goes through, and a single wave issues one instruction per ~4.3 cycles whatever its kind (tools/ubench.hip).
+#if defined(__HIP_DEVICE_COMPILE__)
+T1HD bool t1_any_lane(bool x) {  // wave-uniform; opaque, so that the test stays ONE scalar branch in front of the rare path
+  unsigned long long m = __builtin_amdgcn_ballot_w64(x);
+  asm volatile("" : "+s"(m));
+  return m != 0;
+}
+#else
+T1HD bool t1_any_lane(bool x) { return x; }
+#endif
+T1HD uint32_t mq2_sel(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }  // mask ? a : b
+T1HD uint32_t mq2_neg_mask(int32_t v) {  // v < 0 ? ~0 : 0, opaque to the optimiser (which would turn the inserts back into compare + select)
+  uint32_t m = (uint32_t)(v >> 31);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(m));
+#endif
+  return m;
+}
+T1HD void mq2_chunk16(T1Lane& t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
   const uint32_t w[4] = {w0, w1, w2, w3};
   uint32_t A = t.A;
   uint32_t e = t.cx[(int)(w0 & 31) * t.cs];
 #pragma unroll
   for (int j = 0; j < 16; j++) {
-    const uint32_t v = w[j >> 2] >> (8 * (j & 3));
-    const int cx = (int)(v & 31);
+    const uint32_t wj = w[j >> 2];
+    const int cx = (int)((wj >> (8 * (j & 3))) & 31);
     uint32_t epre = 0;
     int cx1 = -1;
     if (j < 15) { cx1 = (int)((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 31); epre = t.cx[cx1 * t.cs]; }
-    const uint64_t succ = *(const uint64_t*)((const char*)t.mq2 + (e >> 16));
-    const bool valid = j < nvalid;
-    const uint32_t qe = valid ? (e & 0xFFFF) : 0u;
-    const bool ismps = !valid || ((v >> 5) & 1) == ((e >> 19) & 1);
+    const uint64_t succ = *(const uint64_t*)((const char*)t.mq2 + ((e >> 16) & 0x7FFF));
+    const uint32_t qe = e & 0xFFFF;
+    // sign bit of x: the decision is the LPS (d at bit 31 against the MPS at bit 31 of the context word)
+    const uint32_t x = (wj << (26 - 8 * (j & 3))) ^ e;
     A -= qe;
-    const bool lt = A < qe;
-    const bool ren = !ismps || A < 0x8000u;
-    const bool seta = ismps == lt;
-    t.C += seta ? 0u : qe;
-    A = seta ? qe : A;
-    const uint32_t en = ren ? (ismps ? (uint32_t)succ : (uint32_t)(succ >> 32)) : e;
-    t.cx[cx * t.cs] = en;
-    int sh = mq2_clz(A) - 16;  // 0 unless renormalising: A is in [0x8000, 0xFFFF] otherwise
+    // sign bit of (A - qe): A < qe (both below 2^17); seta = ismps == lt = lps != lt
+    const uint32_t seta = mq2_neg_mask((int32_t)((A - qe) ^ x));
+    const uint32_t Cin = t.C + (qe & ~seta);
+    A = mq2_sel(seta, qe, A);
+    const int sh = mq2_clz(A) - 16;  // 0 unless renormalising: A is in [0x8000, 0xFFFF] otherwise
+    const uint32_t noren = mq2_neg_mask((int32_t)(A << 16));  // A >= 0x8000.  Every LPS renormalises (A = Qe, or A - Qe < Qe)
     A <<= sh;
-    if (sh >= t.CT) {
-      do { t.C <<= t.CT; sh -= t.CT; mq2_byteout(t); } while (sh >= t.CT);
-    }
-    t.C <<= sh; t.CT -= sh;
+    // RENORME's shifts and at most one BYTEOUT, with selects.  d = CT - sh <= 0: a byte is due after CT of the sh shifts.
+    const int d = t.CT - sh;
+    const uint32_t take = mq2_neg_mask(d - 1);
+    const int s1 = sh < t.CT ? sh : t.CT;
+    uint32_t C = Cin << s1;
+    const uint32_t bn = (uint32_t)t.B + (C >> 27);   // B + carry; 0x100 only for B == 0xFF, whose carry stays in C (bit stuffing)
+    const uint32_t em = bn < 255u ? bn : 255u;       // the byte that leaves
+    *t.sp = (uint8_t)em;                             // rewritten until `take`
+    C += ((uint32_t)t.B - em) << 27;                 // the carry that went into the byte leaves C
+    const int bo = (int)((bn + 1 + 19 * 256) >> 8);  // 20 when the byte is 0xFF (the next one takes 7 bits and the carry position), else 19
+    const uint32_t Bn = (C >> bo) & 0xFFu, Cm = C & ((1u << bo) - 1u);
+    t.B = (int)mq2_sel(take, Bn, (uint32_t)t.B);
+    C = mq2_sel(take, Cm, C);
+    t.sp -= (int32_t)take;
+    const int rest = sh - s1;                        // shifts still to do (0 unless a byte left)
+    const int ctn = d + (int)((uint32_t)(27 - bo) & take);  // <= 0: another byte is due within `rest` (rare: sh up to 15)
+    t.C = C << rest;
+    t.CT = ctn;
+    // the successor is only needed now: its table read had the whole decision to arrive
+    const uint32_t lps = mq2_neg_mask((int32_t)x);
+    const uint32_t en = mq2_sel(noren, e, mq2_sel(lps, (uint32_t)(succ >> 32), (uint32_t)succ));
+    t.cx[cx * t.cs] = en;
     e = cx1 == cx ? en : epre;
+    if (__builtin_expect(t1_any_lane(ctn <= 0), 0)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("; rare: more than one byte in one renormalisation");  // keeps the uniform test a branch of its own
+#endif
+      if (ctn <= 0) {  // the second (third) byte of one renormalisation, with the flow chart's loop
+        int ct = 27 - bo, r = rest;
+        t.C = C;
+        do { t.C <<= ct; r -= ct; mq2_byteout(t); ct = t.CT; } while (r >= ct);
+        t.CT = ct - r;
+        t.C <<= r;
+      }
+    }
   }
   t.A = A;
 }
@@ -550,7 +635,9 @@ T1HD void t1_cm_plane(Store& S, const uint8_t* zclut, uint8_t* seg, int p, int w
 // Cnt(p, pass) -> decisions in that pass.  Sequential per lane; different lanes run different lengths.
 template <class SegF, class CntF, class DistF>
 T1HD void t1_mq_block(T1Lane& t, const SegF& Seg, const CntF& Cnt, const DistF& Dist, T1Result& res) {
-  mq2_lane_init(t);
+  uint32_t stage[T1_STAGE / 4];
+  t.stg = (uint8_t*)stage;
+  mq2_lane_init(t);  // t.cx: 20 words
   int np = 0;
   for (int p = t.nbps - 1; p >= 0; p--)
     for (int pass = (p == t.nbps - 1 ? 2 : 0); pass < 3; pass++) {
@@ -558,11 +645,12 @@ T1HD void t1_mq_block(T1Lane& t, const SegF& Seg, const CntF& Cnt, const DistF& 
       int n = Cnt(p, pass);
       for (int i = 0; i < n; i += 16) {
         uint32_t w[4] = {0, 0, 0, 0};
-        for (int k = 0; k < 16 && i + k < n; k++) w[k >> 2] |= (uint32_t)sg[i + k] << (8 * (k & 3));
-        mq2_chunk16(t, w[0], w[1], w[2], w[3], n - i);
+        for (int k = 0; k < 16; k++) w[k >> 2] |= (i + k < n ? (uint32_t)sg[i + k] : T1_PAD) << (8 * (k & 3));
+        mq2_chunk16(t, w[0], w[1], w[2], w[3]);
+        if (t.sp - t.stg >= T1_STAGE_FLUSH) mq2_stage_flush(t);
       }
       t.nsym += (uint32_t)n;
-      res.pass_len[np] = t.n + 4;
+      res.pass_len[np] = mq2_count(t) + 4;
       if (res.pass_dist) res.pass_dist[np] = Dist(p, pass);
       np++;
     }

@@ -250,8 +250,8 @@ extern "C" int emul_t1_block_split(const int32_t* vals, int w, int h, int orient
     T1ArrayStore S{flags.data(), mags.data(), 1};
     t1_cm_plane(S, zclut, segs.data() + (size_t)p * T1_SEG_BYTES, p, w, h, orient, nb, w + 7 > 64 ? 64 : w + 7, h + 5 > 64 ? 64 : h + 5, true, &cnt[p * 3], &dist[p * 3]);
   }
-  uint32_t cx[19];
-  std::vector<uint32_t> buf32((size_t)w * h + 16);
+  uint32_t cx[20];
+  std::vector<uint32_t> buf32(((size_t)w * h + 16 + 3) & ~(size_t)3);  // capacity: a multiple of 16 bytes
   uint8_t* bufp = (uint8_t*)buf32.data();
   static uint64_t mq2[94];
   for (int i = 0; i < 94; i++) mq2[i] = mq2_pair(mqtab, i);
@@ -382,8 +382,8 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
   }
   static uint64_t mq2[94];
   for (int i = 0; i < 94; i++) mq2[i] = mq2_pair(mqtab, i);
-  uint32_t cxs[19];
-  std::vector<uint32_t> buf32((size_t)w * h + 16);
+  uint32_t cxs[20];
+  std::vector<uint32_t> buf32(((size_t)w * h + 16 + 3) & ~(size_t)3);  // capacity: a multiple of 16 bytes
   uint8_t* bufp = (uint8_t*)buf32.data();
   T1Lane t;
   t.cx = cxs; t.mqtab = mqtab; t.mq2 = mq2; t.zclut = zclut; t.out = bufp;
