@@ -103,6 +103,7 @@ struct OBuf {
   void u16(int v) { put(v >> 8); put(v & 255); }
   void u32(uint32_t v) { u16(v >> 16); u16(v & 0xFFFF); }
   void bytes(const uint8_t* s, size_t k) { if (n + k <= cap) memcpy(p + n, s, k); else ovf = true; n += k; }
+  void skip(size_t k) { n += k; }
 };
 struct BitW {  // packet-header bit writer with the 0xFF stuffing rule (T.800 B.10.1)
   OBuf* o; int acc = 0, nbits = 0; bool last_ff = false;
@@ -243,7 +244,6 @@ struct J2kState {
   DevBuf joboff_d, order_d, jobs_d, segs_d, cnt_d, dist_d;  // Tier-1: job list, decision segments
   std::vector<int> h_nbps, h_joboff, h_order, h_jobs;
   std::vector<DwtSb> sbtab;
-  std::vector<uint8_t> t2scratch;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
   std::vector<PlaneDesc> planes;
   std::vector<CbDesc> cbs;
@@ -267,8 +267,11 @@ void j2k_release(qsvc_ctx* c) {
 }
 
 // Write one plane's code-stream (T.800 Annex A markers + LRCP packets) from its coded blocks.
+// out == nullptr: only the length is computed (no byte is read or written; the blocks' packet state is left as it was found).
 static long write_codestream(const PlanePlan& pp, const qsvc_j2k_params& prm, int layers, int cbw, int cbh, HostCb* cb,
                              const int* plen_all /*[ncb][T1_MAXPASS]*/, const uint8_t* data, uint8_t* out, size_t cap) {
+  const bool size_only = out == nullptr;
+  if (size_only) cap = 0;
   const int L = pp.L, nsb = (int)pp.sb.size();
   OBuf o{out, 0, cap, false};
   o.u16(0xFF4F);                                      // SOC
@@ -345,12 +348,16 @@ static long write_codestream(const PlanePlan& pp, const qsvc_j2k_params& prm, in
             int prev = l ? c.layer_passes[l - 1] : 0, now = c.layer_passes[l];
             if (now <= prev) continue;
             int a = prev ? pl[prev - 1] : 0, e = pl[now - 1];
-            o.bytes(data + c.data_off + a, (size_t)(e - a));
+            if (size_only) o.skip((size_t)(e - a)); else o.bytes(data + c.data_off + a, (size_t)(e - a));
           }
     }
   size_t psot = o.n - sot;
   if (sot + 10 <= cap) { out[sot + 6] = (uint8_t)(psot >> 24); out[sot + 7] = (uint8_t)(psot >> 16); out[sot + 8] = (uint8_t)(psot >> 8); out[sot + 9] = (uint8_t)psot; }
   o.u16(0xFFD9);                                      // EOC
+  if (size_only) {
+    for (int k = 0; k < pp.ncb; k++) { cb[k].included = false; cb[k].lblock = 3; }
+    return (long)o.n;
+  }
   return o.ovf ? -1 : (long)o.n;
 }
 
@@ -549,44 +556,16 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   HIPCHK(c, hipStreamSynchronize(c->st));
   HIPCHK(c, hipGetLastError());
   if (err) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
-  // host: rate allocation, gather offsets
-  const auto ra_begin = std::chrono::steady_clock::now();
-  S.hcb.assign(ncb, HostCb());
+  // The code bytes of every block (all of them: what a layer leaves out is decided on the host meanwhile) are gathered in block
+  // order and start their way to the host; rate allocation and the code-streams' lengths are worked out under that copy.
   std::vector<unsigned long long> goffs(ncb);
   std::vector<int> glens(ncb);
   size_t gtotal = 0;
-  S.st_cb += ncb;  // the statistics cover every plane group of the call (reset by j2k_encode_planes)
-  for (int p = 0; p < np; p++) {
-    const PlanePlan& pl = plans[plan_of[p]];
-    const qsvc_j2k_params* pprm = src[p].prm;
-    const int layers = pprm->layers < 1 ? 1 : pprm->layers;
-    for (auto& s : pl.sb) {
-      double wgt = (double)s.delta * norm_of(rev, s.orient, s.dlev);
-      wgt *= wgt;
-      for (int i = 0; i < s.gx * s.gy; i++) {
-        int k = first_cb[p] + s.first_cb + i;
-        const CbOut& ro = S.res[k];
-        if (ro.overflow) return c->fail(QSVC_ERR_NOMEM, "code-block segment exceeds %d bytes", J2K_OUTCAP);
-        HostCb& h = S.hcb[k];
-        h.len = ro.len; h.npasses = ro.npasses; h.nbps = ro.nbps; h.zbp = s.Mb - ro.nbps; h.lblock = 3; h.included = false;
-        S.st_pass += ro.npasses; S.st_sym += ro.nsym;
-        const int* plen = S.plen.data() + (size_t)k * T1_MAXPASS;
-        for (int l = 0; l < layers; l++) {
-          int n;
-          if (l == layers - 1 && pprm->slopes[l] <= 0) n = ro.npasses;
-          else if (pprm->slopes[l] <= 0) n = 0;
-          else n = passes_for_lambda(ro.npasses, plen, S.pdist.data() + (size_t)k * T1_MAXPASS, wgt, slope_to_lambda(pprm->slopes[l]));
-          if (l > 0 && n < h.layer_passes[l - 1]) n = h.layer_passes[l - 1];
-          h.layer_passes[l] = n;
-        }
-        h.first_layer = layers;
-        for (int l = layers - 1; l >= 0; l--) if (h.layer_passes[l] > 0) h.first_layer = l;
-        int used = h.layer_passes[layers - 1] ? plen[h.layer_passes[layers - 1] - 1] : 0;
-        h.data_off = gtotal; goffs[k] = gtotal; glens[k] = used; gtotal += used;
-      }
-    }
+  for (int k = 0; k < ncb; k++) {
+    const CbOut& ro = S.res[k];
+    if (ro.overflow) return c->fail(QSVC_ERR_NOMEM, "code-block segment exceeds %d bytes", J2K_OUTCAP);
+    goffs[k] = gtotal; glens[k] = ro.len; gtotal += (size_t)ro.len;
   }
-  c->host_time("host_rate_alloc", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ra_begin).count());
   if ((r = S.gath_d.ensure(c, gtotal ? gtotal : 16))) return r;
   if (S.gath_h_cap < gtotal) {
     if (S.gath_h) (void)hipHostFree(S.gath_h);
@@ -602,42 +581,65 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
                 (uint8_t*)S.gath_d.p);
   pf.end(c);
   if (gtotal) HIPCHK(c, hipMemcpyAsync(S.gath_h, S.gath_d.p, gtotal, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
-  HIPCHK(c, hipGetLastError());
-  // host: Tier-2, one code-stream per plane.  Planes are independent: worker threads write each plane into a
-  // scratch slot (size bound known from its body bytes), then copy to the packed positions.
-  {
-    std::vector<size_t> slot(np + 1, 0), plen_out(np, 0);
-    for (int p = 0; p < np; p++) {
-      size_t body = 0;
-      for (int k = first_cb[p]; k < first_cb[p + 1]; k++) body += (size_t)glens[k];
-      const PlanePlan& pl = plans[plan_of[p]];
-      int layers = src[p].prm->layers < 1 ? 1 : src[p].prm->layers;
-      slot[p + 1] = slot[p] + body + 64 * (size_t)pl.ncb * layers + 16 * (size_t)layers * (pl.L + 1) + 512;
+  // host: rate allocation
+  const auto ra_begin = std::chrono::steady_clock::now();
+  S.hcb.resize(ncb);
+  S.st_cb += ncb;  // the statistics cover every plane group of the call (reset by j2k_encode_planes)
+  for (int p = 0; p < np; p++) {
+    const PlanePlan& pl = plans[plan_of[p]];
+    const qsvc_j2k_params* pprm = src[p].prm;
+    const int layers = pprm->layers < 1 ? 1 : pprm->layers;
+    for (auto& s : pl.sb) {
+      double wgt = (double)s.delta * norm_of(rev, s.orient, s.dlev);
+      wgt *= wgt;
+      for (int i = 0; i < s.gx * s.gy; i++) {
+        int k = first_cb[p] + s.first_cb + i;
+        const CbOut& ro = S.res[k];
+        HostCb& h = S.hcb[k];
+        h.len = ro.len; h.npasses = ro.npasses; h.nbps = ro.nbps; h.zbp = s.Mb - ro.nbps; h.lblock = 3; h.included = false;
+        S.st_pass += ro.npasses; S.st_sym += ro.nsym;
+        const int* plen = S.plen.data() + (size_t)k * T1_MAXPASS;
+        for (int l = 0; l < layers; l++) {
+          int n;
+          if (l == layers - 1 && pprm->slopes[l] <= 0) n = ro.npasses;
+          else if (pprm->slopes[l] <= 0) n = 0;
+          else n = passes_for_lambda(ro.npasses, plen, S.pdist.data() + (size_t)k * T1_MAXPASS, wgt, slope_to_lambda(pprm->slopes[l]));
+          if (l > 0 && n < h.layer_passes[l - 1]) n = h.layer_passes[l - 1];
+          h.layer_passes[l] = n;
+        }
+        h.first_layer = layers;
+        for (int l = layers - 1; l >= 0; l--) if (h.layer_passes[l] > 0) h.first_layer = l;
+        h.data_off = goffs[k];
+      }
     }
-    if (S.t2scratch.size() < slot[np]) S.t2scratch.resize(slot[np] + slot[np] / 8);
+  }
+  c->host_time("host_rate_alloc", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ra_begin).count());
+  // host: Tier-2, one code-stream per plane; planes are independent.  First every stream's length (packet headers are built, no
+  // byte is copied), which fixes the streams' positions in `out`; then, once the code bytes have arrived, the streams themselves.
+  {
     static const int t2_env = [] { const char* e = getenv("QSVC_T2_THREADS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
     if (!S.pool) { S.pool = new T2Pool(); S.pool->start(t2_env - 1); }
     const int nthreads = S.pool->nworkers + 1;
     std::vector<long> rc(np, 0);
-    const auto t2_begin = std::chrono::steady_clock::now();
-    S.pool->run([&](int tid) {
-      for (int p = tid; p < np; p += nthreads)
-        rc[p] = write_codestream(plans[plan_of[p]], *src[p].prm, src[p].prm->layers < 1 ? 1 : src[p].prm->layers, cbw, cbh,
-                                 S.hcb.data() + first_cb[p], S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS, S.gath_h,
-                                 S.t2scratch.data() + slot[p], slot[p + 1] - slot[p]);
-    });
+    auto stream_of = [&](int p, uint8_t* dst, size_t dcap) {
+      return write_codestream(plans[plan_of[p]], *src[p].prm, src[p].prm->layers < 1 ? 1 : src[p].prm->layers, cbw, cbh,
+                              S.hcb.data() + first_cb[p], S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS, S.gath_h, dst, dcap);
+    };
+    const auto t2a_begin = std::chrono::steady_clock::now();
+    S.pool->run([&](int tid) { for (int p = tid; p < np; p += nthreads) rc[p] = stream_of(p, nullptr, 0); });
     size_t pos = 0;
-    for (int p = 0; p < np; p++) {
-      if (rc[p] < 0) return c->fail(QSVC_ERR_NOMEM, "internal Tier-2 scratch too small");
-      offs[p] = pos; pos += (size_t)rc[p];
-    }
+    for (int p = 0; p < np; p++) { offs[p] = pos; pos += (size_t)rc[p]; }
     offs[np] = pos;
+    double t2_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2a_begin).count();
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
     if (pos > cap) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes needed, %zu given)", pos, cap);
-    S.pool->run([&](int tid) {
-      for (int p = tid; p < np; p += nthreads) memcpy(out + offs[p], S.t2scratch.data() + slot[p], (size_t)rc[p]);
-    });
-    c->host_time("host_tier2", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2_begin).count());
+    const auto t2b_begin = std::chrono::steady_clock::now();
+    std::vector<long> rc2(np, 0);
+    S.pool->run([&](int tid) { for (int p = tid; p < np; p += nthreads) rc2[p] = stream_of(p, out + offs[p], (size_t)rc[p]); });
+    for (int p = 0; p < np; p++) if (rc2[p] != rc[p]) return c->fail(QSVC_ERR_HIP, "internal: Tier-2 length of plane %d changed between the passes", p);
+    t2_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2b_begin).count();
+    c->host_time("host_tier2", t2_ms);
   }
   return QSVC_OK;
 }
