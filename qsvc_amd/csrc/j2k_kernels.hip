@@ -218,7 +218,8 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   __shared__ uint32_t s_cwq[CM2_JOBS][18][66];
   __shared__ uint32_t s_sp[64];
   __shared__ uint8_t s_zcq[CM2_JOBS][512];
-  __shared__ __attribute__((aligned(16))) uint8_t s_outq[CM2_JOBS][CM2_OUT_BYTES];
+  __shared__ __attribute__((aligned(16))) uint8_t s_outq[CM2_JOBS][CM2_OUT_BYTES + 16];  // zeroed; the streams OR whole words into it
+  __shared__ uint8_t s_sign[256];
   __shared__ int s_geo[CM2_JOBS][2];
   __shared__ uint64_t s_rowM[CM2_JOBS][64];
   const int jq = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -236,7 +237,8 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   }
   const unsigned long long* mg = mags + (size_t)b * 1024;
   // tables + column words (lane = column x, all stripes: 512-byte rows of magnitudes)
-  if (jq == 0) s_sp[lane] = CM2_SPREAD_INIT((uint32_t)lane);
+  if (jq == 0) { s_sp[lane] = CM2_SPREAD_INIT((uint32_t)lane); for (int i = lane; i < 256; i += 64) s_sign[i] = cm2_sign_entry(i); }
+  for (int i = lane; i < (CM2_OUT_BYTES + 16) / 16; i += 64) ((uint4*)s_out)[i] = make_uint4(0, 0, 0, 0);
   if (lane == 0) { s_geo[jq][0] = w; s_geo[jq][1] = nstr; }
   {
     const int oc = orient == 1 ? 1 : (orient == 3 ? 3 : 0);
@@ -344,10 +346,10 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   // 16-byte aligned bases of the three streams inside s_out when all of them fit at once
   const int base1 = (tot3[0] + 15) & ~15, base2 = base1 + ((tot3[1] + 15) & ~15);
   if (base2 + tot3[2] <= CM2_OUT_BYTES) {
-    Cm2ByteSink B0, B1, B2;
-    B0.out = s_out + off3[0]; B0.n = 0;
-    B1.out = s_out + base1 + off3[1]; B1.n = 0;
-    B2.out = s_out + base2 + off3[2]; B2.n = 0;
+    Cm2Stream T0, T1, T2;
+    cm2_stream_begin(T0, s_out, off3[0]);
+    cm2_stream_begin(T1, s_out + base1, off3[1]);
+    cm2_stream_begin(T2, s_out + base2, off3[2]);
     if (lane_live) {
       Cm2Col c; uint32_t own;
       slide_begin(c, own);
@@ -357,12 +359,14 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
         cm2_gather_slide(c, own, s_cw[ls][lx0 + j + 2], nm, s_cw[ls + 2][lx0 + j + 2]);
         own = nm;
         if (lx0 + j < w) {
-          const uint64_t mag = want_dist ? mg[lane * 16 + j] : 0ull;
-          if (!first) { cm2_pass(B0, cx, 0, c, mag, d3[0]); cm2_pass(B1, cx, 1, c, mag, d3[1]); }
-          cm2_pass(B2, cx, 2, c, mag, d3[2]);
+          Cm2Out3 O;
+          cm2_emit3(O, cx, s_sign, c, want_dist ? mg[lane * 16 + j] : 0ull, d3);
+          cm2_stream_put8(T0, O.p0); cm2_stream_put4(T1, O.p1); cm2_stream_put4(T2, O.hdr); cm2_stream_put8(T2, O.p2);
         }
       }
     }
+    cm2_stream_end(T0); cm2_stream_end(T1); cm2_stream_end(T2);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
     if (lane < 16)  // the tails of the last 16-byte chunks: the idle decision (t1_core.h, T1_PAD)
       for (int pass = pass0; pass < 3; pass++) {
         const int i = tot3[pass] + lane;
@@ -374,7 +378,7 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
       uint8_t* dst = seg + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
       for (int o = lane * 16; o < tot3[pass]; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(src + o);
     }
-  } else {  // a dense plane: one pass at a time through the buffer
+  } else {  // a dense plane: one pass at a time through the buffer (the per-pass column form)
     for (int pass = pass0; pass < 3; pass++) {
       Cm2ByteSink B;
       B.out = s_out + off3[pass]; B.n = 0;

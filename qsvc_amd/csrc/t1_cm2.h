@@ -244,6 +244,144 @@ T1HD void cm2_counts(const Cm2Col& c, int n[3]) {
   n[2] = cm2_popc4(C4) + cm2_popc4(S24);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The three passes of one stripe column AT ONCE, without a branch per sample: every sample belongs to exactly one pass (sig0 ->
+// refinement, M -> significance, else clean-up) and, the masks being final, its neighbourhood "at the moment it is coded" is a
+// function of the masks alone -- the in-column update of cm2_pass ("f |= ..." when a sample turns significant) only ever reaches
+// the next row, as its upper neighbour, and equals S1 (S2) of the row above.  A column's decisions leave as three short byte
+// strings (at most 8 bytes of the significance pass, 4 of the refinement pass, a run-length header of up to 3 bytes and 8 more
+// of the clean-up pass), which the caller appends to the lane's three streams with whole-word accesses.
+struct Cm2Bytes { uint64_t a; int n; };             // n bytes, the first in the low byte
+struct Cm2Out3 { Cm2Bytes p0, p1, hdr, p2; };
+// sign coding (T.800 D.3.2) as a table: index = sigU | sgnU<<1 | sigL<<2 | sgnL<<3 | sigR<<4 | sgnR<<5 | sigD<<6 | sgnD<<7,
+// value = context | xor-bit << 5 (the decision is value ^ (negative << 5))
+T1HD uint8_t cm2_sign_entry(int idx) {
+  auto contrib = [&](int sig, int sgn) { return sig ? (sgn ? -1 : 1) : 0; };
+  int hc = contrib((idx >> 2) & 1, (idx >> 3) & 1) + contrib((idx >> 4) & 1, (idx >> 5) & 1);
+  int vc = contrib(idx & 1, (idx >> 1) & 1) + contrib((idx >> 6) & 1, (idx >> 7) & 1);
+  hc = hc > 1 ? 1 : (hc < -1 ? -1 : hc);
+  vc = vc > 1 ? 1 : (vc < -1 ? -1 : vc);
+  const int xr = hc < 0 || (hc == 0 && vc < 0);
+  if (xr) { hc = -hc; vc = -vc; }
+  const int cx = hc == 1 ? 12 + vc : (vc == 1 ? 10 : 9);
+  return (uint8_t)(cx | (xr << 5));
+}
+// mag / dist[3]: the column's packed magnitudes and the per-pass distortion sums (touched only with cx.want_dist).
+// Written with 0 / ~0 masks and bit-field inserts rather than conditions: a GPU lane pays for both sides of a branch anyway.
+T1HD uint32_t cm2_m(uint32_t field4, int k) { return (uint32_t)((int32_t)(field4 << (31 - k)) >> 31); }  // bit k of a 4-bit field -> 0 / ~0
+T1HD uint32_t cm2_pick(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }         // mask ? a : b
+T1HD void cm2_emit3(Cm2Out3& O, const Cm2Ctx& cx, const uint8_t* signlut, const Cm2Col& c, uint64_t mag = 0, long long* dist = nullptr) {
+  const uint32_t w = c.w;
+  const uint32_t val4 = (w >> CW_VAL) & 0xF;
+  const uint32_t bit4 = (w >> CW_BIT) & 0xF, M4 = (w >> CW_M) & val4, sig04 = (w >> CW_SIG0) & val4;
+  const uint32_t mu4 = (w >> CW_MU) & 0xF, neg4 = (w >> CW_NEG) & 0xF;
+  const uint32_t C4 = val4 & ~sig04 & ~M4;
+  const uint32_t S14 = M4 & bit4, S24 = C4 & bit4;
+  // the 18-bit neighbourhood words (bit 3r + col, r = 0 the row above the stripe) as each pass sees them
+  const uint32_t A0 = cx.sp[c.s0[0]], A1 = cx.sp[c.s0[1]], A2 = cx.sp[c.s0[2]];
+  const uint32_t B0 = cx.sp[c.s1[0]], B1 = cx.sp[c.s1[1]], B2 = cx.sp[c.s1[2]];
+  const uint32_t D0 = cx.sp[c.s2[0]], D1 = cx.sp[c.s2[1]], D2 = cx.sp[c.s2[2]];
+  const uint32_t fref = (A0 | B0) | (A1 | B1) << 1 | (A2 | B2) << 2;
+  const uint32_t f0 = (A0 | (B0 & 0x7FFF)) | (A1 | (B1 & 1)) << 1 | (A2 | (B2 & 1)) << 2;
+  const uint32_t f2 = fref | (D0 & 0x7FFF) | (D1 & 1) << 1 | (D2 & 1) << 2;
+  const uint32_t fchi = cx.sp[(c.chiL >> T1_CHI_SHIFT) & 63] | cx.sp[(c.chiC >> T1_CHI_SHIFT) & 63] << 1 | cx.sp[(c.chiR >> T1_CHI_SHIFT) & 63] << 2;
+  // a sample of this column that turned significant earlier in the SAME pass is the upper neighbour of the next row only:
+  // S1 / S2 of the column's own rows at the centre positions, cut off below the row in work
+  const uint32_t G1 = (B1 & 0x1248) << 1, G2 = (D1 & 0x1248) << 1;
+  // run-length mode (D.3.4): four rows, no significant neighbour (so none significant, none in the significance pass)
+  const uint32_t rl = (val4 == 0xF && f2 == 0) ? ~0u : 0u;
+  const uint32_t lowest = bit4 & (0u - bit4);                     // the first row with a 1 (0: none)
+  const uint32_t skipA4 = rl & (2 * lowest - 1) & 0xF, skipB4 = rl & (lowest - 1) & 0xF;   // rows the run covers: no zero-coding decision / no sign yet
+  const uint32_t fk = (lowest >> 1) - (lowest >> 3);              // 1, 2, 4, 8 -> 0, 1, 2, 3
+  const uint32_t hdr3 = (uint32_t)(T1_CTX_RUN | 32) | (uint32_t)(T1_CTX_UNI | ((fk >> 1) << 5)) << 8 | (uint32_t)(T1_CTX_UNI | ((fk & 1) << 5)) << 16;
+  O.hdr.a = rl & (bit4 ? hdr3 : (uint32_t)T1_CTX_RUN);   // bytes beyond .n must be zero: the streams OR whole words
+  O.hdr.n = (int)(rl & (bit4 ? 3u : 1u));
+  const uint32_t EA0 = M4, EB0 = S14, EA1 = sig04, EA2 = C4 & ~skipA4, EB2 = S24 & ~skipB4;
+  uint32_t x0[4], x1[4], x2[4];   // the rows' bytes for each pass (0 where the row is not of that pass)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t mM = cm2_m(M4, k), m1 = cm2_m(sig04, k), mbit = cm2_m(bit4, k);
+    const uint32_t cmask = (1u << (3 * k + 2)) - 1;
+    const uint32_t nbr = (fref >> (3 * k)) & 0x1EF;
+    const uint32_t rctx = cm2_pick(cm2_m(mu4, k), 16u, 14u + (nbr ? 1u : 0u));
+    const uint32_t nb0 = ((f0 | (G1 & cmask)) >> (3 * k)) & 0x1FF;
+    const uint32_t nb2 = ((f2 | (G2 & cmask)) >> (3 * k)) & 0x1FF;
+    const uint32_t nbz = cm2_pick(mM, nb0, nb2);
+    const uint32_t A = cm2_pick(m1, rctx, (uint32_t)cx.zc[nbz & 0x1EF]) | (mbit & 32);
+    const uint32_t idx = ((nbz & 0xAA) >> 1) | ((fchi >> (3 * k)) & 0xAA);
+    const uint32_t Bv = (uint32_t)signlut[idx] ^ (cm2_m(neg4, k) & 32);
+    const uint32_t ab = A | Bv << 8;
+    x1[k] = A & m1;
+    x0[k] = ab & cm2_m(EA0, k) & (0xFFu | (cm2_m(EB0, k) & 0xFF00u));
+    const uint32_t ea2 = cm2_m(EA2, k), eb2 = cm2_m(EB2, k);
+    x2[k] = cm2_pick(ea2, ab & (0xFFu | (eb2 & 0xFF00u)), Bv & eb2);
+  }
+  auto cnt = [](uint32_t EA, uint32_t EB, int k) { return (int)(((EA >> k) & 1) + ((EB >> k) & 1)); };
+  {  // refinement: one byte per row of sig0
+    const int c0 = (int)(EA1 & 1), c1 = c0 + (int)((EA1 >> 1) & 1), c2 = c1 + (int)((EA1 >> 2) & 1);
+    O.p1.a = x1[0] | x1[1] << (8 * c0) | x1[2] << (8 * c1) | x1[3] << (8 * c2);
+    O.p1.n = c2 + (int)((EA1 >> 3) & 1);
+  }
+  {  // significance: rows 0, 1 in one word, rows 2, 3 in another (at most four bytes each)
+    const int c0 = cnt(EA0, EB0, 0), c1 = cnt(EA0, EB0, 1), c2 = cnt(EA0, EB0, 2), c3 = cnt(EA0, EB0, 3);
+    const uint32_t lo = x0[0] | x0[1] << (8 * c0), hi = x0[2] | x0[3] << (8 * c2);
+    O.p0.a = (uint64_t)lo | (uint64_t)hi << (8 * (c0 + c1));
+    O.p0.n = c0 + c1 + c2 + c3;
+  }
+  {  // clean-up
+    const int c0 = cnt(EA2, EB2, 0), c1 = cnt(EA2, EB2, 1), c2 = cnt(EA2, EB2, 2), c3 = cnt(EA2, EB2, 3);
+    const uint32_t lo = x2[0] | x2[1] << (8 * c0), hi = x2[2] | x2[3] << (8 * c2);
+    O.p2.a = (uint64_t)lo | (uint64_t)hi << (8 * (c0 + c1));
+    O.p2.n = c0 + c1 + c2 + c3;
+  }
+  if (cx.want_dist && dist) {
+    long long d0 = 0, d1 = 0, d2 = 0;
+    for (int k = 0; k < 4; k++) {
+      const int m = t1_mag(mag, k);
+      if ((sig04 >> k) & 1) d1 += t1_dist_ref(m, cx.p);
+      else if ((S14 >> k) & 1) d0 += t1_dist_sig(m, cx.p);
+      else if ((S24 >> k) & 1) d2 += t1_dist_sig(m, cx.p);
+    }
+    dist[0] += d0; dist[1] += d1; dist[2] += d2;
+  }
+}
+
+// A lane's position in one pass's byte stream: whole words are OR-ed into a zeroed buffer (the first and the last word of a
+// lane's range are shared with its neighbours; a word may be written before it is complete and again when it is).
+struct Cm2Stream {
+  uint32_t* wp;    // the word the next byte falls into
+  uint32_t pend;   // its bytes so far
+  uint32_t fill;   // how many (0..3)
+};
+T1HD void cm2_or_word(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicOr(p, v);
+#else
+  *p |= v;
+#endif
+}
+T1HD void cm2_stream_begin(Cm2Stream& s, uint8_t* base /*4-byte aligned*/, int byte_off) {
+  s.wp = (uint32_t*)base + (byte_off >> 2); s.pend = 0; s.fill = (uint32_t)(byte_off & 3);
+}
+T1HD void cm2_stream_put8(Cm2Stream& s, const Cm2Bytes& b) {  // up to 8 bytes
+  const uint64_t sh = b.a << (8 * s.fill);
+  const uint32_t lo = s.pend | (uint32_t)sh, mid = (uint32_t)(sh >> 32), hi = ((uint32_t)(b.a >> 32) >> 8) >> (24 - 8 * s.fill);
+  cm2_or_word(s.wp, lo);
+  cm2_or_word(s.wp + 1, mid);
+  const uint32_t total = s.fill + (uint32_t)b.n, adv = total >> 2;
+  s.pend = adv == 0 ? lo : (adv == 1 ? mid : hi);
+  s.wp += adv; s.fill = total & 3;
+}
+T1HD void cm2_stream_put4(Cm2Stream& s, const Cm2Bytes& b) {  // up to 4 bytes
+  const uint64_t sh = (uint64_t)(uint32_t)b.a << (8 * s.fill);
+  const uint32_t lo = s.pend | (uint32_t)sh, mid = (uint32_t)(sh >> 32);
+  cm2_or_word(s.wp, lo);
+  const uint32_t total = s.fill + (uint32_t)b.n, adv = total >> 2;
+  s.pend = adv ? mid : lo;
+  s.wp += adv; s.fill = total & 3;
+}
+T1HD void cm2_stream_end(Cm2Stream& s) { if (s.fill) cm2_or_word(s.wp, s.pend); }
+
 template <class Sink>
 T1HD void cm2_column(Sink& K, const Cm2Ctx& cx, int pass, const uint32_t u[3], const uint32_t m[3], const uint32_t d[3],
                      uint64_t mag, long long& dist) {

@@ -379,6 +379,33 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
       }
       cnt[p * 3 + pass] = offs[64]; dist[p * 3 + pass] = dsum;
     }
+    {  // the all-passes-at-once column form (cm2_emit3) must produce the same three byte strings
+      static uint8_t signlut[256];
+      for (int i = 0; i < 256; i++) signlut[i] = cm2_sign_entry(i);
+      std::vector<uint8_t> e3[3];
+      // ... appended through the word streams of the kernel (starting at byte offsets 1, 2, 3 of zeroed buffers)
+      std::vector<uint32_t> wbuf[3];
+      Cm2Stream st[3];
+      long long d3[3] = {0, 0, 0};
+      for (int q = 0; q < 3; q++) { wbuf[q].assign(T1_SEG_BYTES / 4 + 8, 0); cm2_stream_begin(st[q], (uint8_t*)wbuf[q].data(), q + 1); }
+      for (int s = 0; s < nstr; s++)
+        for (int x = 0; x < w; x++) {
+          Cm2Col col; Cm2Out3 O;
+          cm2_gather(col, &cw[s][x], &cw[s + 1][x], &cw[s + 2][x]);
+          cm2_emit3(O, cx, signlut, col, mags[s * 64 + x], d3);
+          auto app = [&](std::vector<uint8_t>& v, const Cm2Bytes& b) { for (int i = 0; i < b.n; i++) v.push_back((uint8_t)(b.a >> (8 * i))); };
+          app(e3[0], O.p0); app(e3[1], O.p1); app(e3[2], O.hdr); app(e3[2], O.p2);
+          cm2_stream_put8(st[0], O.p0); cm2_stream_put4(st[1], O.p1); cm2_stream_put4(st[2], O.hdr); cm2_stream_put8(st[2], O.p2);
+        }
+      for (int q = 0; q < 3; q++) cm2_stream_end(st[q]);
+      for (int pass = 0; pass < 3; pass++) {
+        const uint8_t* seg = segs.data() + (size_t)p * T1_SEG_BYTES + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
+        if (first && pass < 2) { if (!e3[pass].empty()) return -6; continue; }
+        if ((int)e3[pass].size() != cnt[p * 3 + pass] || memcmp(e3[pass].data(), seg, e3[pass].size())) return -6;
+        if (memcmp((const uint8_t*)wbuf[pass].data() + pass + 1, seg, e3[pass].size())) return -7;
+        if (d3[pass] != dist[p * 3 + pass]) return -8;
+      }
+    }
   }
   static uint64_t mq2[94];
   for (int i = 0; i < 94; i++) mq2[i] = mq2_pair(mqtab, i);
