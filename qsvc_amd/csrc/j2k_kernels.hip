@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
                                                            long long* dist, int want_dist) {
   __shared__ uint32_t s_cwq[CM2_JOBS][18][66];
   __shared__ uint32_t s_sp[64];
-  __shared__ uint8_t s_zcq[CM2_JOBS][512];
+  __shared__ uint8_t s_zcq[CM2_JOBS][1024];  // [0..511] zero coding, [512..1023] refinement (t1_cm2.h, cm2_emit3w)
   __shared__ __attribute__((aligned(16))) uint8_t s_outq[CM2_JOBS][CM2_OUT_BYTES + 16];  // zeroed; the streams OR whole words into it
   __shared__ uint8_t s_sign[256];
   __shared__ int s_geo[CM2_JOBS][2];
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   if (lane == 0) { s_geo[jq][0] = w; s_geo[jq][1] = nstr; }
   {
     const int oc = orient == 1 ? 1 : (orient == 3 ? 3 : 0);
-    for (int i = lane; i < 512; i += 64) s_zc[i] = (uint8_t)t1_zc_from_nb(i, oc);
+    for (int i = lane; i < 512; i += 64) { s_zc[i] = (uint8_t)t1_zc_from_nb(i, oc); s_zc[512 + i] = (uint8_t)(((i >> 4) & 1) ? 16 : ((i & 0x1EF) ? 15 : 14)); }
   }
   for (int i = lane; i < 18 * 66; i += 64) (&s_cw[0][0])[i] = 0;
   __syncthreads();
@@ -311,27 +311,18 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   // the new right-hand column's three words are read and taken apart per step (cm2_gather_slide)
   const int ls = lane >> 2, lx0 = (lane & 3) * 16;
   const bool lane_live = ls < nstr && lx0 < w;
-  auto slide_begin = [&](Cm2Col& c, uint32_t& own) {
-    const uint32_t u2[2] = {s_cw[ls][lx0], s_cw[ls][lx0 + 1]}, m2[2] = {s_cw[ls + 1][lx0], s_cw[ls + 1][lx0 + 1]},
-                   d2[2] = {s_cw[ls + 2][lx0], s_cw[ls + 2][lx0 + 1]};
-    cm2_gather_first(c, u2, m2, d2);
-    own = m2[1];
-  };
   int n3[3] = {0, 0, 0};
-  if (lane_live) {
-    Cm2Col c; uint32_t own;
-    slide_begin(c, own);
+  if (lane_live) {  // decisions per pass from the raw column words (the 3 x 3 neighbourhood slides along the stripe)
+    uint32_t u[3] = {0, s_cw[ls][lx0], s_cw[ls][lx0 + 1]}, m[3] = {0, s_cw[ls + 1][lx0], s_cw[ls + 1][lx0 + 1]},
+             d[3] = {0, s_cw[ls + 2][lx0], s_cw[ls + 2][lx0 + 1]};
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      const uint32_t nm = s_cw[ls + 1][lx0 + j + 2];
-      cm2_gather_slide(c, own, s_cw[ls][lx0 + j + 2], nm, s_cw[ls + 2][lx0 + j + 2]);
-      own = nm;
-      if (lx0 + j < w) {
-        int n[3];
-        cm2_counts(c, n);
-        if (!first) { n3[0] += n[0]; n3[1] += n[1]; }
-        n3[2] += n[2];
-      }
+      u[0] = u[1]; u[1] = u[2]; u[2] = s_cw[ls][lx0 + j + 2];
+      m[0] = m[1]; m[1] = m[2]; m[2] = s_cw[ls + 1][lx0 + j + 2];
+      d[0] = d[1]; d[1] = d[2]; d[2] = s_cw[ls + 2][lx0 + j + 2];
+      int n[3];
+      cm2_counts_w(u, m, d, n);  // zero for a column beyond the block's width (its word is 0)
+      n3[0] += n[0]; n3[1] += n[1]; n3[2] += n[2];
     }
   }
   int off3[3], tot3[3];
@@ -351,18 +342,23 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
     cm2_stream_begin(T1, s_out + base1, off3[1]);
     cm2_stream_begin(T2, s_out + base2, off3[2]);
     if (lane_live) {
-      Cm2Col c; uint32_t own;
-      slide_begin(c, own);
+      Cm2Win c;
+      c.w = 0; c.B1 = c.D1 = c.Bn = c.Dn = 0;
+      for (int k = 0; k < 3; k++) c.AB[k] = c.P[k] = c.Q[k] = c.DL[k] = c.DB[k] = c.X[k] = 0;
+      cm2_win_push(c, s_sp, 0, s_cw[ls][lx0], s_cw[ls + 1][lx0], s_cw[ls + 2][lx0]);
+      uint32_t own = s_cw[ls + 1][lx0 + 1];
+      cm2_win_push(c, s_sp, 0, s_cw[ls][lx0 + 1], own, s_cw[ls + 2][lx0 + 1]);
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const uint32_t nm = s_cw[ls + 1][lx0 + j + 2];
-        cm2_gather_slide(c, own, s_cw[ls][lx0 + j + 2], nm, s_cw[ls + 2][lx0 + j + 2]);
-        own = nm;
+        cm2_win_push(c, s_sp, own, s_cw[ls][lx0 + j + 2], nm, s_cw[ls + 2][lx0 + j + 2]);
         if (lx0 + j < w) {
           Cm2Out3 O;
-          cm2_emit3(O, cx, s_sign, c, want_dist ? mg[lane * 16 + j] : 0ull, d3);
+          cm2_emit3w(O, s_zc, s_sign, c);
           cm2_stream_put8(T0, O.p0); cm2_stream_put4(T1, O.p1); cm2_stream_put4(T2, O.hdr); cm2_stream_put8(T2, O.p2);
+          if (want_dist) cm2_dist3(cx, own, mg[lane * 16 + j], d3);
         }
+        own = nm;
       }
     }
     cm2_stream_end(T0); cm2_stream_end(T1); cm2_stream_end(T2);

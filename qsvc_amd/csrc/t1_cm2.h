@@ -346,6 +346,123 @@ T1HD void cm2_emit3(Cm2Out3& O, const Cm2Ctx& cx, const uint8_t* signlut, const 
   }
 }
 
+// The same with a sliding window of SPREAD neighbourhood columns (a lane walks consecutive columns of one stripe): only the new
+// right-hand column is taken apart and spread per step, and the merged table zcx ([0..511] zero coding by neighbourhood,
+// [512..1023] refinement: bit 4 = "refined before", the other neighbourhood bits = significant neighbours) gives any row's
+// context with one read.
+struct Cm2Win {
+  uint32_t w;               // the centre column's own word
+  uint32_t AB[3], P[3], Q[3], DL[3], DB[3], X[3];  // per column x-1, x, x+1: sp(s0|s1), sp(s0)|sp(s1)&1, sp(s0)|sp(s1) rows -1..3,
+                                                   // sp(s2) rows -1..3, sp(s2)&1, sp(chi)
+  uint32_t B1, D1;          // sp(s1), sp(s2) of the centre column (its own rows' S1 / S2)
+  uint32_t Bn, Dn;          // the same of column x+1 (becomes the centre at the next step)
+};
+T1HD void cm2_win_push(Cm2Win& c, const uint32_t* sp, uint32_t own, uint32_t u2, uint32_t m2, uint32_t d2) {  // own = the word of the new centre
+  for (int k = 0; k < 2; k++) { c.AB[k] = c.AB[k + 1]; c.P[k] = c.P[k + 1]; c.Q[k] = c.Q[k + 1]; c.DL[k] = c.DL[k + 1]; c.DB[k] = c.DB[k + 1]; c.X[k] = c.X[k + 1]; }
+  c.B1 = c.Bn; c.D1 = c.Dn;
+  const uint32_t A = sp[cm2_six(u2, m2, d2, CW_SIG0)], B = sp[cm2_six(u2, m2, d2, CW_S1)], D = sp[cm2_six(u2, m2, d2, CW_S2)];
+  c.AB[2] = A | B; c.P[2] = A | (B & 1); c.Q[2] = A | (B & 0x7FFF); c.DL[2] = D & 0x7FFF; c.DB[2] = D & 1;
+  c.X[2] = sp[cm2_six(u2, m2, d2, CW_NEG)];
+  c.Bn = B; c.Dn = D;
+  c.w = own;
+}
+T1HD void cm2_emit3w(Cm2Out3& O, const uint8_t* zcx, const uint8_t* signlut, const Cm2Win& c) {
+  const uint32_t w = c.w;
+  const uint32_t val4 = (w >> CW_VAL) & 0xF;
+  const uint32_t bit4 = (w >> CW_BIT) & 0xF, M4 = (w >> CW_M) & val4, sig04 = (w >> CW_SIG0) & val4;
+  const uint32_t mu4 = (w >> CW_MU) & 0xF, neg4 = (w >> CW_NEG) & 0xF;
+  const uint32_t C4 = val4 & ~sig04 & ~M4;
+  const uint32_t S14 = M4 & bit4, S24 = C4 & bit4;
+  const uint32_t fref = c.AB[0] | c.AB[1] << 1 | c.AB[2] << 2;
+  const uint32_t f0 = c.Q[0] | c.P[1] << 1 | c.P[2] << 2;
+  const uint32_t f2 = fref | c.DL[0] | c.DB[1] << 1 | c.DB[2] << 2;
+  const uint32_t fchi = c.X[0] | c.X[1] << 1 | c.X[2] << 2;
+  const uint32_t G1 = (c.B1 & 0x1248) << 1, G2 = (c.D1 & 0x1248) << 1;
+  const uint32_t rl = (val4 == 0xF && f2 == 0 && M4 == 0) ? ~0u : 0u;
+  const uint32_t lowest = bit4 & (0u - bit4);
+  const uint32_t skipA4 = rl & (2 * lowest - 1) & 0xF, skipB4 = rl & (lowest - 1) & 0xF;
+  const uint32_t fk = (lowest >> 1) - (lowest >> 3);
+  const uint32_t hdr3 = (uint32_t)(T1_CTX_RUN | 32) | (uint32_t)(T1_CTX_UNI | ((fk >> 1) << 5)) << 8 | (uint32_t)(T1_CTX_UNI | ((fk & 1) << 5)) << 16;
+  O.hdr.a = rl & (bit4 ? hdr3 : (uint32_t)T1_CTX_RUN);
+  O.hdr.n = (int)(rl & (bit4 ? 3u : 1u));
+  const uint32_t EA0 = M4, EB0 = S14, EA1 = sig04, EA2 = C4 & ~skipA4, EB2 = S24 & ~skipB4;
+  uint32_t x0[4], x1[4], x2[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t mM = cm2_m(M4, k), m1 = cm2_m(sig04, k), mbit = cm2_m(bit4, k);
+    const uint32_t cmask = (1u << (3 * k + 2)) - 1;
+    const uint32_t fz = cm2_pick(m1, fref, cm2_pick(mM, f0 | (G1 & cmask), f2 | (G2 & cmask)));
+    const uint32_t nb = (fz >> (3 * k)) & 0x1FF;
+    const uint32_t li = (nb & 0x1EF) | (m1 & (0x200u | (cm2_m(mu4, k) & 0x10u)));
+    const uint32_t A = (uint32_t)zcx[li] | (mbit & 32);
+    const uint32_t idx = ((nb & 0xAA) >> 1) | ((fchi >> (3 * k)) & 0xAA);
+    const uint32_t Bv = (uint32_t)signlut[idx] ^ (cm2_m(neg4, k) & 32);
+    const uint32_t ab = A | Bv << 8;
+    x1[k] = A & m1;
+    x0[k] = ab & mM & (0xFFu | (mM & mbit & 0xFF00u));
+    const uint32_t ea2 = cm2_m(EA2, k), eb2 = cm2_m(EB2, k);
+    x2[k] = cm2_pick(ea2, ab & (0xFFu | (eb2 & 0xFF00u)), Bv & eb2);
+  }
+  auto cnt = [](uint32_t EA, uint32_t EB, int k) { return (int)(((EA >> k) & 1) + ((EB >> k) & 1)); };
+  {
+    const int c0 = (int)(EA1 & 1), c1 = c0 + (int)((EA1 >> 1) & 1), c2 = c1 + (int)((EA1 >> 2) & 1);
+    O.p1.a = x1[0] | x1[1] << (8 * c0) | x1[2] << (8 * c1) | x1[3] << (8 * c2);
+    O.p1.n = c2 + (int)((EA1 >> 3) & 1);
+  }
+  {
+    const int c0 = cnt(EA0, EB0, 0), c1 = cnt(EA0, EB0, 1), c2 = cnt(EA0, EB0, 2), c3 = cnt(EA0, EB0, 3);
+    const uint32_t lo = x0[0] | x0[1] << (8 * c0), hi = x0[2] | x0[3] << (8 * c2);
+    O.p0.a = (uint64_t)lo | (uint64_t)hi << (8 * (c0 + c1));
+    O.p0.n = c0 + c1 + c2 + c3;
+  }
+  {
+    const int c0 = cnt(EA2, EB2, 0), c1 = cnt(EA2, EB2, 1), c2 = cnt(EA2, EB2, 2), c3 = cnt(EA2, EB2, 3);
+    const uint32_t lo = x2[0] | x2[1] << (8 * c0), hi = x2[2] | x2[3] << (8 * c2);
+    O.p2.a = (uint64_t)lo | (uint64_t)hi << (8 * (c0 + c1));
+    O.p2.n = c0 + c1 + c2 + c3;
+  }
+}
+// the distortion sums of one column (lossy layers only), by pass
+T1HD void cm2_dist3(const Cm2Ctx& cx, uint32_t w, uint64_t mag, long long* dist) {
+  const uint32_t val4 = (w >> CW_VAL) & 0xF, bit4 = (w >> CW_BIT) & 0xF, M4 = (w >> CW_M) & val4, sig04 = (w >> CW_SIG0) & val4;
+  const uint32_t S14 = M4 & bit4, S24 = val4 & ~sig04 & ~M4 & bit4;
+  long long d0 = 0, d1 = 0, d2 = 0;
+  for (int k = 0; k < 4; k++) {
+    const int m = t1_mag(mag, k);
+    if ((sig04 >> k) & 1) d1 += t1_dist_ref(m, cx.p);
+    else if ((S14 >> k) & 1) d0 += t1_dist_sig(m, cx.p);
+    else if ((S24 >> k) & 1) d2 += t1_dist_sig(m, cx.p);
+  }
+  dist[0] += d0; dist[1] += d1; dist[2] += d2;
+}
+// decisions per pass of the centre column from the raw words of its 3 x 3 neighbourhood (u/m/d = stripes s-1, s, s+1; index 0..2 =
+// columns x-1, x, x+1): what cm2_counts derives from the gathered vectors
+T1HD void cm2_counts_w(const uint32_t u[3], const uint32_t m[3], const uint32_t d[3], int n[3]) {
+  const uint32_t w = m[1];
+  const uint32_t val4 = (w >> CW_VAL) & 0xF;
+  const uint32_t bit4 = (w >> CW_BIT) & 0xF, M4 = (w >> CW_M) & val4, sig04 = (w >> CW_SIG0) & val4;
+  const uint32_t C4 = val4 & ~sig04 & ~M4, S14 = M4 & bit4, S24 = C4 & bit4;
+  auto pop = [](uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)__popc(v);
+#else
+    return cm2_popc4(v);
+#endif
+  };
+  n[0] = pop(M4) + pop(S14);
+  n[1] = pop(sig04);
+  // significant neighbours as the clean-up pass sees them at the column's first row (run-length test): sig0 | S1 everywhere,
+  // S2 of the left column's rows -1..3 and of the row above in the centre and right columns
+  const uint32_t ROW3 = 8u, ROW0 = 1u;  // within a 4-bit field
+  const uint32_t SS = (0xFu << CW_SIG0) | (0xFu << CW_S1), S2F = 0xFu << CW_S2;
+  const uint32_t up3 = (ROW3 << CW_SIG0) | (ROW3 << CW_S1) | (ROW3 << CW_S2), dn0 = (ROW0 << CW_SIG0) | (ROW0 << CW_S1);
+  const uint32_t any = (u[0] & up3) | (m[0] & (SS | S2F)) | (d[0] & dn0) | (u[1] & up3) | (m[1] & SS) | (d[1] & dn0) | (u[2] & up3) | (m[2] & SS) | (d[2] & dn0);
+  const uint32_t lowest = bit4 & (0u - bit4);
+  const bool rl = val4 == 0xF && any == 0 && M4 == 0;
+  const uint32_t skipA4 = rl ? ((2 * lowest - 1) & 0xF) : 0u, skipB4 = rl ? ((lowest - 1) & 0xF) : 0u;
+  n[2] = pop(C4 & ~skipA4) + pop(S24 & ~skipB4) + (rl ? (bit4 ? 3 : 1) : 0);
+}
+
 // A lane's position in one pass's byte stream: whole words are OR-ed into a zeroed buffer (the first and the last word of a
 // lane's range are shared with its neighbours; a word may be written before it is complete and again when it is).
 struct Cm2Stream {

@@ -398,6 +398,33 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
           cm2_stream_put8(st[0], O.p0); cm2_stream_put4(st[1], O.p1); cm2_stream_put4(st[2], O.hdr); cm2_stream_put8(st[2], O.p2);
         }
       for (int q = 0; q < 3; q++) cm2_stream_end(st[q]);
+      {  // the kernel's form: 64 "lanes" x 16 consecutive columns through the sliding window of spread columns, counts from raw words
+        static uint8_t zcx[1024];
+        for (int i = 0; i < 512; i++) zcx[i] = cx.zc[i];
+        for (int i = 512; i < 1024; i++) zcx[i] = (uint8_t)(((i >> 4) & 1) ? 16 : ((i & 0x1EF) ? 15 : 14));
+        std::vector<uint8_t> w3[3];
+        int nsum[3] = {0, 0, 0};
+        for (int th = 0; th < 64; th++) {
+          const int ls = th >> 2, lx0 = (th & 3) * 16;
+          if (ls >= nstr || lx0 >= w) continue;
+          Cm2Win win; memset(&win, 0, sizeof win);
+          cm2_win_push(win, sp, 0, cw[ls][lx0], cw[ls + 1][lx0], cw[ls + 2][lx0]);
+          cm2_win_push(win, sp, 0, cw[ls][lx0 + 1], cw[ls + 1][lx0 + 1], cw[ls + 2][lx0 + 1]);
+          for (int j = 0; j < 16; j++) {
+            cm2_win_push(win, sp, cw[ls + 1][lx0 + j + 1], cw[ls][lx0 + j + 2], cw[ls + 1][lx0 + j + 2], cw[ls + 2][lx0 + j + 2]);
+            if (lx0 + j >= w) continue;
+            Cm2Out3 O;
+            cm2_emit3w(O, zcx, signlut, win);
+            auto app = [&](std::vector<uint8_t>& v, const Cm2Bytes& b) { for (int i = 0; i < b.n; i++) v.push_back((uint8_t)(b.a >> (8 * i))); if (b.n < 8 && (b.a >> (8 * b.n))) v.push_back(0xEE); };
+            app(w3[0], O.p0); app(w3[1], O.p1); app(w3[2], O.hdr); app(w3[2], O.p2);
+            int n3[3];
+            cm2_counts_w(&cw[ls][lx0 + j], &cw[ls + 1][lx0 + j], &cw[ls + 2][lx0 + j], n3);
+            if (n3[0] != O.p0.n || n3[1] != O.p1.n || n3[2] != O.hdr.n + O.p2.n) return -9;
+            for (int q = 0; q < 3; q++) nsum[q] += n3[q];
+          }
+        }
+        for (int pass = 0; pass < 3; pass++) if (w3[pass] != e3[pass]) return -10;
+      }
       for (int pass = 0; pass < 3; pass++) {
         const uint8_t* seg = segs.data() + (size_t)p * T1_SEG_BYTES + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
         if (first && pass < 2) { if (!e3[pass].empty()) return -6; continue; }
