@@ -295,9 +295,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # code-blocks per MQ wave: the library's default (64; the coder has no divergent path, so a wave costs the same with 16 or 64
-    # lanes in work and the widest form is best for one sequence and for many).  QSVC_MQ_LANES overrides it.
-    mq_lanes = os.environ.get("QSVC_MQ_LANES", "64")
+    # the MQ coder kernel in work: the library's default is the two-wave pipeline (64 code-blocks per wave pair); QSVC_MQ_PIPE=0
+    # selects the one-wave form (QSVC_MQ_LANES blocks per wave)
+    mq_symbol = "k_t1_mq_pipe<64>" if os.environ.get("QSVC_MQ_PIPE", "1") != "0" else "k_t1_mq<%s>" % os.environ.get("QSVC_MQ_LANES", "64")
     run_steps(args.warmup)
     for e in engs:
         e.set_profiling(True)
@@ -373,11 +373,10 @@ def main():
 
         dom = "j2k_t1_mq"
         a = alg[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e9 if dom in per and per[dom]["ms_per_step"] > 0 else 0.0
-        roof = {"kernel": dom, "kernel_symbol": f"k_t1_mq<{mq_lanes}>", "bound": "hbm", "achieved": round(a, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"kernel": dom, "kernel_symbol": mq_symbol, "bound": "hbm", "achieved": round(a, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(a / HBM_PEAK_GBS, 6),
-                "traffic": traffic_of([("k_t1_mq<%s>" % mq_lanes, 1)]) or traffic_of([("k_t1_mq<16>", 1)]),
-                "traffic_source": "profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE per launch, separate passes, one sequence in flight: the "
-                                  "kernel there is k_t1_mq<16>, the same loads and stores as the 64-lane form)",
+                "traffic": traffic_of([(mq_symbol, 1)]),
+                "traffic_source": "profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE per launch, separate passes, one sequence in flight)",
                 "launch_ms": per.get(dom, {}).get("ms_per_step"), "algorithmic_bytes_per_launch": int(alg[dom]),
                 "algorithmic_bytes": "SURVEY.md 8d: 15 657 code-blocks x 8 KB (int16 coefficients) + emitted code bytes, one launch per step",
                 "note": "the launch with the largest share of the step; EBCOT Tier-1 is serial-dependency bound, not HBM bound (SURVEY.md H4/8d): "

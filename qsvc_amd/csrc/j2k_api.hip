@@ -540,7 +540,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     pf.begin(c, "j2k_t1_mq");
     launch_t1_mq(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p, (const int*)S.order_d.p, nslots,
                  (const uint8_t*)S.segs_d.p, (const int*)S.cnt_d.p, (const long long*)S.dist_d.p, (uint8_t*)S.outbuf.p, J2K_OUTCAP,
-                 (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0);
+                 (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, (int*)S.err_d.p);
     pf.end(c);
   }
   S.res.resize(ncb);
@@ -555,6 +555,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   }
   HIPCHK(c, hipStreamSynchronize(c->st));
   HIPCHK(c, hipGetLastError());
+  if (err & 2) return c->fail(QSVC_ERR_HIP, "internal: the MQ coder's wave pair lost step (a wait gave up)");
   if (err) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
   // The code bytes of every block (all of them: what a layer leaves out is decided on the host meanwhile) are gathered in block
   // order and start their way to the host; rate allocation and the code-streams' lengths are worked out under that copy.

@@ -47,7 +47,7 @@ void launch_level_shift(hipStream_t st, const PlaneDesc* d_planes, int nplanes, 
 void launch_t1_nbps(hipStream_t st, const CbDesc* cbs, int ncb, int* nbps, int* err);
 void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int nslots,
                   const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf, int outcap, CbOut* res, int* pass_len,
-                  long long* pass_dist, int want_dist);
+                  long long* pass_dist, int want_dist, int* err);
 void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef,
                         unsigned long long* mags, int* nbps, int* err, bool reversible);
 void launch_t1_cm2(hipStream_t st, const int* jobs, int njobs, const CbDesc* cbs, const int* nbps, const unsigned long long* mags,

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
     uint4 nxt = pad;
     if (more || (q < npass && q2 < npass)) nxt = *pa;  // next 16 decisions in flight while these are coded
     mq2_chunk16(t, cur.x, cur.y, cur.z, cur.w);
-    if (t.sp - t.stg >= T1_STAGE_FLUSH) mq2_stage_flush(t);
+    if (__any(t.sp - t.stg >= T1_STAGE_FLUSH)) mq2_stage_flush(t);  // all lanes at once: the wave pays for a flush whoever needs it
     cur = nxt;
     i += 16;
     if (q < npass && i >= n) { t.nsym += (uint32_t)n; enter_next(); }
@@ -139,9 +139,154 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
   }
 }
 
+// The coder as a two-wave pipeline (mq2_front16 / mq2_back16, t1_core.h): wave 0 of the workgroup walks the decisions, keeps the
+// contexts and the interval register and leaves a record per decision in an LDS ring; wave 1 follows one or more chunks behind
+// with the code register and the bytes.  Each half is about half a decision long, and a single wave issues one instruction
+// per ~4.3 cycles whatever it does, so the pair codes a block's chain in a little over half the time of one wave.
+// Both waves derive the same chunk schedule from the block's pass table (chunk c of lane l = the c-th 16-decision piece of its
+// passes, the idle context after its last), so the ring needs two counters only: chunks produced, chunks consumed.
+#define MQ_RING 4
+template <int L>
+__global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff, const int* order, int nslots,
+                                                       const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf, int outcap, CbOut* res,
+                                                       int* pass_len, long long* pass_dist, int* err) {
+  static_assert(L == 64, "one front wave and one back wave");
+  __shared__ uint32_t s_cx[21 * L];
+  __shared__ uint32_t s_stage[(T1_STAGE / 4) * L];
+  __shared__ uint16_t s_cnt[MQ_CNT_STRIDE * L];
+  __shared__ uint32_t s_mq[64];
+  __shared__ uint64_t s_mq2[94];
+  __shared__ uint32_t s_ring[MQ_RING][16][L];
+  __shared__ volatile int s_sync[4];  // [0] chunks produced, [1] chunks consumed, [2] a wait gave up
+  const int wv = threadIdx.x / L, lane = threadIdx.x % L;
+  const int slot = blockIdx.x * L + lane, b = slot < nslots ? order[slot] : ncb;
+  for (int i = threadIdx.x; i < 47; i += 2 * L) s_mq[i] = c_mqtab[i];
+  for (int i = threadIdx.x; i < 94; i += 2 * L) s_mq2[i] = mq2_pair(c_mqtab, i);
+  if (threadIdx.x < 4) s_sync[threadIdx.x] = 0;
+  T1Lane t;
+  t.cx = s_cx + 21 * lane; t.cs = 1; t.mqtab = s_mq; t.mq2 = s_mq2; t.zclut = nullptr;
+  t.stg = (uint8_t*)(s_stage + (T1_STAGE / 4) * lane);
+  t.w = t.h = t.orient = 0; t.nbps = 0; t.out = outbuf; t.cap = 0;
+  size_t job0 = 0;
+  if (b < ncb) { t.nbps = nbps_in[b] > 15 ? 15 : nbps_in[b]; t.out = outbuf + (size_t)b * outcap; t.cap = outcap; job0 = (size_t)joboff[b]; }
+  const int bb = b < ncb ? b : 0;
+  int* pl = pass_len + (size_t)bb * T1_MAXPASS;
+  long long* pd = pass_dist ? pass_dist + (size_t)bb * T1_MAXPASS : nullptr;
+  const int nbps = t.nbps, npass = nbps ? 3 * nbps - 2 : 0;
+  auto plane_of = [&](int q) { return q ? nbps - 2 - (((q - 1) * 43) >> 7) : nbps - 1; };
+  auto kind_of = [&](int q) { return q ? (q - 1) - 3 * (((q - 1) * 43) >> 7) : 2; };
+  uint16_t* mycnt = s_cnt + MQ_CNT_STRIDE * lane;
+  if (wv == 0)
+    for (int q = 0; q < npass; q++) {
+      const size_t e = (job0 + plane_of(q)) * 3 + kind_of(q);
+      mycnt[q] = (uint16_t)cnt[e];
+      if (pd) pd[q] = dist[e];
+    }
+  __syncthreads();
+  // this lane's chunks and the wave's: the same in both waves
+  int my_chunks = 0;
+  for (int q = 0; q < npass; q++) my_chunks += (mycnt[q] + 15) >> 4;
+  int nchunks = my_chunks;
+  for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nchunks, o, 64); nchunks = v > nchunks ? v : nchunks; }
+  nchunks = __builtin_amdgcn_readfirstlane(nchunks);
+  int seen = 0;  // the partner's counter as last read (a wave waits on one counter only): it is re-read only when that is not enough
+  auto wait_for = [&](int which, int at_least) {  // bounded: a lost update must not hang the GPU
+    if (seen >= at_least) return;
+    seen = s_sync[which];
+    for (int spin = 0; seen < at_least && !s_sync[2]; spin++) {
+      __builtin_amdgcn_s_sleep(1);
+      seen = s_sync[which];
+      if (spin > (1 << 24)) { s_sync[2] = 1; atomicOr(err, 2); }
+    }
+  };
+  // (q, n): the pass in work; i: decisions of it already taken; q2 / n2: the next pass with decisions
+  int q = -1, n = 0, i = 0, q2 = 0, n2 = 0;
+  auto look_ahead = [&]() {
+    q2 = q + 1; n2 = 0;
+    while (q2 < npass && (n2 = mycnt[q2]) == 0) q2++;
+  };
+  if (wv == 0) {  // ---- front
+    t.A = 0x8000;
+    for (int c = 0; c < 19; c++) t.cx[c] = mq2_word(t.mqtab, 0, 0);
+    t.cx[0] = mq2_word(t.mqtab, 4, 0); t.cx[T1_CTX_RUN] = mq2_word(t.mqtab, 3, 0); t.cx[T1_CTX_UNI] = mq2_word(t.mqtab, 46, 0);
+    t.cx[T1_CTX_PAD] = 0;
+    auto seg_of = [&](int qq) {
+      const int k = kind_of(qq);
+      return (const uint4*)(segs + (job0 + plane_of(qq)) * T1_SEG_BYTES + (k == 0 ? 0 : (k == 1 ? T1_SEG1 : T1_SEG2)));
+    };
+    // the decisions are fetched three chunks ahead of the coder: with half a decision per wave a chunk lasts less than a load from HBM
+    const uint4* sg = nullptr;
+    look_ahead();
+    q = q2; n = n2; sg = q < npass ? seg_of(q) : nullptr;
+    const uint4 pad = make_uint4(T1_PAD4, T1_PAD4, T1_PAD4, T1_PAD4);
+    auto fetch = [&]() {
+      uint4 v = pad;
+      if (q < npass) {
+        v = sg[i >> 4];
+        i += 16;
+        if (i >= n) { look_ahead(); q = q2; n = n2; i = 0; sg = q < npass ? seg_of(q) : nullptr; }
+      }
+      return v;
+    };
+    uint4 d0 = fetch(), d1 = fetch(), d2 = fetch();
+    for (int c = 0; c < nchunks; c++) {
+      const uint4 cur = d0;
+      d0 = d1; d1 = d2; d2 = fetch();
+      wait_for(1, c - MQ_RING + 1);  // the ring slot is free again
+      asm volatile("" ::: "memory");
+      mq2_front16(t, cur.x, cur.y, cur.z, cur.w, &s_ring[c % MQ_RING][0][lane], L);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the records are in LDS (only LDS: the fetches stay in flight)
+      if (lane == 0) s_sync[0] = c + 1;
+    }
+    t.cx[20] = t.A;  // FLUSH (the back's) needs the final interval
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) s_sync[3] = 1;
+    return;
+  }
+  // ---- back
+  t.C = 0; t.CT = 12; t.B = 0; t.n = 0; t.ob = 0; t.nsym = 0; t.sp = t.stg; t.nfl = 0; t.A = 0x8000;
+  auto enter_next = [&]() {
+    const int c4 = mq2_count(t) + 4;
+    for (int k = q < 0 ? 0 : q; k < q2; k++) pl[k] = c4;
+    q = q2; n = n2; i = 0;
+    look_ahead();
+  };
+  look_ahead();
+  enter_next();
+  for (int c = 0; c < nchunks; c++) {
+    wait_for(0, c + 1);
+    asm volatile("" ::: "memory");
+    mq2_back_chunk(t, &s_ring[c % MQ_RING][0][lane], L);
+    asm volatile("" ::: "memory");  // (LDS runs a wave's accesses in order: the records were read before this store lands)
+    if (lane == 0) s_sync[1] = c + 1;
+    if (__any(t.sp - t.stg >= T1_STAGE_FLUSH)) mq2_stage_flush(t);  // all lanes at once: the wave pays for a flush whoever needs it
+    i += 16;
+    if (q < npass && i >= n) { t.nsym += (uint32_t)n; enter_next(); }
+  }
+  seen = 0;
+  wait_for(3, 1);
+  asm volatile("" ::: "memory");
+  t.A = t.cx[20];
+  T1Result r;
+  r.pass_len = pl; r.pass_dist = pd;
+  t1_lane_finish<true>(t, npass, r);
+  if (b < ncb) {
+    CbOut o;
+    o.len = r.len; o.npasses = r.npasses; o.nbps = r.nbps; o.overflow = r.overflow; o.nsym = r.nsym;
+    res[b] = o;
+  }
+}
+
 void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int nslots,
                   const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf, int outcap, CbOut* res, int* pass_len,
-                  long long* pass_dist, int want_dist) {
+                  long long* pass_dist, int want_dist, int* err) {
+  // QSVC_MQ_PIPE (read at every launch): 1 = the two-wave pipeline (shortest chain: one sequence alone), 0 = one wave per 64 blocks
+  const bool pipe = [] { const char* e = getenv("QSVC_MQ_PIPE"); return e ? atoi(e) != 0 : true; }();
+  if (pipe) {
+    hipLaunchKernelGGL(k_t1_mq_pipe<64>, dim3((nslots + 63) / 64), dim3(128), 0, st, cbs, ncb, nbps, joboff, order, nslots, segs, cnt, dist, outbuf, outcap, res,
+                       pass_len, want_dist ? pass_dist : nullptr, err);
+    return;
+  }
   // lanes (code-blocks) per MQ wave: the coder is straight-line (no divergent path in a decision), so a wave costs the same
   // whatever the number of lanes in work; 64 is best for one sequence (245 waves, one per CU) and for many.  QSVC_MQ_LANES
   // (4, 8, 16, 32; read at every launch) is kept for experiments.

@@ -359,6 +359,92 @@ T1HD void mq2_chunk16(T1Lane& t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t
   t.A = A;
 }
 
+// The same decision cut in two for a pair of waves (k_t1_mq_pipe): the FRONT keeps the contexts and the interval register A and
+// leaves one record per decision -- what is added to the code register (Qe or 0) | the renormalisation shift << 16 -- and the
+// BACK keeps the code register, CT, the byte register and the output.  Nothing flows from the back to the front (T.800 C.2:
+// A and the context states never depend on C), so the two halves run as a pipeline, each about half a decision long.
+// rec: this lane's 16 record slots of the chunk, rs words apart.
+T1HD void mq2_front16(T1Lane& t, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t* rec, int rs) {
+  const uint32_t w[4] = {w0, w1, w2, w3};
+  uint32_t A = t.A;
+  uint32_t e = t.cx[(int)(w0 & 31) * t.cs];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint32_t wj = w[j >> 2];
+    const int cx = (int)((wj >> (8 * (j & 3))) & 31);
+    uint32_t epre = 0;
+    int cx1 = -1;
+    if (j < 15) { cx1 = (int)((w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 31); epre = t.cx[cx1 * t.cs]; }
+    const uint64_t succ = *(const uint64_t*)((const char*)t.mq2 + ((e >> 16) & 0x7FFF));
+    const uint32_t qe = e & 0xFFFF;
+    const uint32_t x = (wj << (26 - 8 * (j & 3))) ^ e;
+    A -= qe;
+    const uint32_t seta = mq2_neg_mask((int32_t)((A - qe) ^ x));
+    const uint32_t add = qe & ~seta;
+    A = mq2_sel(seta, qe, A);
+    const int sh = mq2_clz(A) - 16;
+    const uint32_t noren = mq2_neg_mask((int32_t)(A << 16));
+    A <<= sh;
+    rec[j * rs] = add | (uint32_t)sh << 16;
+    const uint32_t lps = mq2_neg_mask((int32_t)x);
+    const uint32_t en = mq2_sel(noren, e, mq2_sel(lps, (uint32_t)(succ >> 32), (uint32_t)succ));
+    t.cx[cx * t.cs] = en;
+    e = cx1 == cx ? en : epre;
+  }
+  t.A = A;
+}
+// The back half runs its 16 decisions WITHOUT looking for the rare second byte of one renormalisation (sh up to 15 against at most
+// one BYTEOUT per decision here): it only remembers whether that happened (the smallest CT seen, <= 0), and the caller then
+// restores the lane's four registers and codes the chunk again with the flow chart's loop (mq2_back16_exact) -- the back keeps
+// no other state, and the records are still in the ring.  Measured on config 3: 4 decisions in a million.
+T1HD int mq2_back16(T1Lane& t, const uint32_t* rec, int rs) {
+  uint32_t r[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) r[j] = rec[j * rs];
+  int lowest = 1;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint32_t Cin = t.C + (r[j] & 0xFFFF);
+    const int sh = (int)(r[j] >> 16);
+    const int d = t.CT - sh;
+    const uint32_t take = mq2_neg_mask(d - 1);
+    const int s1 = sh < t.CT ? sh : t.CT;
+    uint32_t C = Cin << s1;
+    const uint32_t bn = (uint32_t)t.B + (C >> 27);
+    const uint32_t em = bn < 255u ? bn : 255u;
+    *t.sp = (uint8_t)em;
+    C += ((uint32_t)t.B - em) << 27;
+    const int bo = (int)((bn + 1 + 19 * 256) >> 8);
+    const uint32_t Bn = (C >> bo) & 0xFFu, Cm = C & ((1u << bo) - 1u);
+    t.B = (int)mq2_sel(take, Bn, (uint32_t)t.B);
+    C = mq2_sel(take, Cm, C);
+    t.sp -= (int32_t)take;
+    const int rest = (sh - s1) & 15;   // (& 15: a lane that has already gone wrong must still shift by less than 32)
+    const int ctn = d + (int)((uint32_t)(27 - bo) & take);
+    t.C = C << rest;
+    t.CT = ctn;
+    lowest = ctn < lowest ? ctn : lowest;
+  }
+  return lowest;
+}
+T1HD void mq2_back16_exact(T1Lane& t, const uint32_t* rec, int rs) {  // RENORME (T.800 C.2.6) bit count by bit count
+  for (int j = 0; j < 16; j++) {
+    const uint32_t r = rec[j * rs];
+    t.C += r & 0xFFFF;
+    int sh = (int)(r >> 16);
+    while (sh >= t.CT) { t.C <<= t.CT; sh -= t.CT; mq2_byteout(t); }
+    t.C <<= sh; t.CT -= sh;
+  }
+}
+// one chunk of the back half, exact in every case
+T1HD void mq2_back_chunk(T1Lane& t, const uint32_t* rec, int rs) {
+  const uint32_t C0 = t.C; const int CT0 = t.CT, B0 = t.B; uint8_t* const sp0 = t.sp;
+  const int lowest = mq2_back16(t, rec, rs);
+  if (__builtin_expect(t1_any_lane(lowest <= 0), 0)) {
+    if (lowest <= 0) { t.C = C0; t.CT = CT0; t.B = B0; t.sp = sp0; mq2_back16_exact(t, rec, rs); }
+  }
+}
+
 T1HD int t1_mag(uint64_t m, int k) { return (int)((m >> (16 * k)) & 0x7FFF); }
 T1HD int t1_neg(uint64_t m, int k) { return (int)((m >> (16 * k + 15)) & 1); }
 
@@ -634,7 +720,7 @@ T1HD void t1_cm_plane(Store& S, const uint8_t* zclut, uint8_t* seg, int p, int w
 // MQ coding of one block from its decision segments.  Seg(p) -> base of plane p's segments,
 // Cnt(p, pass) -> decisions in that pass.  Sequential per lane; different lanes run different lengths.
 template <class SegF, class CntF, class DistF>
-T1HD void t1_mq_block(T1Lane& t, const SegF& Seg, const CntF& Cnt, const DistF& Dist, T1Result& res) {
+T1HD void t1_mq_block(T1Lane& t, const SegF& Seg, const CntF& Cnt, const DistF& Dist, T1Result& res, bool front_back = false) {
   uint32_t stage[T1_STAGE / 4];
   t.stg = (uint8_t*)stage;
   mq2_lane_init(t);  // t.cx: 20 words
@@ -646,7 +732,8 @@ T1HD void t1_mq_block(T1Lane& t, const SegF& Seg, const CntF& Cnt, const DistF& 
       for (int i = 0; i < n; i += 16) {
         uint32_t w[4] = {0, 0, 0, 0};
         for (int k = 0; k < 16; k++) w[k >> 2] |= (i + k < n ? (uint32_t)sg[i + k] : T1_PAD) << (8 * (k & 3));
-        mq2_chunk16(t, w[0], w[1], w[2], w[3]);
+        if (front_back) { uint32_t rec[16]; mq2_front16(t, w[0], w[1], w[2], w[3], rec, 1); mq2_back_chunk(t, rec, 1); }
+        else mq2_chunk16(t, w[0], w[1], w[2], w[3]);
         if (t.sp - t.stg >= T1_STAGE_FLUSH) mq2_stage_flush(t);
       }
       t.nsym += (uint32_t)n;

@@ -448,7 +448,7 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
   auto Seg = [&](int p) { return (const uint8_t*)segs.data() + (size_t)p * T1_SEG_BYTES; };
   auto Cnt = [&](int p, int pass) { return cnt[p * 3 + pass]; };
   auto Dist = [&](int p, int pass) { return dist[p * 3 + pass]; };
-  t1_mq_block(t, Seg, Cnt, Dist, r);
+  t1_mq_block(t, Seg, Cnt, Dist, r, true);  // the two-wave form of the coder (front / back halves)
   if (r.overflow) return -2;
   memcpy(out, bufp + 1, r.len);
   *npasses = r.npasses; *nbps = r.nbps;

@@ -165,6 +165,28 @@ def test_plane_groups_do_not_change_the_streams(eng):
     assert runs[0].stdout == runs[1].stdout and runs[0].stdout.startswith("15 ")
 
 
+def test_both_mq_kernel_forms_give_the_same_streams(eng):
+    """The MQ coder runs as a two-wave pipeline (k_t1_mq_pipe, the default) or as one wave per 64 blocks (QSVC_MQ_PIPE=0, any
+    QSVC_MQ_LANES); the switches are read at every launch.  Same bytes, and equal to the restatement's."""
+    import os
+    from qsvc_amd import hip
+    y = _luma("pan_noise", 352, 288, 12)
+    prm = hip.j2k_params(reversible=True, levels=4)
+    want = J.encode_plane(y, reversible=True, levels=4)
+    saved = {k: os.environ.get(k) for k in ("QSVC_MQ_PIPE", "QSVC_MQ_LANES", "QSVC_MQ_SORT")}
+    try:
+        for env in ({}, {"QSVC_MQ_PIPE": "0"}, {"QSVC_MQ_PIPE": "0", "QSVC_MQ_LANES": "16"}, {"QSVC_MQ_SORT": "0"}):
+            for k in saved:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            assert eng.j2k_encode_plane(y, prm) == want, env
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
 def test_too_many_bitplanes_is_an_error_not_a_fault(eng):
     """A quantiser step so small that a subband needs more than its M_b (or more than 15) magnitude bit-planes must come back
     as QSVC_ERR_UNSUPPORTED before any Tier-1 kernel runs on the unclamped count (j2k_api.hip: err_d is read in the same sync
