@@ -238,18 +238,42 @@ struct T2Pool {
   }
 };
 
+// Page-locked host array (grow-only): the per-block results come back, and the job tables go up, by DMA without a staging copy.
+template <class T>
+struct Pinned {
+  T* p = nullptr; size_t cap = 0, n = 0;
+  bool resize(size_t k) {
+    if (k > cap) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr; cap = 0;
+      const size_t want = k + k / 4 + 64;
+      if (hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault) != hipSuccess) return false;
+      cap = want;
+    }
+    n = k;
+    return true;
+  }
+  T* data() { return p; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  size_t size() const { return n; }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; }
+};
+
 struct J2kState {
   T2Pool* pool = nullptr;
   DevBuf coefA, llA, llB, sbtab_d, planes_d, cbs_d, nbps_d, mags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
   DevBuf joboff_d, order_d, jobs_d, segs_d, cnt_d, dist_d;  // Tier-1: job list, decision segments
-  std::vector<int> h_nbps, h_joboff, h_order, h_jobs;
+  Pinned<int> h_nbps, h_joboff, h_jobs;
+  std::vector<int> h_order;
   std::vector<DwtSb> sbtab;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
   std::vector<PlaneDesc> planes;
   std::vector<CbDesc> cbs;
-  std::vector<CbOut> res;
-  std::vector<int> plen;
-  std::vector<long long> pdist;
+  Pinned<CbOut> res;
+  Pinned<int> plen;
+  Pinned<long long> pdist;
+  Pinned<int> h_err;
   std::vector<HostCb> hcb;
   uint64_t st_cb = 0, st_pass = 0, st_sym = 0;
 };
@@ -261,6 +285,7 @@ void j2k_release(qsvc_ctx* c) {
                    &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->jobs_d, &s->segs_d, &s->cnt_d, &s->dist_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
+  s->h_nbps.release(); s->h_joboff.release(); s->h_jobs.release(); s->res.release(); s->plen.release(); s->pdist.release(); s->h_err.release();
   delete s->pool;
   delete s;
   c->j2k = nullptr;
@@ -484,15 +509,16 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   }
   {
     // the per-block bit-plane counts decide the job list: one context-modelling wave per (block, bit-plane)
-    S.h_nbps.resize(ncb);
-    int perr = 0;
+    if (!S.h_nbps.resize(ncb) || !S.h_err.resize(2)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
+    int& perr = S.h_err[0];
+    perr = 0;
     HIPCHK(c, hipMemcpyAsync(S.h_nbps.data(), S.nbps_d.p, (size_t)ncb * 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(&perr, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     // a block with more bit-planes than its subband allows (or than the 15-bit magnitude format holds) must never reach
     // the context-modelling / MQ kernels: their job and pass tables are sized for nbps <= 15
     if (perr) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
-    S.h_joboff.resize(ncb);
+    if (!S.h_joboff.resize(ncb)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
     size_t njobs = 0;
     for (int b = 0; b < ncb; b++) { S.h_joboff[b] = (int)njobs; njobs += S.h_nbps[b] > 15 ? 15 : S.h_nbps[b]; }
     // MQ slot table: slot k of the MQ launch codes block order[k] (ncb = idle lane).  A wave runs until its longest block is
@@ -525,7 +551,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
     if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
     if (njobs) {  // job list: (block << 4 | plane) at joboff[block] + plane
-      S.h_jobs.resize(njobs);
+      if (!S.h_jobs.resize(njobs)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
       for (int b = 0; b < ncb; b++) {
         int nb = S.h_nbps[b] > 15 ? 15 : S.h_nbps[b];
         for (int p = 0; p < nb; p++) S.h_jobs[S.h_joboff[b] + p] = (b << 4) | p;
@@ -543,14 +569,14 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
                  (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, (int*)S.err_d.p);
     pf.end(c);
   }
-  S.res.resize(ncb);
-  int err = 0;
+  if (!S.res.resize(ncb) || !S.h_err.resize(2) || !S.plen.resize((size_t)ncb * T1_MAXPASS) || (want_dist && !S.pdist.resize((size_t)ncb * T1_MAXPASS)))
+    return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
+  int& err = S.h_err[1];
+  err = 0;
   HIPCHK(c, hipMemcpyAsync(S.res.data(), S.res_d.p, (size_t)ncb * sizeof(CbOut), hipMemcpyDeviceToHost, c->st));
   HIPCHK(c, hipMemcpyAsync(&err, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
-  S.plen.resize((size_t)ncb * T1_MAXPASS);
   HIPCHK(c, hipMemcpyAsync(S.plen.data(), S.plen_d.p, (size_t)ncb * T1_MAXPASS * 4, hipMemcpyDeviceToHost, c->st));
   if (want_dist) {
-    S.pdist.resize((size_t)ncb * T1_MAXPASS);
     HIPCHK(c, hipMemcpyAsync(S.pdist.data(), S.pdist_d.p, (size_t)ncb * T1_MAXPASS * 8, hipMemcpyDeviceToHost, c->st));
   }
   HIPCHK(c, hipStreamSynchronize(c->st));

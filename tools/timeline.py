@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Kernel timeline of ONE single-sequence encode from a rocprofv3 --kernel-trace csv:  timeline.py <kernel_trace.csv> [step]
+(steps are found by the first k_pyr_level<unsigned char> launch of each level-1 analysis)"""
+import csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+first = [i for i, r in enumerate(rows) if "k_pyr_level<unsigned char>" in r["Kernel_Name"]]
+steps = first[::3]
+st = int(sys.argv[2]) if len(sys.argv) > 2 else len(steps) - 2
+i0, i1 = steps[st], steps[st + 1]
+t0 = int(rows[i0]["Start_Timestamp"])
+prev_end = 0.0
+for r in rows[i0:i1]:
+    n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("qsvc::", "")
+    s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
+    print(f"{s:8.3f} -> {e:8.3f}  ({e - s:6.3f} ms, gap before {s - prev_end:6.3f})  {n[:60]}")
+    prev_end = max(prev_end, e)
+print("next step starts at %.3f" % ((int(rows[i1]["Start_Timestamp"]) - t0) / 1e6))
