@@ -31,3 +31,5 @@ ms = (time.perf_counter() - t0) / steps * 1e3
 tm = e.timings()
 print(os.environ.get("QSVC_HIP_LIB", "default"), "lanes", os.environ.get("QSVC_MQ_LANES", "64"),
       " ".join(f"{k} {tm[k][0] / steps:.3f}" for k in ("j2k_t1_cm", "j2k_t1_mq") if k in tm), f"encode {ms:.3f} ms", h.hexdigest()[:16], flush=True)
+if os.environ.get("MQ_TIME_ALL"):
+    print("  " + " ".join(f"{k}={v[0] / steps:.3f}" for k, v in tm.items()), "sum=%.3f" % (sum(v[0] for v in tm.values()) / steps), flush=True)
