@@ -497,7 +497,13 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
       for (int j = 0; j < 16; j++) {
         const uint32_t nm = s_cw[ls + 1][lx0 + j + 2];
         cm2_win_push(c, s_sp, own, s_cw[ls][lx0 + j + 2], nm, s_cw[ls + 2][lx0 + j + 2]);
-        if (lx0 + j < w) {
+        // In the upper bit-planes most columns are a run of four zeros without a significant neighbour: one RUN decision.  When
+        // that holds for the column in work of EVERY lane, the wave skips the general form.
+        const bool col_on = lx0 + j < w;
+        const bool plain = !col_on || cm2_plain_run(c);
+        if (!__any(!plain)) {
+          if (col_on) { Cm2Bytes run1; run1.a = T1_CTX_RUN; run1.n = 1; cm2_stream_put4(T2, run1); }
+        } else if (col_on) {
           Cm2Out3 O;
           cm2_emit3w(O, s_zc, s_sign, c);
           cm2_stream_put8(T0, O.p0); cm2_stream_put4(T1, O.p1); cm2_stream_put4(T2, O.hdr); cm2_stream_put8(T2, O.p2);

@@ -366,6 +366,12 @@ T1HD void cm2_win_push(Cm2Win& c, const uint32_t* sp, uint32_t own, uint32_t u2,
   c.Bn = B; c.Dn = D;
   c.w = own;
 }
+// the centre column is four insignificant zeros without a significant neighbour: its only decision is RUN = 0 (clean-up pass)
+T1HD bool cm2_plain_run(const Cm2Win& c) {
+  const uint32_t w = c.w;
+  const uint32_t f2 = c.AB[0] | c.AB[1] << 1 | c.AB[2] << 2 | c.DL[0] | c.DB[1] << 1 | c.DB[2] << 2;
+  return ((w >> CW_VAL) & 0xF) == 0xF && ((w >> CW_BIT) & 0xF) == 0 && f2 == 0;
+}
 T1HD void cm2_emit3w(Cm2Out3& O, const uint8_t* zcx, const uint8_t* signlut, const Cm2Win& c) {
   const uint32_t w = c.w;
   const uint32_t val4 = (w >> CW_VAL) & 0xF;
