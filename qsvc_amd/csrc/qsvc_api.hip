@@ -75,6 +75,7 @@ static void free_seq(qsvc_ctx* c) {
   for (auto& l : c->lv) {
     l.low.release(); l.high.release(); l.pred.release(); l.mv_raw.release(); l.mv_filt.release(); l.hist.release();
     l.low_n = l.high_n = l.pred_n = 0; l.mv_raw_n = l.mv_filt_n = 0; l.mv_bs = 0; l.types.clear();
+    l.types_d.release(); l.types_pin.release(); l.types_d_ok = false; l.mv_bound = -1;
     l.halo[0] = l.halo[1] = nullptr;
   }
 }
@@ -107,7 +108,7 @@ void qsvc_destroy(qsvc_ctx* c) {
   for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); }
   c->margin.release(); c->cup.release(); c->ovl[0].release(); c->ovl[1].release();
   if (c->comm) qsvc_comm_destroy(c);
-  c->scal.release(); c->tmp16[0].release(); c->tmp16[1].release();
+  c->scal.release(); c->tmp16[0].release(); c->tmp16[1].release(); c->hhist.release();
   j2k_release(c);
   j2k_decode_release(c);
   for (auto& s : c->segs) for (auto& p : s.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -180,6 +181,7 @@ int qsvc_put_motion(qsvc_ctx* c, int kind, int t, int nB, int bs, const int16_t*
   if (r) return r;
   (kind == QSVC_MOTION_RAW ? l.mv_raw_n : l.mv_filt_n) = nB;
   l.mv_bs = bs;
+  l.mv_bound = -1;
   HIPCHK(c, hipMemcpyAsync(b.p, mv, bytes, hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   return QSVC_OK;
@@ -202,6 +204,7 @@ int qsvc_get_motion(qsvc_ctx* c, int kind, int t, int b_pictures, int block_size
 int qsvc_put_frame_types(qsvc_ctx* c, int t, int nB, const char* types) {
   if (!c || !types || t < 1 || t > QSVC_MAX_T || nB < 0) return QSVC_ERR_INVALID;
   c->lv[t].types.assign(types, types + nB);
+  c->lv[t].types_d_ok = false;
   return QSVC_OK;
 }
 int qsvc_get_frame_types(qsvc_ctx* c, int t, int b_pictures, char* types) {
@@ -273,6 +276,7 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   size_t fld = (size_t)g.BY * g.BX, mvbytes = (size_t)g.nB * 4 * fld * sizeof(int16_t);
   if ((r = lv.mv_raw.ensure(c, mvbytes ? mvbytes : 16))) return r;
   lv.mv_raw_n = g.nB; lv.mv_bs = bs;
+  lv.mv_bound = (2 << L) - 1;  // one step of +-1 per pyramid level, doubled from level to level
   if (g.nB == 0) return QSVC_OK;
   const uint8_t* frames = (const uint8_t*)c->lv[t - 1].low.p;
   size_t N = (size_t)g.H * g.W;
@@ -378,11 +382,12 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   HIPCHK(c, hipMemcpyAsync(lv.mv_filt.p, lv.mv_raw.p, mvbytes, hipMemcpyDeviceToDevice, c->st));
   if (!always_B) {
     // host-side I/B rule (decorrelate.cpp:964-979) on the three device histograms
-    c->hhist.resize((size_t)g.nB * 3 * 256);
-    HIPCHK(c, hipMemcpyAsync(c->hhist.data(), lv.hist.p, c->hhist.size() * 4, hipMemcpyDeviceToHost, c->st));
+    const size_t hbytes = (size_t)g.nB * 3 * 256 * 4;
+    if (!c->hhist.ensure(hbytes)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%zu)", hbytes);
+    HIPCHK(c, hipMemcpyAsync(c->hhist.p, lv.hist.p, hbytes, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     for (int i = 0; i < g.nB; i++) {
-      const uint32_t* h = c->hhist.data() + (size_t)i * 3 * 256;
+      const uint32_t* h = (const uint32_t*)c->hhist.p + (size_t)i * 3 * 256;
       float predicted_entropy = entropy256(h), residue_entropy = entropy256(h + 256), motion_entropy = entropy256(h + 512);
       int predicted_size = (int)(predicted_entropy * (float)g.H * (float)g.W);
       int residue_size = (int)(residue_entropy * (float)g.H * (float)g.W);
@@ -394,6 +399,13 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
         HIPCHK(c, hipMemsetAsync((int16_t*)lv.mv_filt.p + (size_t)i * 4 * fld, 0, 4 * fld * sizeof(int16_t), c->st));
       }
     }
+  }
+  // frame_types_t on the device for `update` (page-locked source: nothing the caller can touch is read after this call returns)
+  lv.types_d_ok = false;
+  if (g.nB && lv.types_pin.ensure((size_t)g.nB) && lv.types_d.ensure(c, (size_t)g.nB + 16) == QSVC_OK) {
+    memcpy(lv.types_pin.p, lv.types.data(), (size_t)g.nB);
+    HIPCHK(c, hipMemcpyAsync(lv.types_d.p, lv.types_pin.p, (size_t)g.nB, hipMemcpyHostToDevice, c->st));
+    lv.types_d_ok = true;
   }
   HIPCHK(c, hipGetLastError());
   return QSVC_OK;
@@ -412,24 +424,31 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   if ((r = lv.low.ensure(c, (size_t)(g.nB + 1) * g.F))) return r;
   lv.low_n = g.nB + 1;
   if ((r = c->scal.ensure(c, 256))) return r;
-  // reach = max |mv| over everything the gather may touch
-  HIPCHK(c, hipMemsetAsync(c->scal.p, 0, 16, c->st));
-  if (g.nB) launch_mv_maxabs(c->st, (const int16_t*)lv.mv_filt.p, (size_t)g.nB * 4 * fld, (int*)c->scal.p);
-  for (int s = 0; s < 2; s++)
-    if (lv.halo[s]) launch_mv_maxabs(c->st, (const int16_t*)((const uint8_t*)lv.halo[s] + g.F), 4 * fld, (int*)c->scal.p);
-  int reach = 0;
+  // reach >= max |mv| over everything an update may touch.  Motion that motion_estimate produced in this context has a known
+  // bound and frame_types_t is on the device since decorrelate: then no host round trip stands between predict and update.
+  const bool have_halo = lv.halo[0] || lv.halo[1];
+  const bool resident = lv.mv_bound >= 0 && lv.types_d_ok && !have_halo;
+  int reach = resident ? lv.mv_bound : 0;
   uint8_t halo_types[2][16] = {{0}, {0}};
-  HIPCHK(c, hipMemcpyAsync(&reach, c->scal.p, sizeof(int), hipMemcpyDeviceToHost, c->st));
-  for (int s = 0; s < 2; s++)
-    if (lv.halo[s])
-      HIPCHK(c, hipMemcpyAsync(halo_types[s], (const uint8_t*)lv.halo[s] + g.F + 4 * fld * sizeof(int16_t), 16, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
-  // frame types to the device (tiny)
-  if ((r = c->tmp16[0].ensure(c, (size_t)g.nB + 16))) return r;
-  if (g.nB) HIPCHK(c, hipMemcpyAsync(c->tmp16[0].p, lv.types.data(), g.nB, hipMemcpyHostToDevice, c->st));
+  const uint8_t* types_dev = (const uint8_t*)lv.types_d.p;
+  if (!resident) {
+    HIPCHK(c, hipMemsetAsync(c->scal.p, 0, 16, c->st));
+    if (g.nB) launch_mv_maxabs(c->st, (const int16_t*)lv.mv_filt.p, (size_t)g.nB * 4 * fld, (int*)c->scal.p);
+    for (int s = 0; s < 2; s++)
+      if (lv.halo[s]) launch_mv_maxabs(c->st, (const int16_t*)((const uint8_t*)lv.halo[s] + g.F), 4 * fld, (int*)c->scal.p);
+    HIPCHK(c, hipMemcpyAsync(&reach, c->scal.p, sizeof(int), hipMemcpyDeviceToHost, c->st));
+    for (int s = 0; s < 2; s++)
+      if (lv.halo[s])
+        HIPCHK(c, hipMemcpyAsync(halo_types[s], (const uint8_t*)lv.halo[s] + g.F + 4 * fld * sizeof(int16_t), 16, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    // frame types to the device (tiny)
+    if ((r = c->tmp16[0].ensure(c, (size_t)g.nB + 16))) return r;
+    if (g.nB) HIPCHK(c, hipMemcpyAsync(c->tmp16[0].p, lv.types.data(), g.nB, hipMemcpyHostToDevice, c->st));
+    types_dev = (const uint8_t*)c->tmp16[0].p;
+  }
   UpdArgs a;
   a.g = g; a.frames = (const uint8_t*)c->lv[t - 1].low.p; a.high = (const uint8_t*)lv.high.p;
-  a.mv = (const int16_t*)lv.mv_filt.p; a.types = (const uint8_t*)c->tmp16[0].p; a.low = (uint8_t*)lv.low.p;
+  a.mv = (const int16_t*)lv.mv_filt.p; a.types = types_dev; a.low = (uint8_t*)lv.low.p;
   a.uf = uf; a.reach = reach; a.src_mul = 2; a.dst_mul = 1;
   for (int s = 0; s < 2; s++) {
     a.halo_high[s] = (const uint8_t*)lv.halo[s];
@@ -444,7 +463,7 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   pf.end(c);
   c->cup_src = nullptr;  // low_t was written: nothing interpolated from pictures may be reused across this point
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->st));  // lv.types / halo buffers may be changed by the caller next
+  if (!resident) HIPCHK(c, hipStreamSynchronize(c->st));  // lv.types / halo buffers may be changed by the caller next
   return QSVC_OK;
 }
 

@@ -22,6 +22,21 @@ struct DevBuf {  // grow-only device allocation: steady-state stage calls never 
   void release();
 };
 
+struct PinBuf {  // grow-only page-locked host allocation (small result / table transfers without a staging copy)
+  void* p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t n) {
+    if (n <= cap) return true;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = n + n / 4 + 256;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return false;
+    cap = want;
+    return true;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct Level {  // the device-resident "files" of temporal subband t
   DevBuf low, high, pred;        // low_t, high_t, prediction_even_t
   int low_n = 0, high_n = 0, pred_n = 0;
@@ -29,6 +44,8 @@ struct Level {  // the device-resident "files" of temporal subband t
   int mv_raw_n = 0, mv_filt_n = 0, mv_bs = 0;
   DevBuf hist;                   // [nB][3][256] u32
   std::string types;             // frame_types_t
+  DevBuf types_d; PinBuf types_pin; bool types_d_ok = false;  // the same on the device (written by decorrelate; put_frame_types invalidates)
+  int mv_bound = -1;             // >= 0: no component of motion_t / motion_filtered_t exceeds it (set by motion_estimate, cleared by put_motion)
   const void* halo[2] = {nullptr, nullptr};
   bool ragged = false;           // Q7: decorrelate ran on a picture the block grid does not tile
 };
@@ -70,7 +87,7 @@ struct qsvc_ctx {
   uint8_t halo_tb[2][16];
   void* comm = nullptr;            // ncclComm_t (RCCL), line topology
   int rank = 0, nranks = 1;
-  std::vector<uint32_t> hhist;
+  PinBuf hhist;                  // the B pictures' histograms on the host: [nB][3][256] u32
   std::string err;
   int profiling = 0;
   std::vector<Seg> segs;
