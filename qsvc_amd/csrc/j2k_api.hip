@@ -268,6 +268,7 @@ struct J2kState {
   std::vector<int> h_order;
   std::vector<DwtSb> sbtab;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
+  hipEvent_t copied[4] = {nullptr, nullptr, nullptr, nullptr};  // the code bytes reach the host in up to four pieces
   std::vector<PlaneDesc> planes;
   std::vector<CbDesc> cbs;
   Pinned<CbOut> res;
@@ -285,6 +286,7 @@ void j2k_release(qsvc_ctx* c) {
                    &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->jobs_d, &s->segs_d, &s->cnt_d, &s->dist_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
+  for (auto& e : s->copied) if (e) (void)hipEventDestroy(e);
   s->h_nbps.release(); s->h_joboff.release(); s->h_jobs.release(); s->res.release(); s->plen.release(); s->pdist.release(); s->h_err.release();
   delete s->pool;
   delete s;
@@ -607,24 +609,40 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   launch_gather(c->st, (const uint8_t*)S.outbuf.p, J2K_OUTCAP, (const unsigned long long*)S.offs_d.p, (const int*)S.lens_d.p, ncb,
                 (uint8_t*)S.gath_d.p);
   pf.end(c);
-  if (gtotal) HIPCHK(c, hipMemcpyAsync(S.gath_h, S.gath_d.p, gtotal, hipMemcpyDeviceToHost, c->st));
-  // host: rate allocation
-  const auto ra_begin = std::chrono::steady_clock::now();
+  // ... in up to four pieces of whole planes, an event after each: a plane's stream is written as soon as ITS bytes are there
+  std::vector<int> piece_of(np, 0);
+  {
+    const int want = np < 4 ? np : 4;
+    int p0 = 0;
+    for (int g = 0; g < want && p0 < np; g++) {
+      int p1 = p0 + 1;
+      const size_t target = gtotal / want * (g + 1);
+      while (p1 < np && (g == want - 1 || (size_t)goffs[first_cb[p1]] < target)) p1++;
+      if (g == want - 1) p1 = np;
+      const size_t b0 = (size_t)goffs[first_cb[p0]], b1 = p1 < np ? (size_t)goffs[first_cb[p1]] : gtotal;
+      if (!S.copied[g]) HIPCHK(c, hipEventCreateWithFlags(&S.copied[g], hipEventDisableTiming));
+      if (b1 > b0) HIPCHK(c, hipMemcpyAsync(S.gath_h + b0, (const uint8_t*)S.gath_d.p + b0, b1 - b0, hipMemcpyDeviceToHost, c->st));
+      HIPCHK(c, hipEventRecord(S.copied[g], c->st));
+      for (int p = p0; p < p1; p++) piece_of[p] = g;
+      p0 = p1;
+    }
+  }
   S.hcb.resize(ncb);
   S.st_cb += ncb;  // the statistics cover every plane group of the call (reset by j2k_encode_planes)
-  for (int p = 0; p < np; p++) {
+  // host, per plane and in parallel: rate allocation (which passes of a block go into which layer), then Tier-2
+  auto rate_alloc = [&](int p, uint64_t& n_pass, uint64_t& n_sym) {
     const PlanePlan& pl = plans[plan_of[p]];
     const qsvc_j2k_params* pprm = src[p].prm;
     const int layers = pprm->layers < 1 ? 1 : pprm->layers;
-    for (auto& s : pl.sb) {
-      double wgt = (double)s.delta * norm_of(rev, s.orient, s.dlev);
+    for (auto& sb : pl.sb) {
+      double wgt = (double)sb.delta * norm_of(rev, sb.orient, sb.dlev);
       wgt *= wgt;
-      for (int i = 0; i < s.gx * s.gy; i++) {
-        int k = first_cb[p] + s.first_cb + i;
+      for (int i = 0; i < sb.gx * sb.gy; i++) {
+        int k = first_cb[p] + sb.first_cb + i;
         const CbOut& ro = S.res[k];
         HostCb& h = S.hcb[k];
-        h.len = ro.len; h.npasses = ro.npasses; h.nbps = ro.nbps; h.zbp = s.Mb - ro.nbps; h.lblock = 3; h.included = false;
-        S.st_pass += ro.npasses; S.st_sym += ro.nsym;
+        h.len = ro.len; h.npasses = ro.npasses; h.nbps = ro.nbps; h.zbp = sb.Mb - ro.nbps; h.lblock = 3; h.included = false;
+        n_pass += ro.npasses; n_sym += ro.nsym;
         const int* plen = S.plen.data() + (size_t)k * T1_MAXPASS;
         for (int l = 0; l < layers; l++) {
           int n;
@@ -639,8 +657,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
         h.data_off = goffs[k];
       }
     }
-  }
-  c->host_time("host_rate_alloc", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ra_begin).count());
+  };
   // host: Tier-2, one code-stream per plane; planes are independent.  First every stream's length (packet headers are built, no
   // byte is copied), which fixes the streams' positions in `out`; then, once the code bytes have arrived, the streams themselves.
   {
@@ -653,17 +670,31 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
                               S.hcb.data() + first_cb[p], S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS, S.gath_h, dst, dcap);
     };
     const auto t2a_begin = std::chrono::steady_clock::now();
-    S.pool->run([&](int tid) { for (int p = tid; p < np; p += nthreads) rc[p] = stream_of(p, nullptr, 0); });
+    std::vector<uint64_t> n_pass(nthreads, 0), n_sym(nthreads, 0);
+    S.pool->run([&](int tid) {
+      for (int p = tid; p < np; p += nthreads) { rate_alloc(p, n_pass[tid], n_sym[tid]); rc[p] = stream_of(p, nullptr, 0); }
+    });
+    for (int k = 0; k < nthreads; k++) { S.st_pass += n_pass[k]; S.st_sym += n_sym[k]; }
     size_t pos = 0;
     for (int p = 0; p < np; p++) { offs[p] = pos; pos += (size_t)rc[p]; }
     offs[np] = pos;
     double t2_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2a_begin).count();
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    HIPCHK(c, hipGetLastError());
-    if (pos > cap) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes needed, %zu given)", pos, cap);
+    if (pos > cap) {
+      (void)hipStreamSynchronize(c->st);
+      return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes needed, %zu given)", pos, cap);
+    }
     const auto t2b_begin = std::chrono::steady_clock::now();
     std::vector<long> rc2(np, 0);
-    S.pool->run([&](int tid) { for (int p = tid; p < np; p += nthreads) rc2[p] = stream_of(p, out + offs[p], (size_t)rc[p]); });
+    std::vector<int> waited(nthreads, -1);
+    S.pool->run([&](int tid) {
+      (void)hipSetDevice(c->dev);
+      for (int p = tid; p < np; p += nthreads) {
+        if (piece_of[p] > waited[tid]) { (void)hipEventSynchronize(S.copied[piece_of[p]]); waited[tid] = piece_of[p]; }  // pieces complete in order
+        rc2[p] = stream_of(p, out + offs[p], (size_t)rc[p]);
+      }
+    });
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipGetLastError());
     for (int p = 0; p < np; p++) if (rc2[p] != rc[p]) return c->fail(QSVC_ERR_HIP, "internal: Tier-2 length of plane %d changed between the passes", p);
     t2_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2b_begin).count();
     c->host_time("host_tier2", t2_ms);
