@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   __syncthreads();
   // column words (lane = column x); at the same time the rows' sig0 / bit masks are collected by ballots: afterwards lane y
   // holds row y (bit x = column x)
-  uint64_t Zr = 0, Br = 0;
+  uint32_t zlo = 0, zhi = 0, blo = 0, bhi = 0;  // Zr, Br halves: a ballot lands in its row's lane by v_writelane
   uint32_t cwreg[16];
 #pragma unroll
   for (int s = 0; s < 16; s++) {
@@ -404,11 +404,15 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const uint64_t zb = __ballot((c >> (CW_SIG0 + k)) & 1), bb = __ballot((c >> (CW_BIT + k)) & 1);
-        if (lane == 4 * s + k) { Zr = zb; Br = bb; }
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(zlo) : "s"((uint32_t)zb), "n"(4 * s + k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(zhi) : "s"((uint32_t)(zb >> 32)), "n"(4 * s + k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(blo) : "s"((uint32_t)bb), "n"(4 * s + k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(bhi) : "s"((uint32_t)(bb >> 32)), "n"(4 * s + k));
       }
     }
     cwreg[s] = c;
   }
+  const uint64_t Zr = (uint64_t)zlo | (uint64_t)zhi << 32, Br = (uint64_t)blo | (uint64_t)bhi << 32;
   // membership: fixpoint of cm2_row_update over the 64 rows (t1_cm2.h)
   {
     const uint64_t wmask = w == 64 ? ~0ull : ((1ull << w) - 1);
