@@ -297,7 +297,15 @@ def main():
 
     # the MQ coder kernel in work: the library's default is the two-wave pipeline (64 code-blocks per wave pair); QSVC_MQ_PIPE=0
     # selects the one-wave form (QSVC_MQ_LANES blocks per wave)
-    mq_symbol = "k_t1_mq_pipe<64>" if os.environ.get("QSVC_MQ_PIPE", "1") != "0" else "k_t1_mq<%s>" % os.environ.get("QSVC_MQ_LANES", "64")
+    # With several sequences in flight the pipeline runs in its small-LDS form (two ring slots, a third of the staging area: its
+    # workgroups leave room on a CU for the other sequences' kernels; QSVC_MQ_LDS is read at every launch); the single-sequence
+    # figure below uses the library's default.  A caller's own QSVC_MQ_LDS wins.
+    user_lds = os.environ.get("QSVC_MQ_LDS")
+    if user_lds is None and S > 1:
+        os.environ["QSVC_MQ_LDS"] = "small"
+    small = os.environ.get("QSVC_MQ_LDS") == "small"
+    mq_symbol = (("k_t1_mq_pipe<64, 2, 116, 48>" if small else "k_t1_mq_pipe<64, 4, 196, 144>") if os.environ.get("QSVC_MQ_PIPE", "1") != "0"
+                 else "k_t1_mq<%s>" % os.environ.get("QSVC_MQ_LANES", "64"))
     run_steps(args.warmup)
     for e in engs:
         e.set_profiling(True)
@@ -318,6 +326,8 @@ def main():
         e.set_profiling(False)
     serial_ms, iso = None, {}
     if world == 1:  # ONE sequence alone on the chip: its latency, and every kernel group's ISOLATED duration (HIP events)
+        if user_lds is None:
+            os.environ.pop("QSVC_MQ_LDS", None)
         step(0)
         engs[0].sync()
         engs[0].set_profiling(True)
@@ -375,8 +385,9 @@ def main():
         a = alg[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e9 if dom in per and per[dom]["ms_per_step"] > 0 else 0.0
         roof = {"kernel": dom, "kernel_symbol": mq_symbol, "bound": "hbm", "achieved": round(a, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(a / HBM_PEAK_GBS, 6),
-                "traffic": traffic_of([(mq_symbol, 1)]),
-                "traffic_source": "profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE per launch, separate passes, one sequence in flight)",
+                "traffic": traffic_of([(mq_symbol, 1)]) or traffic_of([("k_t1_mq_pipe<64, 4, 196, 144>", 1)]),
+                "traffic_source": "profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE per launch, separate passes, one sequence in flight: the "
+                                  "pipeline in its default form, the same loads and stores as the small-LDS form)",
                 "launch_ms": per.get(dom, {}).get("ms_per_step"), "algorithmic_bytes_per_launch": int(alg[dom]),
                 "algorithmic_bytes": "SURVEY.md 8d: 15 657 code-blocks x 8 KB (int16 coefficients) + emitted code bytes, one launch per step",
                 "note": "the launch with the largest share of the step; EBCOT Tier-1 is serial-dependency bound, not HBM bound (SURVEY.md H4/8d): "

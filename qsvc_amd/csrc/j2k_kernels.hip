@@ -7,6 +7,7 @@
 // No MFMA: integer/bit work and short float lifting chains.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include "j2k_kernels.h"
 #include "t1_cm2.h"
 
@@ -145,14 +146,13 @@ __global__ void __launch_bounds__(T1_MQ_LANES) k_t1_mq(const CbDesc* cbs, int nc
 // per ~4.3 cycles whatever it does, so the pair codes a block's chain in a little over half the time of one wave.
 // Both waves derive the same chunk schedule from the block's pass table (chunk c of lane l = the c-th 16-decision piece of its
 // passes, the idle context after its last), so the ring needs two counters only: chunks produced, chunks consumed.
-#define MQ_RING 4
-template <int L>
+template <int L, int MQ_RING, int STAGE, int STAGE_FLUSH>
 __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff, const int* order, int nslots,
                                                        const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf, int outcap, CbOut* res,
                                                        int* pass_len, long long* pass_dist, int* err) {
   static_assert(L == 64, "one front wave and one back wave");
   __shared__ uint32_t s_cx[21 * L];
-  __shared__ uint32_t s_stage[(T1_STAGE / 4) * L];
+  __shared__ uint32_t s_stage[(STAGE / 4) * L];
   __shared__ uint16_t s_cnt[MQ_CNT_STRIDE * L];
   __shared__ uint32_t s_mq[64];
   __shared__ uint64_t s_mq2[94];
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb
   if (threadIdx.x < 4) s_sync[threadIdx.x] = 0;
   T1Lane t;
   t.cx = s_cx + 21 * lane; t.cs = 1; t.mqtab = s_mq; t.mq2 = s_mq2; t.zclut = nullptr;
-  t.stg = (uint8_t*)(s_stage + (T1_STAGE / 4) * lane);
+  t.stg = (uint8_t*)(s_stage + (STAGE / 4) * lane);
   t.w = t.h = t.orient = 0; t.nbps = 0; t.out = outbuf; t.cap = 0;
   size_t job0 = 0;
   if (b < ncb) { t.nbps = nbps_in[b] > 15 ? 15 : nbps_in[b]; t.out = outbuf + (size_t)b * outcap; t.cap = outcap; job0 = (size_t)joboff[b]; }
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb
     mq2_back_chunk(t, &s_ring[c % MQ_RING][0][lane], L);
     asm volatile("" ::: "memory");  // (LDS runs a wave's accesses in order: the records were read before this store lands)
     if (lane == 0) s_sync[1] = c + 1;
-    if (__any(t.sp - t.stg >= T1_STAGE_FLUSH)) mq2_stage_flush(t);  // all lanes at once: the wave pays for a flush whoever needs it
+    if (__any(t.sp - t.stg >= STAGE_FLUSH)) mq2_stage_flush(t);  // all lanes at once: the wave pays for a flush whoever needs it
     i += 16;
     if (q < npass && i >= n) { t.nsym += (uint32_t)n; enter_next(); }
   }
@@ -280,11 +280,19 @@ __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb
 void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int nslots,
                   const uint8_t* segs, const int* cnt, const long long* dist, uint8_t* outbuf, int outcap, CbOut* res, int* pass_len,
                   long long* pass_dist, int want_dist, int* err) {
-  // QSVC_MQ_PIPE (read at every launch): 1 = the two-wave pipeline (shortest chain: one sequence alone), 0 = one wave per 64 blocks
+  // QSVC_MQ_PIPE (read at every launch): 1 = the two-wave pipeline (default), 0 = one wave per 64 blocks.
+  // QSVC_MQ_LDS=small: the pipeline with a two-slot ring and a third of the staging area (25 instead of 40 KB of LDS per wave
+  // pair): + 5 % throughput when many sequences share the GPU (its workgroups leave room for the other kernels' on a CU),
+  // + 4 % latency for one sequence alone.
   const bool pipe = [] { const char* e = getenv("QSVC_MQ_PIPE"); return e ? atoi(e) != 0 : true; }();
+  const bool small = [] { const char* e = getenv("QSVC_MQ_LDS"); return e && !strcmp(e, "small"); }();
   if (pipe) {
-    hipLaunchKernelGGL(k_t1_mq_pipe<64>, dim3((nslots + 63) / 64), dim3(128), 0, st, cbs, ncb, nbps, joboff, order, nslots, segs, cnt, dist, outbuf, outcap, res,
-                       pass_len, want_dist ? pass_dist : nullptr, err);
+    if (small)
+      hipLaunchKernelGGL((k_t1_mq_pipe<64, 2, T1_STAGE_SMALL, T1_STAGE_SMALL_FLUSH>), dim3((nslots + 63) / 64), dim3(128), 0, st, cbs, ncb, nbps, joboff, order, nslots,
+                         segs, cnt, dist, outbuf, outcap, res, pass_len, want_dist ? pass_dist : nullptr, err);
+    else
+      hipLaunchKernelGGL((k_t1_mq_pipe<64, 4, T1_STAGE, T1_STAGE_FLUSH>), dim3((nslots + 63) / 64), dim3(128), 0, st, cbs, ncb, nbps, joboff, order, nslots,
+                         segs, cnt, dist, outbuf, outcap, res, pass_len, want_dist ? pass_dist : nullptr, err);
     return;
   }
   // lanes (code-blocks) per MQ wave: the coder is straight-line (no divergent path in a decision), so a wave costs the same

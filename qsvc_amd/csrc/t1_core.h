@@ -209,6 +209,8 @@ T1HD int mq_flush(T1Lane& t) {  // FLUSH, T.800 C.2.9; returns the segment lengt
 #define T1_PAD4 0x13131313u
 #define T1_STAGE 196                 // bytes per lane (49 words: odd stride, conflict-free across lanes)
 #define T1_STAGE_FLUSH 144           // flush once a lane holds this many: + 16 decisions x 3 bytes + FLUSH's 3 stays below T1_STAGE - 1
+#define T1_STAGE_SMALL 116           // the same with a third of the LDS (29 words), for kernels that share a CU with others
+#define T1_STAGE_SMALL_FLUSH 48
 T1HD uint32_t mq2_word(const uint32_t* mqtab, int state, int mps) {
   return (mqtab[state] & 0xFFFF) | (uint32_t)(8 * (2 * state + mps)) << 16 | (uint32_t)mps << 31;
 }

@@ -173,9 +173,9 @@ def test_both_mq_kernel_forms_give_the_same_streams(eng):
     y = _luma("pan_noise", 352, 288, 12)
     prm = hip.j2k_params(reversible=True, levels=4)
     want = J.encode_plane(y, reversible=True, levels=4)
-    saved = {k: os.environ.get(k) for k in ("QSVC_MQ_PIPE", "QSVC_MQ_LANES", "QSVC_MQ_SORT")}
+    saved = {k: os.environ.get(k) for k in ("QSVC_MQ_PIPE", "QSVC_MQ_LANES", "QSVC_MQ_SORT", "QSVC_MQ_LDS")}
     try:
-        for env in ({}, {"QSVC_MQ_PIPE": "0"}, {"QSVC_MQ_PIPE": "0", "QSVC_MQ_LANES": "16"}, {"QSVC_MQ_SORT": "0"}):
+        for env in ({}, {"QSVC_MQ_LDS": "small"}, {"QSVC_MQ_PIPE": "0"}, {"QSVC_MQ_PIPE": "0", "QSVC_MQ_LANES": "16"}, {"QSVC_MQ_SORT": "0"}):
             for k in saved:
                 os.environ.pop(k, None)
             os.environ.update(env)
