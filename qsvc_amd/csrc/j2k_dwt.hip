@@ -50,32 +50,47 @@ template <int STEP> __device__ __forceinline__ float lift97(float x, float lo, f
 }
 
 // Vertical step STEP over the staged tile: updates rows of parity (STEP even -> odd rows), lanes along a row.
-template <bool REV, int STEP, int NR>
+// INTERIOR (tile-uniform): every staged row has both neighbours inside the signal, so the boundary rule never applies and the
+// rows above / below the staged range are padding rows of the LDS array (what they feed is halo that nobody reads).
+template <bool REV, int STEP, int NR, bool INTERIOR>
 __device__ __forceinline__ void sweep_v(typename DwtTraits<REV>::T* T, int tid, int g0, int n) {
   typedef typename DwtTraits<REV>::T TT;
   const int par = (STEP & 1) ^ 1;
-#pragma unroll DT_UNROLL
-  for (int idx = tid; idx < (NR / 2) * DT_NC; idx += 256) {
-    const int c = idx % DT_NC, l = 2 * (idx / DT_NC) + par, g = g0 + l;
-    if (g < 0 || g >= n) continue;
+  auto one = [&](int lr, int c) {
+    const int l = 2 * lr + par, g = g0 + l;
     TT* p = T + l * DT_NCP + c;
-    const TT a = l > 0 ? p[-DT_NCP] : p[0], b = l + 1 < NR ? p[DT_NCP] : p[0];
-    const TT lo = g > 0 ? a : b, hi = g + 1 < n ? b : a;
+    TT lo, hi;
+    if (INTERIOR) { lo = p[-DT_NCP]; hi = p[DT_NCP]; }
+    else {
+      if (g < 0 || g >= n) return;
+      const TT a = l > 0 ? p[-DT_NCP] : p[0], b = l + 1 < NR ? p[DT_NCP] : p[0];
+      lo = g > 0 ? a : b; hi = g + 1 < n ? b : a;
+    }
     if (REV) p[0] = (TT)lift53<STEP>((int)p[0], (int)lo, (int)hi); else p[0] = (TT)lift97<STEP>((float)p[0], (float)lo, (float)hi);
-  }
+  };
+  // columns 0..127: two rows of the parity per pass of the 256 threads (no division); the last DT_NC - 128 columns afterwards
+  static_assert(DT_NC >= 128 && DT_NC - 128 == 8, "column split of sweep_v");
+  const int c = tid & 127;
+#pragma unroll DT_UNROLL
+  for (int lr = tid >> 7; lr < NR / 2; lr += 2) one(lr, c);
+  for (int e = tid; e < (NR / 2) * 8; e += 256) one(e >> 3, 128 + (e & 7));
 }
 // Horizontal step over the output rows [r0, r0 + nrows) of the tile: lanes along a column (row stride is odd).
-template <bool REV, int STEP>
+template <bool REV, int STEP, bool INTERIOR>
 __device__ __forceinline__ void sweep_h(typename DwtTraits<REV>::T* T, int tid, int r0, int nrows, int g0, int n) {
   typedef typename DwtTraits<REV>::T TT;
   const int par = (STEP & 1) ^ 1;
 #pragma unroll DT_UNROLL
   for (int idx = tid; idx < nrows * (DT_NC / 2); idx += 256) {
     const int r = r0 + idx % nrows, l = 2 * (idx / nrows) + par, g = g0 + l;
-    if (g < 0 || g >= n) continue;
     TT* p = T + r * DT_NCP + l;
-    const TT a = l > 0 ? p[-1] : p[0], b = l + 1 < DT_NC ? p[1] : p[0];
-    const TT lo = g > 0 ? a : b, hi = g + 1 < n ? b : a;
+    TT lo, hi;
+    if (INTERIOR) { lo = p[-1]; hi = p[1]; }   // column -1 / DT_NC of a row is the stride's padding word
+    else {
+      if (g < 0 || g >= n) continue;
+      const TT a = l > 0 ? p[-1] : p[0], b = l + 1 < DT_NC ? p[1] : p[0];
+      lo = g > 0 ? a : b; hi = g + 1 < n ? b : a;
+    }
     if (REV) p[0] = (TT)lift53<STEP>((int)p[0], (int)lo, (int)hi); else p[0] = (TT)lift97<STEP>((float)p[0], (float)lo, (float)hi);
   }
 }
@@ -115,7 +130,8 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
   typedef typename DwtTraits<REV>::LL LLT;
   constexpr int HALO = DwtTraits<REV>::HALO;
   constexpr int NR = 2 * DT_TH + 2 * HALO;
-  __shared__ TT sT[NR * DT_NCP];
+  __shared__ TT sTpad[(NR + 2) * DT_NCP];   // one padding row above and below the staged tile (interior sweeps read them)
+  TT* const sT = sTpad + DT_NCP;
   const int tid = threadIdx.x;
   const PlaneDesc pd = a.planes[blockIdx.z];
   int w = pd.W, h = pd.H;
@@ -176,12 +192,24 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
   }
   __syncthreads();
   // ---- vertical lifting, then horizontal lifting on the rows that are output ----------------------------------------------
+  const bool inner_v = gr0 >= 1 && gr0 + NR <= h - 1, inner_h = gc0 >= 1 && gc0 + DT_NC <= w - 1;   // workgroup-uniform
   if (h >= 2) {
-    sweep_v<REV, 0, NR>(sT, tid, gr0, h); __syncthreads();
-    sweep_v<REV, 1, NR>(sT, tid, gr0, h); __syncthreads();
+    if (inner_v) {
+      sweep_v<REV, 0, NR, true>(sT, tid, gr0, h); __syncthreads();
+      sweep_v<REV, 1, NR, true>(sT, tid, gr0, h); __syncthreads();
+      if (!REV) {
+        sweep_v<REV, 2, NR, true>(sT, tid, gr0, h); __syncthreads();
+        sweep_v<REV, 3, NR, true>(sT, tid, gr0, h); __syncthreads();
+      }
+    } else {
+      sweep_v<REV, 0, NR, false>(sT, tid, gr0, h); __syncthreads();
+      sweep_v<REV, 1, NR, false>(sT, tid, gr0, h); __syncthreads();
+      if (!REV) {
+        sweep_v<REV, 2, NR, false>(sT, tid, gr0, h); __syncthreads();
+        sweep_v<REV, 3, NR, false>(sT, tid, gr0, h); __syncthreads();
+      }
+    }
     if (!REV) {
-      sweep_v<REV, 2, NR>(sT, tid, gr0, h); __syncthreads();
-      sweep_v<REV, 3, NR>(sT, tid, gr0, h); __syncthreads();
       const float invK = 1.0f / F97_K;
       for (int idx = tid; idx < NR * DT_NC; idx += 256) {  // low (even rows) * 1/K, high (odd rows) * K
         const int l = idx / DT_NC, c = idx % DT_NC;
@@ -192,11 +220,22 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
     }
   }
   if (w >= 2) {
-    sweep_h<REV, 0>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
-    sweep_h<REV, 1>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+    if (inner_h) {
+      sweep_h<REV, 0, true>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+      sweep_h<REV, 1, true>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+      if (!REV) {
+        sweep_h<REV, 2, true>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+        sweep_h<REV, 3, true>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+      }
+    } else {
+      sweep_h<REV, 0, false>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+      sweep_h<REV, 1, false>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+      if (!REV) {
+        sweep_h<REV, 2, false>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+        sweep_h<REV, 3, false>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
+      }
+    }
     if (!REV) {
-      sweep_h<REV, 2>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
-      sweep_h<REV, 3>(sT, tid, HALO, 2 * DT_TH, gc0, w); __syncthreads();
       const float invK = 1.0f / F97_K;
       for (int idx = tid; idx < 2 * DT_TH * DT_NC; idx += 256) {
         const int r = HALO + idx % (2 * DT_TH), l = idx / (2 * DT_TH);
