@@ -463,9 +463,8 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   cx.zc = s_zc; cx.sp = s_sp; cx.p = p; cx.want_dist = want_dist != 0;
   const bool first = p == nb - 1;
   const int pass0 = first ? 2 : 0;
-  // count the three passes' decisions of this lane's 16 stripe columns (one neighbourhood assembly per column)
-  // a lane walks 16 consecutive columns of ONE stripe (s = lane / 4, x from 16 (lane % 4)): the 3 x 3 neighbourhood slides, only
-  // the new right-hand column's three words are read and taken apart per step (cm2_gather_slide)
+  // a lane walks 16 consecutive columns of ONE stripe (s = lane / 4, x from 16 (lane % 4)): first it counts the three passes'
+  // decisions from the raw column words, then it emits them through a sliding window of spread neighbourhood columns
   const int ls = lane >> 2, lx0 = (lane & 3) * 16;
   const bool lane_live = ls < nstr && lx0 < w;
   int n3[3] = {0, 0, 0};

@@ -126,26 +126,6 @@ T1HD void cm2_gather(Cm2Col& c, const uint32_t u[3], const uint32_t m[3], const 
   c.chiR = cm2_six(u[2], m[2], d[2], CW_NEG) << T1_CHI_SHIFT;
 }
 
-// Sliding form for a lane that walks consecutive columns of one stripe: the column that was x+1 becomes x, x becomes x-1, and
-// only the new right-hand column (words u2, m2, d2 of stripes s-1, s, s+1 at x+2 of the old position) is taken apart.
-T1HD void cm2_gather_first(Cm2Col& c, const uint32_t u[2], const uint32_t m[2], const uint32_t d[2]) {  // columns x-1, x into slots 1, 2
-  for (int k = 0; k < 2; k++) {
-    c.s0[k + 1] = cm2_six(u[k], m[k], d[k], CW_SIG0);
-    c.s1[k + 1] = cm2_six(u[k], m[k], d[k], CW_S1);
-    c.s2[k + 1] = cm2_six(u[k], m[k], d[k], CW_S2);
-  }
-  c.chiC = cm2_six(u[0], m[0], d[0], CW_NEG) << T1_CHI_SHIFT;
-  c.chiR = cm2_six(u[1], m[1], d[1], CW_NEG) << T1_CHI_SHIFT;
-  c.w = m[1];
-}
-T1HD void cm2_gather_slide(Cm2Col& c, uint32_t own, uint32_t u2, uint32_t m2, uint32_t d2) {  // own = the word of the new centre column
-  c.s0[0] = c.s0[1]; c.s0[1] = c.s0[2]; c.s0[2] = cm2_six(u2, m2, d2, CW_SIG0);
-  c.s1[0] = c.s1[1]; c.s1[1] = c.s1[2]; c.s1[2] = cm2_six(u2, m2, d2, CW_S1);
-  c.s2[0] = c.s2[1]; c.s2[1] = c.s2[2]; c.s2[2] = cm2_six(u2, m2, d2, CW_S2);
-  c.chiL = c.chiC; c.chiC = c.chiR; c.chiR = cm2_six(u2, m2, d2, CW_NEG) << T1_CHI_SHIFT;
-  c.w = own;
-}
-
 // The decisions of one stripe column in one pass (0 significance propagation, 1 magnitude refinement, 2 clean-up), in
 // coding order, with the column words final (M/S1/S2 set everywhere).  mag = the column's four packed magnitudes (only the
 // distortion estimates read it).
