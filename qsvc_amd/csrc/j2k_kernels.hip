@@ -7,6 +7,7 @@
 // No MFMA: integer/bit work and short float lifting chains.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include "j2k_kernels.h"
 #include "t1_cm2.h"
