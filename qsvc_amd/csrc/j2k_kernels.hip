@@ -469,6 +469,10 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   const int ls = lane >> 2, lx0 = (lane & 3) * 16;
   const bool lane_live = ls < nstr && lx0 < w;
   int n3[3] = {0, 0, 0};
+  uint16_t pk[16];     // per column: decisions of pass 0 | pass 1 << 4 | pass 2 << 8
+  uint32_t act = 0;    // columns that are not "plain" (more to do than one RUN = 0)
+#pragma unroll
+  for (int j = 0; j < 16; j++) pk[j] = 0;
   if (lane_live) {  // decisions per pass from the raw column words (the 3 x 3 neighbourhood slides along the stripe)
     uint32_t u[3] = {0, s_cw[ls][lx0], s_cw[ls][lx0 + 1]}, m[3] = {0, s_cw[ls + 1][lx0], s_cw[ls + 1][lx0 + 1]},
              d[3] = {0, s_cw[ls + 2][lx0], s_cw[ls + 2][lx0 + 1]};
@@ -477,9 +481,11 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
       u[0] = u[1]; u[1] = u[2]; u[2] = s_cw[ls][lx0 + j + 2];
       m[0] = m[1]; m[1] = m[2]; m[2] = s_cw[ls + 1][lx0 + j + 2];
       d[0] = d[1]; d[1] = d[2]; d[2] = s_cw[ls + 2][lx0 + j + 2];
-      int n[3];
-      cm2_counts_w(u, m, d, n);  // zero for a column beyond the block's width (its word is 0)
+      int n[3]; bool plain;
+      cm2_counts_w(u, m, d, n, &plain);  // zero for a column beyond the block's width (its word is 0)
       n3[0] += n[0]; n3[1] += n[1]; n3[2] += n[2];
+      pk[j] = (uint16_t)(n[0] | n[1] << 4 | n[2] << 8);
+      if (!plain && (n[0] | n[1] | n[2])) act |= 1u << j;
     }
   }
   int off3[3], tot3[3];
@@ -493,7 +499,63 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
   long long d3[3] = {0, 0, 0};
   // 16-byte aligned bases of the three streams inside s_out when all of them fit at once
   const int base1 = (tot3[0] + 15) & ~15, base2 = base1 + ((tot3[1] + 15) & ~15);
-  if (base2 + tot3[2] <= CM2_OUT_BYTES) {
+  // the columns with more to do than one RUN = 0, over the wave
+  int apos, nact;
+  {
+    const int mine = __popc(act);
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    apos = incl - mine;
+    nact = __shfl(incl, 63, 64);
+  }
+  if (nact <= CM2_LIST_MAX && base2 + tot3[2] + 16 <= CM2_LIST_AT) {
+    // ---- sparse plane: plain columns put their RUN byte, the others are listed and worked off 64 at a time ---------------
+    Cm2Entry* list = (Cm2Entry*)(s_out + CM2_LIST_AT);
+    if (lane_live) {
+      int o0 = off3[0], o1 = off3[1], o2 = off3[2], lp = apos;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const int n0 = pk[j] & 15, n1 = (pk[j] >> 4) & 15, n2 = pk[j] >> 8;
+        if ((act >> j) & 1) {
+          Cm2Entry e;
+          e.col = (uint16_t)(ls * 64 + lx0 + j); e.o0 = (uint16_t)o0; e.o1 = (uint16_t)o1; e.o2 = (uint16_t)o2;
+          list[lp++] = e;
+        } else if (n2) {
+          cm2_or_word((uint32_t*)(s_out + base2) + (o2 >> 2), (uint32_t)T1_CTX_RUN << (8 * (o2 & 3)));
+        }
+        o0 += n0; o1 += n1; o2 += n2;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < nact; base += 64) {
+      const int k = base + lane;
+      if (k < nact) {
+        const Cm2Entry e = list[k];
+        const int s = e.col >> 6, x = e.col & 63;
+        Cm2Win c;
+        cm2_win_at(c, s_sp, &s_cw[0][0], 66, s, x);
+        Cm2Out3 O;
+        cm2_emit3w(O, s_zc, s_sign, c);
+        Cm2Stream T0, T1, T2;
+        cm2_stream_begin(T0, s_out, e.o0); cm2_stream_begin(T1, s_out + base1, e.o1); cm2_stream_begin(T2, s_out + base2, e.o2);
+        cm2_stream_put8(T0, O.p0); cm2_stream_put4(T1, O.p1); cm2_stream_put4(T2, O.hdr); cm2_stream_put8(T2, O.p2);
+        cm2_stream_end(T0); cm2_stream_end(T1); cm2_stream_end(T2);
+        if (want_dist) cm2_dist3(cx, c.w, mg[e.col], d3);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+    if (lane < 16)  // the tails of the last 16-byte chunks: the idle decision (t1_core.h, T1_PAD)
+      for (int pass = pass0; pass < 3; pass++) {
+        const int i = tot3[pass] + lane;
+        if (i < ((tot3[pass] + 15) & ~15)) s_out[(pass == 0 ? 0 : (pass == 1 ? base1 : base2)) + i] = (uint8_t)T1_PAD;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (int pass = pass0; pass < 3; pass++) {
+      const uint8_t* src = s_out + (pass == 0 ? 0 : (pass == 1 ? base1 : base2));
+      uint8_t* dst = seg + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
+      for (int o = lane * 16; o < tot3[pass]; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(src + o);
+    }
+  } else if (base2 + tot3[2] <= CM2_OUT_BYTES) {
     Cm2Stream T0, T1, T2;
     cm2_stream_begin(T0, s_out, off3[0]);
     cm2_stream_begin(T1, s_out + base1, off3[1]);

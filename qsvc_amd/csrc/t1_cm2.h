@@ -346,6 +346,21 @@ T1HD void cm2_win_push(Cm2Win& c, const uint32_t* sp, uint32_t own, uint32_t u2,
   c.Bn = B; c.Dn = D;
   c.w = own;
 }
+// the window around an arbitrary stripe column (cw: the column-word array with its one-cell apron, row stride cwstride words;
+// column x of stripe s is cw[(s + 1) * cwstride + x + 1]) -- for the sparse form, where the columns in work are not consecutive
+T1HD void cm2_win_at(Cm2Win& c, const uint32_t* sp, const uint32_t* cw, int cwstride, int s, int x) {
+  c.w = 0; c.B1 = c.D1 = c.Bn = c.Dn = 0;
+  for (int k = 0; k < 3; k++) c.AB[k] = c.P[k] = c.Q[k] = c.DL[k] = c.DB[k] = c.X[k] = 0;
+  const uint32_t *u = cw + s * cwstride + x, *m = u + cwstride, *d = m + cwstride;
+  cm2_win_push(c, sp, 0, u[0], m[0], d[0]);
+  cm2_win_push(c, sp, 0, u[1], m[1], d[1]);
+  cm2_win_push(c, sp, m[1], u[2], m[2], d[2]);
+}
+// Sparse bit-planes (most columns "plain"): the columns that are not plain are listed -- column, and where its decisions go in
+// each of the three streams -- and worked off 64 at a time, instead of every lane walking all of its 16 columns.
+struct Cm2Entry { uint16_t col, o0, o1, o2; };   // col = stripe * 64 + x; byte offsets into the three streams
+#define CM2_LIST_MAX 512
+#define CM2_LIST_AT 6144            // the list lives in the upper part of the (then small) stream buffer
 // the centre column is four insignificant zeros without a significant neighbour: its only decision is RUN = 0 (clean-up pass)
 T1HD bool cm2_plain_run(const Cm2Win& c) {
   const uint32_t w = c.w;
@@ -423,7 +438,8 @@ T1HD void cm2_dist3(const Cm2Ctx& cx, uint32_t w, uint64_t mag, long long* dist)
 }
 // decisions per pass of the centre column from the raw words of its 3 x 3 neighbourhood (u/m/d = stripes s-1, s, s+1; index 0..2 =
 // columns x-1, x, x+1): what cm2_counts derives from the gathered vectors
-T1HD void cm2_counts_w(const uint32_t u[3], const uint32_t m[3], const uint32_t d[3], int n[3]) {
+// *plain (optional): the column's only decision is RUN = 0 (four insignificant zeros, no significant neighbour)
+T1HD void cm2_counts_w(const uint32_t u[3], const uint32_t m[3], const uint32_t d[3], int n[3], bool* plain = nullptr) {
   const uint32_t w = m[1];
   const uint32_t val4 = (w >> CW_VAL) & 0xF;
   const uint32_t bit4 = (w >> CW_BIT) & 0xF, M4 = (w >> CW_M) & val4, sig04 = (w >> CW_SIG0) & val4;
@@ -447,6 +463,7 @@ T1HD void cm2_counts_w(const uint32_t u[3], const uint32_t m[3], const uint32_t 
   const bool rl = val4 == 0xF && any == 0 && M4 == 0;
   const uint32_t skipA4 = rl ? ((2 * lowest - 1) & 0xF) : 0u, skipB4 = rl ? ((lowest - 1) & 0xF) : 0u;
   n[2] = pop(C4 & ~skipA4) + pop(S24 & ~skipB4) + (rl ? (bit4 ? 3 : 1) : 0);
+  if (plain) *plain = rl && !bit4;
 }
 
 // A lane's position in one pass's byte stream: whole words are OR-ed into a zeroed buffer (the first and the last word of a

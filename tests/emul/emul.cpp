@@ -424,6 +424,32 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
           }
         }
         for (int pass = 0; pass < 3; pass++) if (w3[pass] != e3[pass]) return -10;
+        // the sparse form: plain columns put their RUN byte, the others are listed with their stream offsets and worked off in any order
+        {
+          std::vector<uint32_t> sb[3];
+          for (int q = 0; q < 3; q++) sb[q].assign(T1_SEG_BYTES / 4 + 8, 0);
+          std::vector<Cm2Entry> list;
+          int o[3] = {0, 0, 0};
+          for (int s = 0; s < nstr; s++)
+            for (int x = 0; x < w; x++) {
+              int n3[3]; bool plain = false;
+              cm2_counts_w(&cw[s][x], &cw[s + 1][x], &cw[s + 2][x], n3, &plain);
+              if (plain) { if (n3[0] || n3[1] || n3[2] != 1) return -11; cm2_or_word(sb[2].data() + (o[2] >> 2), (uint32_t)T1_CTX_RUN << (8 * (o[2] & 3))); }
+              else if (n3[0] + n3[1] + n3[2]) list.push_back(Cm2Entry{(uint16_t)(s * 64 + x), (uint16_t)o[0], (uint16_t)o[1], (uint16_t)o[2]});
+              for (int q = 0; q < 3; q++) o[q] += n3[q];
+            }
+          for (size_t k = list.size(); k-- > 0;) {  // (backwards: the order must not matter)
+            const Cm2Entry e = list[k];
+            Cm2Win win; Cm2Out3 O; Cm2Stream t0, t1, t2;
+            cm2_win_at(win, sp, &cw[0][0], 66, e.col >> 6, e.col & 63);
+            cm2_emit3w(O, zcx, signlut, win);
+            cm2_stream_begin(t0, (uint8_t*)sb[0].data(), e.o0); cm2_stream_begin(t1, (uint8_t*)sb[1].data(), e.o1); cm2_stream_begin(t2, (uint8_t*)sb[2].data(), e.o2);
+            cm2_stream_put8(t0, O.p0); cm2_stream_put4(t1, O.p1); cm2_stream_put4(t2, O.hdr); cm2_stream_put8(t2, O.p2);
+            cm2_stream_end(t0); cm2_stream_end(t1); cm2_stream_end(t2);
+          }
+          for (int pass = 0; pass < 3; pass++)
+            if (o[pass] != (int)e3[pass].size() || memcmp(sb[pass].data(), e3[pass].data(), e3[pass].size())) return -12;
+        }
       }
       for (int pass = 0; pass < 3; pass++) {
         const uint8_t* seg = segs.data() + (size_t)p * T1_SEG_BYTES + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
