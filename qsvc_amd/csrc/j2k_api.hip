@@ -263,8 +263,8 @@ struct Pinned {
 struct J2kState {
   T2Pool* pool = nullptr;
   DevBuf coefA, llA, llB, sbtab_d, planes_d, cbs_d, nbps_d, mags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
-  DevBuf joboff_d, order_d, jobs_d, segs_d, cnt_d, dist_d;  // Tier-1: job list, decision segments
-  Pinned<int> h_nbps, h_joboff, h_jobs;
+  DevBuf joboff_d, order_d, segs_d, cnt_d, dist_d;  // Tier-1: first job of each block, MQ slot table, decision segments
+  Pinned<int> h_nbps, h_joboff;
   std::vector<int> h_order;
   std::vector<DwtSb> sbtab;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
@@ -283,11 +283,11 @@ void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->llA, &s->llB, &s->sbtab_d, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->jobs_d, &s->segs_d, &s->cnt_d, &s->dist_d};
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   for (auto& e : s->copied) if (e) (void)hipEventDestroy(e);
-  s->h_nbps.release(); s->h_joboff.release(); s->h_jobs.release(); s->res.release(); s->plen.release(); s->pdist.release(); s->h_err.release();
+  s->h_nbps.release(); s->h_joboff.release(); s->res.release(); s->plen.release(); s->pdist.release(); s->h_err.release();
   delete s->pool;
   delete s;
   c->j2k = nullptr;
@@ -552,16 +552,9 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     if ((r = S.segs_d.ensure(c, (njobs ? njobs : 1) * (size_t)T1_SEG_BYTES))) return r;
     if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
     if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
-    if (njobs) {  // job list: (block << 4 | plane) at joboff[block] + plane
-      if (!S.h_jobs.resize(njobs)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
-      for (int b = 0; b < ncb; b++) {
-        int nb = S.h_nbps[b] > 15 ? 15 : S.h_nbps[b];
-        for (int p = 0; p < nb; p++) S.h_jobs[S.h_joboff[b] + p] = (b << 4) | p;
-      }
-      if ((r = S.jobs_d.ensure(c, njobs * 4))) return r;
-      HIPCHK(c, hipMemcpyAsync(S.jobs_d.p, S.h_jobs.data(), njobs * 4, hipMemcpyHostToDevice, c->st));
+    if (njobs) {  // one context-modelling wave per block, its bit-planes one after the other (plane p = job joboff[block] + p)
       pf.begin(c, "j2k_t1_cm");
-      launch_t1_cm2(c->st, (const int*)S.jobs_d.p, (int)njobs, (const CbDesc*)S.cbs_d.p, (const int*)S.nbps_d.p,
+      launch_t1_cm2(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p,
                     (const unsigned long long*)S.mags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p, want_dist ? 1 : 0);
       pf.end(c);
     }

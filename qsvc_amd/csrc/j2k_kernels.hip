@@ -307,7 +307,8 @@ void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sample-parallel context modelling (t1_cm2.h): ONE WAVE per (code-block, bit-plane) job.  The block's magnitudes are read
+// Sample-parallel context modelling (t1_cm2.h): ONE WAVE per code-block, bit-plane after bit-plane (each plane is a "job" with its own
+// decision segments); the magnitudes stay in registers, the column words and row masks are carried from plane to plane.  The block's magnitudes are read
 // once (block-contiguous layout, 512-byte rows), the per-column state words live in LDS, the decisions of a pass are laid
 // out in LDS in scan order by a prefix sum over the lanes' counts and leave as 16-byte stores.  No flag words in HBM.
 template <bool REV>
@@ -363,65 +364,72 @@ void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneD
 }
 
 #define CM2_OUT_BYTES 10240  // the largest pass segment (clean-up: 10 decisions per stripe column at most)
-#ifndef CM2_JOBS
-#define CM2_JOBS 1           // jobs (waves) per workgroup (<= 4): their membership recurrences share wave 0, 16 lanes each.
-#endif                       // Measured: 1 -> 3.8 ms, 4 -> 4.8 ms per 17-picture step (the other waves idle through the chain)
-__global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int njobs, const CbDesc* cbs, const int* nbps_in,
-                                                           const unsigned long long* mags, uint8_t* segs, int* cnt,
-                                                           long long* dist, int want_dist) {
-  __shared__ uint32_t s_cwq[CM2_JOBS][18][66];
+__global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
+                                                const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist) {
+  __shared__ uint32_t s_cw[18][66];
   __shared__ uint32_t s_sp[64];
-  __shared__ uint8_t s_zcq[CM2_JOBS][1024];  // [0..511] zero coding, [512..1023] refinement (t1_cm2.h, cm2_emit3w)
-  __shared__ __attribute__((aligned(16))) uint8_t s_outq[CM2_JOBS][CM2_OUT_BYTES + 16];  // zeroed; the streams OR whole words into it
+  __shared__ uint8_t s_zc[1024];  // [0..511] zero coding, [512..1023] refinement (t1_cm2.h, cm2_emit3w)
+  __shared__ __attribute__((aligned(16))) uint8_t s_out[CM2_OUT_BYTES + 16];  // zeroed per plane; the streams OR whole words into it
   __shared__ uint8_t s_sign[256];
-  __shared__ int s_geo[CM2_JOBS][2];
-  __shared__ uint64_t s_rowM[CM2_JOBS][64];
-  const int jq = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int job = blockIdx.x * CM2_JOBS + jq;
-  const bool live = job < njobs;
-  uint32_t (*s_cw)[66] = s_cwq[jq];
-  uint8_t* s_zc = s_zcq[jq];
-  uint8_t* s_out = s_outq[jq];
-  int b = 0, p = 0, w = 0, h = 0, nstr = 0, nb = 0, orient = 0;
-  if (live) {
-    const int jb = jobs[job];
-    b = jb >> 4; p = jb & 15;
-    const CbDesc cb = cbs[b];
-    w = cb.w; h = cb.h; nstr = (h + 3) >> 2; nb = nbps_in[b]; orient = cb.orient;
-  }
+  __shared__ uint64_t s_rowM[64];
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const CbDesc cb = cbs[b];
+  const int w = cb.w, h = cb.h, nstr = (h + 3) >> 2, orient = cb.orient;
+  const int nb = nbps_in[b] > 15 ? 15 : nbps_in[b];
+  if (nb <= 0) return;  // (the whole workgroup)
+  const size_t job0 = (size_t)joboff[b];
   const unsigned long long* mg = mags + (size_t)b * 1024;
-  // tables + column words (lane = column x, all stripes: 512-byte rows of magnitudes)
-  if (jq == 0) { s_sp[lane] = CM2_SPREAD_INIT((uint32_t)lane); for (int i = lane; i < 256; i += 64) s_sign[i] = cm2_sign_entry(i); }
-  for (int i = lane; i < (CM2_OUT_BYTES + 16) / 16; i += 64) ((uint4*)s_out)[i] = make_uint4(0, 0, 0, 0);
-  if (lane == 0) { s_geo[jq][0] = w; s_geo[jq][1] = nstr; }
+  // tables, once per block
+  s_sp[lane] = CM2_SPREAD_INIT((uint32_t)lane);
+  for (int i = lane; i < 256; i += 64) s_sign[i] = cm2_sign_entry(i);
   {
     const int oc = orient == 1 ? 1 : (orient == 3 ? 3 : 0);
     for (int i = lane; i < 512; i += 64) { s_zc[i] = (uint8_t)t1_zc_from_nb(i, oc); s_zc[512 + i] = (uint8_t)(((i >> 4) & 1) ? 16 : ((i & 0x1EF) ? 15 : 14)); }
   }
   for (int i = lane; i < 18 * 66; i += 64) (&s_cw[0][0])[i] = 0;
+  // The block's magnitudes stay in registers for all of its bit-planes (lane = column x: 16 stripes x 4 rows), and the column
+  // words are carried from plane to plane: sig0(p) = sig0(p+1) | bit(p+1), mu(p) = sig0(p+1); only bit(p) is new.  The same for
+  // the row masks: Zr(p) = Zr(p+1) | Br(p+1), so only the bit rows go through ballots.
+  uint32_t mlo[16], mhi[16], fixed[16], st[16];   // fixed: neg | val fields; st: sig0 nibble | previous plane's bit nibble << 4
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    unsigned long long m = 0;
+    if (s < nstr && lane < w) m = mg[s * 64 + lane];
+    mlo[s] = (uint32_t)m; mhi[s] = (uint32_t)(m >> 32);
+    const int rows = h - 4 * s > 4 ? 4 : (h - 4 * s < 0 ? 0 : h - 4 * s);
+    const uint32_t tl = (mlo[s] >> 15) & 0x00010001u, th = (mhi[s] >> 15) & 0x00010001u;
+    const uint32_t neg4 = ((tl | tl >> 15) & 3) | (((th | th >> 15) & 3) << 2);
+    const uint32_t val4 = (s < nstr && lane < w) ? ((1u << rows) - 1) : 0u;
+    fixed[s] = neg4 << CW_NEG | val4 << CW_VAL;
+    st[s] = 0;
+  }
+  uint64_t Zr = 0, Br = 0;   // row masks of the plane above (lane = row)
   __syncthreads();
-  // column words (lane = column x); at the same time the rows' sig0 / bit masks are collected by ballots: afterwards lane y
-  // holds row y (bit x = column x)
-  uint32_t zlo = 0, zhi = 0, blo = 0, bhi = 0;  // Zr, Br halves: a ballot lands in its row's lane by v_writelane
+  for (int p = nb - 1; p >= 0; p--) {
+  const size_t job = job0 + p;
+  for (int i = lane; i < (CM2_OUT_BYTES + 16) / 16; i += 64) ((uint4*)s_out)[i] = make_uint4(0, 0, 0, 0);
+  Zr |= Br;
+  uint32_t blo = 0, bhi = 0;  // Br halves: a ballot lands in its row's lane by v_writelane
   uint32_t cwreg[16];
 #pragma unroll
   for (int s = 0; s < 16; s++) {
     uint32_t c = 0;
     if (s < nstr) {  // uniform
-      const int rows = h - 4 * s > 4 ? 4 : h - 4 * s;
-      if (lane < w) c = cm2_colword(mg[s * 64 + lane], p, rows, true);
+      const uint32_t sig_prev = st[s] & 0xF, sig0 = sig_prev | (st[s] >> 4);
+      const uint32_t tl = (mlo[s] >> p) & 0x00010001u, th = (mhi[s] >> p) & 0x00010001u;
+      const uint32_t bit4 = ((tl | tl >> 15) & 3) | (((th | th >> 15) & 3) << 2);
+      st[s] = sig0 | bit4 << 4;
+      c = sig0 << CW_SIG0 | bit4 << CW_BIT | sig_prev << CW_MU | fixed[s];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const uint64_t zb = __ballot((c >> (CW_SIG0 + k)) & 1), bb = __ballot((c >> (CW_BIT + k)) & 1);
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(zlo) : "s"((uint32_t)zb), "n"(4 * s + k));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(zhi) : "s"((uint32_t)(zb >> 32)), "n"(4 * s + k));
+        const uint64_t bb = __ballot((bit4 >> k) & 1);
         asm("v_writelane_b32 %0, %1, %2" : "+v"(blo) : "s"((uint32_t)bb), "n"(4 * s + k));
         asm("v_writelane_b32 %0, %1, %2" : "+v"(bhi) : "s"((uint32_t)(bb >> 32)), "n"(4 * s + k));
       }
     }
     cwreg[s] = c;
   }
-  const uint64_t Zr = (uint64_t)zlo | (uint64_t)zhi << 32, Br = (uint64_t)blo | (uint64_t)bhi << 32;
+  Br = (uint64_t)blo | (uint64_t)bhi << 32;
   // membership: fixpoint of cm2_row_update over the 64 rows (t1_cm2.h)
   {
     const uint64_t wmask = w == 64 ? ~0ull : ((1ull << w) - 1);
@@ -443,7 +451,7 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
       M = Mn;
       if (!__any(changed)) break;
     }
-    s_rowM[jq][lane] = M;
+    s_rowM[lane] = M;
   }
   __syncthreads();
 #pragma unroll
@@ -452,14 +460,13 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
       const uint32_t c = cwreg[s];
       uint32_t M4 = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) M4 |= (uint32_t)((s_rowM[jq][4 * s + k] >> lane) & 1) << k;
+      for (int k = 0; k < 4; k++) M4 |= (uint32_t)((s_rowM[4 * s + k] >> lane) & 1) << k;
       const uint32_t S1 = M4 & (c >> CW_BIT) & 0xF;
       const uint32_t S2 = (c >> CW_VAL) & ~(c >> CW_SIG0) & ~M4 & (c >> CW_BIT) & 0xF;
       s_cw[s + 1][lane + 1] = c | (M4 << CW_M) | (S1 << CW_S1) | (S2 << CW_S2);
     }
   }
   __syncthreads();
-  if (!live) return;  // no workgroup-wide barrier below this line
   Cm2Ctx cx;
   cx.zc = s_zc; cx.sp = s_sp; cx.p = p; cx.want_dist = want_dist != 0;
   const bool first = p == nb - 1;
@@ -623,10 +630,12 @@ __global__ void __launch_bounds__(64 * CM2_JOBS) k_t1_cm2(const int* jobs, int n
     }
     if (lane == 0) cnt[(size_t)job * 3 + pass] = tot3[pass];
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads();  // the next plane rewrites the column words and the streams
+  }  // planes
 }
-void launch_t1_cm2(hipStream_t st, const int* jobs, int njobs, const CbDesc* cbs, const int* nbps, const unsigned long long* mags,
+void launch_t1_cm2(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const unsigned long long* mags,
                    uint8_t* segs, int* cnt, long long* dist, int want_dist) {
-  if (njobs > 0) hipLaunchKernelGGL(k_t1_cm2, dim3((njobs + CM2_JOBS - 1) / CM2_JOBS), dim3(64 * CM2_JOBS), 0, st, jobs, njobs, cbs, nbps, mags, segs, cnt, dist, want_dist);
+  if (ncb > 0) hipLaunchKernelGGL(k_t1_cm2, dim3(ncb), dim3(64), 0, st, cbs, ncb, nbps, joboff, mags, segs, cnt, dist, want_dist);
 }
 
 // gather: segment of block b (bytes 1..len of its lane buffer) -> dst + offs[b]
