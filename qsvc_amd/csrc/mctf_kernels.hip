@@ -659,9 +659,12 @@ struct UpdScatter {
     }
   }
   // reg: the residues of rows [ry0, ..) x columns [rx0, ..), row stride RW, or nullptr (then `h`, the B picture's plane, is read).
-  __device__ __forceinline__ void run(uint8_t* tile, const uint8_t* reg, int ry0, int rx0, int RW, int ty0, int tx0, const uint8_t* h,
-                                      int hstride, const int16_t* mvx, const int16_t* mvy, int BX, int bs, int Hs, int Ws, int H, int W,
-                                      float uf, int lane) {
+  // TGT_IN (wave-uniform): every target of the tile lies strictly inside the picture, so only the tile's own bounds decide a hit
+  // pixel; SRC_IN: every pixel of every candidate block can carry a residue (Hs, Ws are multiples of the block size).
+  template <bool TGT_IN, bool SRC_IN>
+  __device__ __forceinline__ void run_t(uint8_t* tile, const uint8_t* reg, int ry0, int rx0, int RW, int ty0, int tx0, const uint8_t* h,
+                                        int hstride, const int16_t* mvx, const int16_t* mvy, int BX, int bs, int Hs, int Ws, int H, int W,
+                                        float uf, int lane) {
     const int lbs = 31 - __builtin_clz(bs);
     const bool pow2 = (1 << lbs) == bs;
     // 64 candidates at a time are tested against the tile in parallel; the hits are visited in ascending order = the reference's
@@ -686,7 +689,10 @@ struct UpdScatter {
           const int py = pow2 ? p >> lbs : p / bs, px = pow2 ? p & (bs - 1) : p % bs;
           const int sy = hy0 + py, sx = hx0 + px;
           const int t_y = sy + hdy, t_x = sx + hdx, ly = t_y - ty0, lx = t_x - tx0;
-          if (sy < Hs && sx < Ws && t_y > 0 && t_y < H - 1 && t_x > 0 && t_x < W - 1 && (unsigned)ly < (unsigned)TH && (unsigned)lx < (unsigned)TW) {
+          bool ok = (unsigned)ly < (unsigned)TH && (unsigned)lx < (unsigned)TW;
+          if (!SRC_IN) ok = ok && sy < Hs && sx < Ws;
+          if (!TGT_IN) ok = ok && t_y > 0 && t_y < H - 1 && t_x > 0 && t_x < W - 1;
+          if (ok) {
             const int r = (reg ? (int)reg[(sy - ry0) * RW + (sx - rx0)] : (int)h[(size_t)sy * hstride + sx]) - 128;
             uint8_t* t = tile + ly * TW + lx;
             *t = (uint8_t)upd_one((int)*t, r, uf);
@@ -694,6 +700,15 @@ struct UpdScatter {
         }
       }
     }
+  }
+  __device__ __forceinline__ void run(uint8_t* tile, const uint8_t* reg, int ry0, int rx0, int RW, int ty0, int tx0, const uint8_t* h,
+                                      int hstride, const int16_t* mvx, const int16_t* mvy, int BX, int bs, int Hs, int Ws, int H, int W,
+                                      float uf, int lane) {
+    const bool tgt_in = ty0 >= 1 && ty0 + TH <= H - 1 && tx0 >= 1 && tx0 + TW <= W - 1;   // wave-uniform
+    const bool src_in = Hs % bs == 0 && Ws % bs == 0;
+    if (tgt_in && src_in) run_t<true, true>(tile, reg, ry0, rx0, RW, ty0, tx0, h, hstride, mvx, mvy, BX, bs, Hs, Ws, H, W, uf, lane);
+    else if (tgt_in) run_t<true, false>(tile, reg, ry0, rx0, RW, ty0, tx0, h, hstride, mvx, mvy, BX, bs, Hs, Ws, H, W, uf, lane);
+    else run_t<false, false>(tile, reg, ry0, rx0, RW, ty0, tx0, h, hstride, mvx, mvy, BX, bs, Hs, Ws, H, W, uf, lane);
   }
 };
 // residues of rows [ry0, ry0+RH) x columns [rx0, rx0+RW) of a B picture's plane into LDS, 4 bytes per thread-load (all threads)
