@@ -204,6 +204,18 @@ QHD int analyze2d_coef(const Plane& P, int y, int x, int ny, int nx) {
   };
   return (int16_t)a53_coef(col, y, ny);
 }
+// The low-low coefficient (y, x) of one 2-D analysis level AWAY from the signal's ends (1 <= x <= nx/2 - 2, 1 <= y <= ny/2 - 2):
+// analyze2d_coef's expressions with every boundary case of a53_low / a53_high ruled out -- the same operations and truncations,
+// no branch (most of what the ME pyramid computes).
+template <class Plane>
+QHD int analyze2d_ll_inner(const Plane& P, int y, int x) {
+  auto rowlow = [&](int yy) {
+    const int a = P(yy, 2 * x - 2), b = P(yy, 2 * x - 1), c = P(yy, 2 * x), d = P(yy, 2 * x + 1), e = P(yy, 2 * x + 2);
+    return (int)(int16_t)(c + tdiv4((d - tdiv2(c + e)) + (b - tdiv2(a + c))));
+  };
+  const int r0 = rowlow(2 * y - 2), r1 = rowlow(2 * y - 1), r2 = rowlow(2 * y), r3 = rowlow(2 * y + 1), r4 = rowlow(2 * y + 2);
+  return (int16_t)(r2 + tdiv4((r3 - tdiv2(r2 + r4)) + (r1 - tdiv2(r0 + r2))));
+}
 // One sample (y,x) of one 2-D synthesis level (dwt2d.cpp:139-173: all columns, then all rows).
 template <class Plane>
 QHD int synthesize2d_sample(const Plane& P, int y, int x, int ny, int nx) {

@@ -40,7 +40,8 @@ QHD void pyr_thread(const T* src, size_t src_pic_stride, int src_row_stride, int
   int v;
   if (y < ny && x < nx) {
     auto P = [&](int yy, int xx) { return (int)s[(size_t)yy * src_row_stride + xx]; };
-    v = analyze2d_coef(P, y, x, ny, nx);
+    if (x >= 1 && x <= (nx >> 1) - 2 && y >= 1 && y <= (ny >> 1) - 2) v = analyze2d_ll_inner(P, y, x);
+    else v = analyze2d_coef(P, y, x, ny, nx);
   } else {
     v = s[(size_t)y * src_row_stride + x];
   }
