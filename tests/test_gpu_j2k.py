@@ -165,6 +165,32 @@ def test_plane_groups_do_not_change_the_streams(eng):
     assert runs[0].stdout == runs[1].stdout and runs[0].stdout.startswith("15 ")
 
 
+def test_random_planes_equal_restatement(eng):
+    """Random sizes (1..200), contents (noise, a few isolated samples on a flat plane, smooth, sparse), decomposition levels 0..5,
+    code-block sizes, both filters: byte-identical to the restatement.  Sparse and partial blocks exercise the column-list form
+    of the context modelling kernel and blocks of any height / width; tools/stress_j2k.py is the long version (700 cases)."""
+    from qsvc_amd import hip
+    rng = np.random.default_rng(20)
+    for k in range(70):
+        W, H = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        kind = k % 4
+        if kind == 0:
+            p = rng.integers(0, 256, size=(H, W))
+        elif kind == 1:
+            p = np.full((H, W), int(rng.integers(0, 256)))
+            for _ in range(int(rng.integers(0, 6))):
+                p[rng.integers(0, H), rng.integers(0, W)] = int(rng.integers(0, 256))
+        elif kind == 2:
+            yy, xx = np.mgrid[0:H, 0:W]
+            p = (128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0)).astype(np.int64)
+        else:
+            p = np.where(rng.random((H, W)) < 0.03, 255, 0)
+        p = np.ascontiguousarray(p, dtype=np.uint8)
+        rev, levels, cblk = bool(rng.integers(0, 2)), int(rng.integers(0, 6)), int(rng.choice([64, 64, 32, 16]))
+        got = eng.j2k_encode_plane(p, hip.j2k_params(reversible=rev, levels=levels, cblk=cblk))
+        assert got == J.encode_plane(p, reversible=rev, levels=levels, cblk=cblk), (k, W, H, kind, rev, levels, cblk)
+
+
 def test_both_mq_kernel_forms_give_the_same_streams(eng):
     """The MQ coder runs as a two-wave pipeline (k_t1_mq_pipe, the default) or as one wave per 64 blocks (QSVC_MQ_PIPE=0, any
     QSVC_MQ_LANES); the switches are read at every launch.  Same bytes, and equal to the restatement's."""
