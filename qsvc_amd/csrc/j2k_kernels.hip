@@ -177,12 +177,23 @@ __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb
   auto plane_of = [&](int q) { return q ? nbps - 2 - (((q - 1) * 43) >> 7) : nbps - 1; };
   auto kind_of = [&](int q) { return q ? (q - 1) - 3 * (((q - 1) * 43) >> 7) : 2; };
   uint16_t* mycnt = s_cnt + MQ_CNT_STRIDE * lane;
-  if (wv == 0)
-    for (int q = 0; q < npass; q++) {
-      const size_t e = (job0 + plane_of(q)) * 3 + kind_of(q);
-      mycnt[q] = (uint16_t)cnt[e];
-      if (pd) pd[q] = dist[e];
+  if (wv == 0) {  // the block's pass table; all of a lane's loads are in flight together (plane pl = passes 3 (nbps-1-pl) - 2 .. + 2)
+    int c3[15][3];
+#pragma unroll
+    for (int pl = 0; pl < 15; pl++) {
+      const int* src = cnt + (job0 + (pl < nbps ? pl : 0)) * 3;
+      c3[pl][0] = src[0]; c3[pl][1] = src[1]; c3[pl][2] = src[2];
     }
+#pragma unroll
+    for (int pl = 0; pl < 15; pl++)
+      if (pl < nbps) {
+        const int q0 = 3 * (nbps - 1 - pl) - 2;   // the plane's significance pass (the top plane has only its clean-up pass, q = 0)
+        if (q0 >= 0) { mycnt[q0] = (uint16_t)c3[pl][0]; mycnt[q0 + 1] = (uint16_t)c3[pl][1]; }
+        mycnt[q0 + 2] = (uint16_t)c3[pl][2];
+      }
+    if (pd)
+      for (int q = 0; q < npass; q++) pd[q] = dist[(job0 + plane_of(q)) * 3 + kind_of(q)];
+  }
   __syncthreads();
   // this lane's chunks and the wave's: the same in both waves
   int my_chunks = 0;
