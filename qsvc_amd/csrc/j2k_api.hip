@@ -343,7 +343,7 @@ static long write_codestream(const PlanePlan& pp, const qsvc_j2k_params& prm, in
           for (int i = 0; i < pp.sb[s].gx * pp.sb[s].gy; i++) {
             int ci = pp.sb[s].first_cb + i;
             HostCb& c = cb[ci];
-            const int* pl = plen_all + (size_t)ci * T1_MAXPASS;
+            const int* pl = plen_all ? plen_all + (size_t)ci * T1_MAXPASS : nullptr;
             int bx = i % pp.sb[s].gx, by = i / pp.sb[s].gx;
             int prev = l ? c.layer_passes[l - 1] : 0, now = c.layer_passes[l], add = now - prev;
             if (!c.included) {
@@ -356,7 +356,7 @@ static long write_codestream(const PlanePlan& pp, const qsvc_j2k_params& prm, in
               if (add <= 0) continue;
             }
             put_npasses(bw, add);
-            int len = pl[now - 1] - (prev ? pl[prev - 1] : 0);
+            int len = pl ? pl[now - 1] - (prev ? pl[prev - 1] : 0) : c.len;   // no table: all passes in this one layer
             int need = 1; while ((len >> need) && need < 32) need++;
             int have = c.lblock + ilog2i(add);
             int inc = need > have ? need - have : 0;
@@ -371,10 +371,10 @@ static long write_codestream(const PlanePlan& pp, const qsvc_j2k_params& prm, in
           for (int i = 0; i < pp.sb[s].gx * pp.sb[s].gy; i++) {
             int ci = pp.sb[s].first_cb + i;
             HostCb& c = cb[ci];
-            const int* pl = plen_all + (size_t)ci * T1_MAXPASS;
+            const int* pl = plen_all ? plen_all + (size_t)ci * T1_MAXPASS : nullptr;
             int prev = l ? c.layer_passes[l - 1] : 0, now = c.layer_passes[l];
             if (now <= prev) continue;
-            int a = prev ? pl[prev - 1] : 0, e = pl[now - 1];
+            int a = pl && prev ? pl[prev - 1] : 0, e = pl ? pl[now - 1] : c.len;
             if (size_only) o.skip((size_t)(e - a)); else o.bytes(data + c.data_off + a, (size_t)(e - a));
           }
     }
@@ -564,14 +564,15 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
                  (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, (int*)S.err_d.p);
     pf.end(c);
   }
-  if (!S.res.resize(ncb) || !S.h_err.resize(2) || !S.plen.resize((size_t)ncb * T1_MAXPASS) || (want_dist && !S.pdist.resize((size_t)ncb * T1_MAXPASS)))
+  // (the per-pass lengths and distortions only matter when some layer leaves passes out: lossless single-layer streams take every pass)
+  if (!S.res.resize(ncb) || !S.h_err.resize(2) || (want_dist && (!S.plen.resize((size_t)ncb * T1_MAXPASS) || !S.pdist.resize((size_t)ncb * T1_MAXPASS))))
     return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
   int& err = S.h_err[1];
   err = 0;
   HIPCHK(c, hipMemcpyAsync(S.res.data(), S.res_d.p, (size_t)ncb * sizeof(CbOut), hipMemcpyDeviceToHost, c->st));
   HIPCHK(c, hipMemcpyAsync(&err, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipMemcpyAsync(S.plen.data(), S.plen_d.p, (size_t)ncb * T1_MAXPASS * 4, hipMemcpyDeviceToHost, c->st));
   if (want_dist) {
+    HIPCHK(c, hipMemcpyAsync(S.plen.data(), S.plen_d.p, (size_t)ncb * T1_MAXPASS * 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(S.pdist.data(), S.pdist_d.p, (size_t)ncb * T1_MAXPASS * 8, hipMemcpyDeviceToHost, c->st));
   }
   HIPCHK(c, hipStreamSynchronize(c->st));
@@ -636,7 +637,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
         HostCb& h = S.hcb[k];
         h.len = ro.len; h.npasses = ro.npasses; h.nbps = ro.nbps; h.zbp = sb.Mb - ro.nbps; h.lblock = 3; h.included = false;
         n_pass += ro.npasses; n_sym += ro.nsym;
-        const int* plen = S.plen.data() + (size_t)k * T1_MAXPASS;
+        const int* plen = want_dist ? S.plen.data() + (size_t)k * T1_MAXPASS : nullptr;
         for (int l = 0; l < layers; l++) {
           int n;
           if (l == layers - 1 && pprm->slopes[l] <= 0) n = ro.npasses;
@@ -660,7 +661,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     std::vector<long> rc(np, 0);
     auto stream_of = [&](int p, uint8_t* dst, size_t dcap) {
       return write_codestream(plans[plan_of[p]], *src[p].prm, src[p].prm->layers < 1 ? 1 : src[p].prm->layers, cbw, cbh,
-                              S.hcb.data() + first_cb[p], S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS, S.gath_h, dst, dcap);
+                              S.hcb.data() + first_cb[p], want_dist ? S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS : nullptr, S.gath_h, dst, dcap);
     };
     const auto t2a_begin = std::chrono::steady_clock::now();
     std::vector<uint64_t> n_pass(nthreads, 0), n_sym(nthreads, 0);
