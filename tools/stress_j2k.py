@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity stress of the JPEG 2000 stage (GPU box): HIP code-streams against the T.800 restatement (oracle/, test
 infrastructure) for random plane sizes, contents, levels, code-block sizes, reversible and irreversible, 8-bit planes and signed
-16-bit planes.   python3 tools/stress_j2k.py [cases=300] [seed=1]"""
+16-bit planes.   python3 tools/stress_j2k.py [cases=300] [seed=1] [max_size=260]"""
 import os
 import sys
 
@@ -13,10 +13,11 @@ from qsvc_amd import hip  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+MAXS = int(sys.argv[3]) if len(sys.argv) > 3 else 260
 e = hip.Engine(0)
 bad = 0
 for k in range(n):
-    W, H = int(rng.integers(1, 260)), int(rng.integers(1, 260))
+    W, H = int(rng.integers(1, MAXS)), int(rng.integers(1, MAXS))
     kind = int(rng.integers(0, 6))
     if kind == 0:
         p = rng.integers(0, 256, size=(H, W))
