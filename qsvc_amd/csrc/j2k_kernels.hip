@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb
   __shared__ uint32_t s_mq[64];
   __shared__ uint64_t s_mq2[94];
   __shared__ uint32_t s_ring[MQ_RING][16][L];
-  __shared__ volatile int s_sync[4];  // [0] chunks produced, [1] chunks consumed, [2] a wait gave up
+  __shared__ int s_sync[4];  // [0] chunks produced, [1] chunks consumed, [2] a wait gave up, [3] front done (LDS atomics: ds_read / ds_write)
   const int wv = threadIdx.x / L, lane = threadIdx.x % L;
   const int slot = blockIdx.x * L + lane, b = slot < nslots ? order[slot] : ncb;
   for (int i = threadIdx.x; i < 47; i += 2 * L) s_mq[i] = c_mqtab[i];
@@ -201,14 +201,18 @@ __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb
   int nchunks = my_chunks;
   for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(nchunks, o, 64); nchunks = v > nchunks ? v : nchunks; }
   nchunks = __builtin_amdgcn_readfirstlane(nchunks);
+  // relaxed workgroup-scope atomics on LDS words: plain ds_read_b32 / ds_write_b32 (a volatile access through a generic pointer
+  // became a FLAT load with vmcnt(0) -- it waited for the wave's decision prefetches every time it looked at a counter)
+  auto sync_get = [&](int which) { return __hip_atomic_load(&s_sync[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto sync_set = [&](int which, int v) { __hip_atomic_store(&s_sync[which], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   int seen = 0;  // the partner's counter as last read (a wave waits on one counter only): it is re-read only when that is not enough
   auto wait_for = [&](int which, int at_least) {  // bounded: a lost update must not hang the GPU
     if (seen >= at_least) return;
-    seen = s_sync[which];
-    for (int spin = 0; seen < at_least && !s_sync[2]; spin++) {
+    seen = sync_get(which);
+    for (int spin = 0; seen < at_least && !sync_get(2); spin++) {
       __builtin_amdgcn_s_sleep(1);
-      seen = s_sync[which];
-      if (spin > (1 << 24)) { s_sync[2] = 1; atomicOr(err, 2); }
+      seen = sync_get(which);
+      if (spin > (1 << 24)) { sync_set(2, 1); atomicOr(err, 2); }
     }
   };
   // (q, n): the pass in work; i: decisions of it already taken; q2 / n2: the next pass with decisions
@@ -248,11 +252,11 @@ __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb
       asm volatile("" ::: "memory");
       mq2_front16(t, cur.x, cur.y, cur.z, cur.w, &s_ring[c % MQ_RING][0][lane], L);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the records are in LDS (only LDS: the fetches stay in flight)
-      if (lane == 0) s_sync[0] = c + 1;
+      if (lane == 0) sync_set(0, c + 1);
     }
     t.cx[20] = t.A;  // FLUSH (the back's) needs the final interval
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) s_sync[3] = 1;
+    if (lane == 0) sync_set(3, 1);
     return;
   }
   // ---- back
@@ -270,7 +274,7 @@ __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb
     asm volatile("" ::: "memory");
     mq2_back_chunk(t, &s_ring[c % MQ_RING][0][lane], L);
     asm volatile("" ::: "memory");  // (LDS runs a wave's accesses in order: the records were read before this store lands)
-    if (lane == 0) s_sync[1] = c + 1;
+    if (lane == 0) sync_set(1, c + 1);
     if (__any(t.sp - t.stg >= STAGE_FLUSH)) mq2_stage_flush(t);  // all lanes at once: the wave pays for a flush whoever needs it
     i += 16;
     if (q < npass && i >= n) { t.nsym += (uint32_t)n; enter_next(); }
