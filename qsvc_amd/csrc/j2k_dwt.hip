@@ -143,7 +143,10 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
 
   // ---- stage the tile: rows [gr0, gr0 + NR) x columns [gc0, gc0 + DT_NC), zero outside the signal -----------------------
   {
-    const uint8_t* u = pd.src;
+    // (pd.src comes out of a descriptor in memory: without the address space the compiler emits FLAT loads, which also count in lgkmcnt)
+    typedef const uint8_t __attribute__((address_space(1))) * gu8;
+    typedef const uint32_t __attribute__((address_space(1))) * gu32;
+    const gu8 u = (gu8)(uintptr_t)pd.src;
     const LLT* lin = (const LLT*)a.llin + (((a.lev - 1) & 1) ? pd.ll[1] : pd.ll[0]);  // (a dynamic index would send pd to scratch)
     const int sstr = FROM_U8 ? pd.u8stride : dwt_ll_stride(w);
     const bool wide = FROM_U8 ? ((((uintptr_t)u) & 3) == 0 && (sstr & 3) == 0) : true;
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
       const int idx = tid + it * 256, lr = idx / (DT_NC / 4), q = idx % (DT_NC / 4), gr = gr0 + lr, gc = gc0 + 4 * q;
       if (idx < NQ && gr >= 0 && gr < h && gc >= 0 && gc + 3 < w && wide) {
         fast |= 1u << it;
-        if (FROM_U8) raw[it] = *(const Raw*)(u + (size_t)gr * sstr + gc);
+        if constexpr (FROM_U8) raw[it] = *(gu32)(u + (size_t)gr * sstr + gc);
         else raw[it] = *(const Raw*)(lin + (size_t)gr * sstr + gc);
       }
     }
