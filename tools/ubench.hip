@@ -90,6 +90,7 @@ int main(int argc, char** argv) {
                          "dependent s_add", "3 v_add + not-taken branch (cmp+saveexec+cbranch)", "3 v_add + divergent taken branch", "LDS read + 3 v_add, use at end", "ffbh/lshl_add/bfe/min chain"};
   for (int rep = 0; rep < 2; rep++)
     for (int m = 0; m < 10; m++) {
+      if (m == 5) continue;  // (the scalar chain compiles into a many-second loop with this toolchain: left out)
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       hipEventRecord(e0);
       hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, m, out, clk);
