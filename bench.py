@@ -161,7 +161,8 @@ def main():
     # Tier-2 worker threads per encoder context: the host's cores shared by every rank of the node and every session of a rank
     # (8 sessions x 8 workers x 8 ranks would be 512 threads); a caller's own setting wins
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    os.environ.setdefault("QSVC_T2_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // max(1, local_world * S)))))
+    user_t2 = os.environ.get("QSVC_T2_THREADS")
+    os.environ.setdefault("QSVC_T2_THREADS", str(max(1, min(16 if S == 1 else 8, (os.cpu_count() or 8) // max(1, local_world * S)))))
     dev = os.environ.get("QSVC_BENCH_DEVICE")  # test hook: several ranks on one GPU (forces the host-staged exchange)
     devno = int(dev) if dev is not None else (local if world > 1 else 0)
     engs = [hip.Engine(devno) for _ in range(S)]
@@ -328,6 +329,8 @@ def main():
     if world == 1:  # ONE sequence alone on the chip: its latency, and every kernel group's ISOLATED duration (HIP events)
         if user_lds is None:
             os.environ.pop("QSVC_MQ_LDS", None)
+        if user_t2 is None:  # one sequence alone: its Tier-2 may use the cores the other sessions' would (read at every call)
+            os.environ["QSVC_T2_THREADS"] = str(max(1, min(16, (os.cpu_count() or 8) // max(1, local_world))))  # (16: 7.0 ms; 8: 7.6; 32: noisy)
         step(0)
         engs[0].sync()
         engs[0].set_profiling(True)
