@@ -9,6 +9,7 @@ tiny outputs verbatim (motion fields, frame types, whole small-geometry pictures
 digests of the frame-sized outputs of larger cases.
 
     python tests/golden/make_goldens.py        # rewrites tests/golden/mctf_*.npz, dwt_kat.npz
+    python tests/golden/make_goldens.py <case> …   # only the named mctf_<case>.npz
 """
 import hashlib
 import os
@@ -39,6 +40,11 @@ CASES = [
     ("sat_360x200", "saturating", 45, 9, 360, 200, 4, 8, 4, False),  # has 'I' pictures
     ("odd_350x286", "pan_noise", 43, 5, 350, 286, 3, 32, 8, False),  # non-PR sizes (Q5), Q7
     ("q7_200x120", "pan", 42, 5, 200, 120, 2, 32, 4, False),         # rows/cols beyond BY*bs (Q7)
+    # deep ME pyramids (motion_estimate.cpp:277: L = rint(log2 S) - 1 up to 6) and the S <- min(2S, 128) clamp of
+    # analyze.py:144-147: at the coarse levels one 16x16 block window covers far more than the LL quadrant (Q6/H3)
+    ("deep_pan_256x192", "pan_noise", 43, 129, 256, 192, 8, 16, 4, False),    # S = 4, 8, 16, 32, 64, 128, 128 (TRLs 8)
+    ("deep_edge_s32_256x192", "edge", 47, 9, 256, 192, 4, 16, 32, False),     # started at --search_range=32: 32, 64, 128
+    ("deep_sat_384x256", "saturating", 45, 17, 384, 256, 5, 32, 16, False),   # block 32: 16, 32, 64, 128
 ]
 
 
@@ -48,7 +54,10 @@ def sha(a) -> str:
 
 def main():
     assert O.have_ref(), "oracle/_ref missing: run `make -C oracle` in the build container"
+    only = set(sys.argv[1:])
     for name, kind, seed, frames, W, H, TRLs, bs, S, full in CASES:
+        if only and name not in only:
+            continue
         clip = make_clip(kind, frames, W, H, seed)
         levels = O.ref_analyze(clip, W, H, TRLs, bs, S)
         out = dict(meta=np.array([frames, W, H, TRLs, bs, S, seed], dtype=np.int64), kind=np.array(kind),
@@ -82,6 +91,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"mctf_{name}.npz"), **out)
         print(name, [lv["frame_types"] for lv in levels])
 
+    if only:
+        return
     # known answers of the in-tree transforms (dwt2d.cpp / 5_3.cpp / Haar.cpp) via oracle/_ref/dwt_probe
     rng = np.random.default_rng(7)
     kat = {}
