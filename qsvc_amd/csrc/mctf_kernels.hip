@@ -8,6 +8,7 @@
 // Wave = 64 lanes everywhere.  No MFMA: this is byte/integer streaming and gather work.
 #include <hip/hip_runtime.h>
 #include "mctf_kernels.h"
+#include <stdlib.h>
 
 namespace qsvc {
 
@@ -43,14 +44,18 @@ void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int 
 template <class T, int LPB>
 __global__ void __launch_bounds__(64) k_me_search(MeArgs a) {
   const int sub = threadIdx.x / LPB, lane = threadIdx.x % LPB;
-  const int bx = blockIdx.x * (64 / LPB) + sub, by = blockIdx.y, i = blockIdx.z;
-  const bool live = bx < a.nbx;
+  int bx = blockIdx.x * (64 / LPB) + sub, by = blockIdx.y;
+  const int i = blockIdx.z;
+  bool live = a.ring ? me_ring_block(a, bx, by, bx) : bx < a.nbx;
   MePlane<T> r0, r1, pr;
   me_block_setup<T>(a, i, r0, r1, pr);
   int pvx = 0, pvy = 0, nvx = 0, nvy = 0;
   int sad[18];
   if (live) {
     me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
+    if (a.ring && me_inner(a.g.H, a.g.W, a.g.bs, by * a.g.bs, bx * a.g.bs, pvy, pvx, nvy, nvx)) live = false;  // k_me_piece's
+  }
+  if (live) {
     me_block_sads<T>(r0, r1, pr, a.g.bs, by, bx, pvy, pvx, nvy, nvx, lane, LPB, sad, a.g.bord);
   } else {
 #pragma unroll
@@ -102,8 +107,9 @@ template <> struct MeRow<int16_t> {
 template <class T>
 __global__ void __launch_bounds__(64) k_me_search8(MeArgs a) {
   const int sub = threadIdx.x >> 3, row = threadIdx.x & 7;
-  const int bx = blockIdx.x * 8 + sub, by = blockIdx.y, i = blockIdx.z;
-  const bool live = bx < a.nbx;
+  int bx = blockIdx.x * 8 + sub, by = blockIdx.y;
+  const int i = blockIdx.z;
+  bool live = a.ring ? me_ring_block(a, bx, by, bx) : bx < a.nbx;
   MePlane<T> r0, r1, pr;
   me_block_setup<T>(a, i, r0, r1, pr);
   int pvx = 0, pvy = 0, nvx = 0, nvy = 0;
@@ -113,9 +119,9 @@ __global__ void __launch_bounds__(64) k_me_search8(MeArgs a) {
   if (live) {
     me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
     const int y0 = by * 8, x0 = bx * 8, y = y0 + row;
-    const bool inner = y0 + pvy - 1 >= 0 && y0 + pvy + 9 <= r0.g.H && x0 + pvx - 1 >= 0 && x0 + pvx + 9 <= r0.g.W &&
-                       y0 + nvy - 1 >= 0 && y0 + nvy + 9 <= r0.g.H && x0 + nvx - 1 >= 0 && x0 + nvx + 9 <= r0.g.W;
-    if (inner) {
+    const bool inner = me_inner(r0.g.H, r0.g.W, 8, y0, x0, pvy, pvx, nvy, nvx);
+    if (inner && a.ring) live = false;  // k_me_piece's
+    else if (inner) {
       MeRow<T> p, w;
       p.load(pr.snap + (size_t)y * pr.stride + x0);
       const int cand[9][2] = QSVC_ME_CANDS;
@@ -149,10 +155,27 @@ __global__ void __launch_bounds__(64) k_me_search8(MeArgs a) {
   }
   if (live && row == 7) me_block_store(a, i, by, bx, sad, pvx, pvy, nvx, nvy);
 }
-void launch_me_search(hipStream_t st, const MeArgs& a) {
+// mv_bound: no component of the vectors this level starts from exceeds it (0 at the coarsest level)
+void launch_me_search(hipStream_t st, const MeArgs& a0, int mv_bound) {
+  MeArgs a = a0;
+  a.ring = 0;
+  a.rby_lo = a.rby_hi = a.rbx_lo = a.rbx_hi = 0;
+  int cnt = 0;
+  if (me_piece_applies(a) && getenv("QSVC_ME_PIECE") == nullptr) {
+    // inner blocks (one lane per 8x8 samples, no border rule), then the ring where a displaced window can leave the picture
+    launch_me_piece(st, a);
+    const int bs = a.g.bs, b1 = mv_bound + 1;
+    a.ring = 1;
+    a.rby_lo = (b1 + bs - 1) / bs; a.rby_hi = imin(a.nby - 1, (a.g.H - b1) / bs - 1);
+    a.rbx_lo = (b1 + bs - 1) / bs; a.rbx_hi = imin(a.nbx - 1, (a.g.W - b1) / bs - 1);
+    if (a.rby_hi < a.rby_lo || a.rbx_hi < a.rbx_lo) { a.rby_lo = a.nby; a.rby_hi = a.nby - 1; a.rbx_lo = 0; a.rbx_hi = a.nbx - 1; }  // all ring
+    cnt = me_ring_count(a);
+    if (cnt == 0) return;
+  }
   dim3 block(64);
   if (a.g.bs == 8 && a.g.bord == 0) {
     dim3 grid((a.nbx + 7) / 8, a.nby, a.g.nB);
+    if (a.ring) grid = dim3((cnt + 7) / 8, 1, a.g.nB);
     if (a.l == 0) hipLaunchKernelGGL(k_me_search8<uint8_t>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_me_search8<int16_t>, grid, block, 0, st, a);
   } else if (a.g.bs * a.g.bs <= 64) {
@@ -161,6 +184,7 @@ void launch_me_search(hipStream_t st, const MeArgs& a) {
     else hipLaunchKernelGGL((k_me_search<int16_t, 16>), grid, block, 0, st, a);
   } else {
     dim3 grid(a.nbx, a.nby, a.g.nB);
+    if (a.ring) grid = dim3(cnt, 1, a.g.nB);
     if (a.l == 0) hipLaunchKernelGGL((k_me_search<uint8_t, 64>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_me_search<int16_t, 64>), grid, block, 0, st, a);
   }

@@ -58,7 +58,38 @@ struct MeArgs {
   int16_t* mv_out;         // level l result, same layout
   int l;                   // DWT level of this search
   int nby, nbx;            // desp(BY,l), desp(BX,l)
+  // Fast path split (mctf_me.hip): blocks whose displaced windows lie inside the picture ("inner", me_inner) are searched by the
+  // lane-per-8x8 kernel; the others can only lie outside the rectangle [rby_lo, rby_hi] x [rbx_lo, rbx_hi] of the block grid.
+  // ring != 0: the border-rule kernels enumerate only that ring and skip its inner blocks.
+  int ring;
+  int rby_lo, rby_hi, rbx_lo, rbx_hi;
 };
+// every sample the nine candidates of both directions read lies inside the picture (no border rule needed)
+QHD bool me_inner(int H, int W, int bs, int y0, int x0, int pvy, int pvx, int nvy, int nvx) {
+  return y0 + pvy - 1 >= 0 && y0 + pvy + bs + 1 <= H && x0 + pvx - 1 >= 0 && x0 + pvx + bs + 1 <= W &&
+         y0 + nvy - 1 >= 0 && y0 + nvy + bs + 1 <= H && x0 + nvx - 1 >= 0 && x0 + nvx + bs + 1 <= W;
+}
+// ring enumeration: idx -> (by, bx); false past the end.  Rows above the rectangle, then the left/right parts of the rectangle's
+// rows, then the rows below.
+QHD int me_ring_count(const MeArgs& a) {
+  const int mid = a.rby_hi - a.rby_lo + 1, per = a.rbx_lo + (a.nbx - 1 - a.rbx_hi);
+  return a.rby_lo * a.nbx + mid * per + (a.nby - 1 - a.rby_hi) * a.nbx;
+}
+QHD bool me_ring_block(const MeArgs& a, int idx, int& by, int& bx) {
+  const int ntop = a.rby_lo * a.nbx;
+  if (idx < ntop) { by = idx / a.nbx; bx = idx % a.nbx; return true; }
+  idx -= ntop;
+  const int mid = a.rby_hi - a.rby_lo + 1, per = a.rbx_lo + (a.nbx - 1 - a.rbx_hi);
+  if (per > 0 && idx < mid * per) {
+    const int k = idx % per;
+    by = a.rby_lo + idx / per;
+    bx = k < a.rbx_lo ? k : a.rbx_hi + 1 + (k - a.rbx_lo);
+    return true;
+  }
+  idx -= mid * per;
+  by = a.rby_hi + 1 + idx / a.nbx; bx = idx % a.nbx;
+  return by < a.nby;
+}
 template <class T>
 QHD void me_block_setup(const MeArgs& a, int i, MePlane<T>& r0, MePlane<T>& r1, MePlane<T>& pr) {
   BorderGeom bg = make_border(a.g.H, a.g.W, a.g.S + a.g.bord);  // motion_estimate.cpp:714

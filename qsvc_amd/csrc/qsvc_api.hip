@@ -295,15 +295,17 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
     if ((r = c->mvtmp[1].ensure(c, mvbytes))) return r;
   }
   const int16_t* prev = nullptr;
+  int bound = 0;  // max |component| of the vectors a level starts from: one +-1 step per level, doubled (and clamped) in between
   for (int l = L; l >= 0; l--) {
     MeArgs a;
     a.g = g; a.frames = frames; a.snap = l ? c->snap[l].p : nullptr; a.snap_pic_stride = N;
     a.mv_prev = prev; a.mv_out = l == 0 ? (int16_t*)lv.mv_raw.p : (int16_t*)c->mvtmp[l & 1].p;
     a.l = l; a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l);
     pf.begin(c, l == 0 ? "me_search_l0" : "me_search_coarse");
-    launch_me_search(c->st, a);
+    launch_me_search(c->st, a, bound);
     pf.end(c);
     prev = a.mv_out;
+    bound = imin(2 * (bound + 1), S);
   }
   HIPCHK(c, hipGetLastError());
   return QSVC_OK;

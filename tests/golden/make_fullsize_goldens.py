@@ -31,6 +31,8 @@ CASES = [
     ("cfg3_pan_noise", "pan_noise", 43, 17, 1920, 1080, 4, 8, 4),
     ("cfg3_edge", "edge", 47, 17, 1920, 1080, 4, 8, 4),
     ("cfg4_pan_noise_2levels", "pan_noise", 43, 9, 3840, 2160, 3, 16, 4),
+    # BASELINE config 4 whole: 33 pictures, TRLs=5, search 4 -> 8 -> 16 -> 32 (L = 4 at the last level)
+    ("cfg4_pan_noise", "pan_noise", 43, 33, 3840, 2160, 5, 16, 4),
 ]
 
 

@@ -85,8 +85,17 @@ def test_config4_4k_gop32_97(eng, oracle):
     out = comp.compress()
     assert sum(len(v) for v in out.values()) == 33 * 3
     assert eng.j2k_stats()["codeblocks"] == 33 * 3261
-    types = b"".join(eng.get_frame_types(t, n) for t, n in ((1, 16), (2, 8), (3, 4), (4, 2)))
-    assert set(types) <= {ord("I"), ord("B")}
+    # every level of this very clip is pinned by the reference tools' digests (test_fullsize_levels_match_reference_digests
+    # [cfg4_pan_noise]); here the same digests are checked on the state the whole-pipeline run left behind
+    from helpers import sha
+    c4 = _fullsize_cases()["cfg4_pan_noise"]
+    assert sha(clip) == c4["input_sha"]
+    for lv in c4["levels"]:
+        t, nB = lv["t"], lv["pictures"] // 2
+        assert eng.get_frame_types(t, nB).decode() == lv["frame_types"], f"frame_types_{t}"
+        assert sha(eng.get_motion(hip.MOTION_FILTERED, t, nB, 16)) == lv["motion_filtered"], f"motion_filtered_{t}"
+        assert sha(eng.get_frames(hip.HIGH, t, 0, nB)) == lv["high"], f"high_{t}"
+        assert sha(eng.get_frames(hip.LOW, t, 0, nB + 1)) == lv["low"], f"low_{t}"
     low = eng.get_frames(hip.LOW, 4, 0, 3)[1]
     for c, pl in enumerate(planes_of(low, W, H)):
         assert J.psnr(J.decode(out[(hip.LOW, 4)][3 + c]), pl) > 50
@@ -121,10 +130,10 @@ def _fullsize_cases():
     return json.load(open(os.path.join(GOLDEN, "fullsize_digests.json")))
 
 
-@pytest.mark.parametrize("name", ["cfg3_pan_noise", "cfg3_edge", "cfg4_pan_noise_2levels"])
+@pytest.mark.parametrize("name", ["cfg3_pan_noise", "cfg3_edge", "cfg4_pan_noise_2levels", "cfg4_pan_noise"])
 def test_fullsize_levels_match_reference_digests(eng, name):
-    """BASELINE config 3 (all three 1080p levels: S = 4/8/16, 135x240 block grid) and levels 1-2 of config 4 (3840x2160,
-    block 16): motion_t, motion_filtered_t, frame_types_t, high_t, low_t == the compiled reference tools' files
+    """BASELINE config 3 (all three 1080p levels: S = 4/8/16, 135x240 block grid), levels 1-2 of a 9-picture 4K clip and ALL FOUR
+    levels of config 4 (3840x2160, 33 pictures, block 16, S = 4/8/16/32, i.e. pyramids up to L = 4): motion_t, motion_filtered_t, frame_types_t, high_t, low_t == the compiled reference tools' files
     (motion_estimate.cpp:260-481, decorrelate.cpp:583-1075, update.cpp:506-656), by SHA-256 per picture and per file."""
     from helpers import sha
     from qsvc_amd import hip

@@ -1,22 +1,27 @@
+"""Per-stage HIP-event times of the MCTF levels of one sequence (tools, GPU box):  python tools/time_mctf.py [cfg3|cfg4] [iters]"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 from qsvc_amd import hip
 from qsvc_amd.synth import make_clip
-W,H,bs=1920,1080,8
-P=17
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+W, H, bs, P, TRLs = (1920, 1080, 8, 17, 4) if cfg == "cfg3" else (3840, 2160, 16, 33, 5)
 clip = make_clip("pan_noise", P, W, H, 43)
 e = hip.Engine(0)
-e.seq_config(W,H)
-e.put_frames(hip.LOW,0,clip)
+e.seq_config(W, H)
+e.put_frames(hip.LOW, 0, clip)
 def run():
     p, S = P, 4
-    for t in range(1,4):
-        e.analyze_step(t,p,bs,S)
-        p=(p+1)//2; S*=2
+    for t in range(1, TRLs):
+        e.analyze_step(t, p, bs, S)
+        p = (p + 1) // 2; S *= 2
 run(); e.sync()
 e.set_profiling(True)
-t0=time.time()
-for _ in range(3): run()
-e.sync(); dt=(time.time()-t0)/3
-print("MCTF 3 levels 17 frames: %.2f ms -> %.1f fps"%(dt*1e3, 16/dt))
-for k,(ms,n) in e.timings().items(): print(f"  {k:20s} {ms/3:8.3f} ms/iter  ({n} launches)")
+t0 = time.time()
+for _ in range(iters): run()
+e.sync(); dt = (time.time() - t0) / iters
+print("%s MCTF %d levels %d pictures: %.3f ms wall" % (cfg, TRLs - 1, P, dt * 1e3))
+tot = 0.0
+for k, (ms, n) in e.timings().items():
+    print(f"  {k:20s} {ms/iters:8.3f} ms/iter  ({n // iters} launches)"); tot += ms / iters
+print(f"  {'sum of kernels':20s} {tot:8.3f} ms/iter")
