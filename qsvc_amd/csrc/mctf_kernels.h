@@ -13,6 +13,9 @@ void launch_me_piece(hipStream_t st, const MeArgs& a);
 // into cup[k][c][H][W]: computed once per even picture instead of inside every prediction / update footprint
 void launch_chroma_up(hipStream_t st, const uint8_t* frames, const LevelGeom& g, int mul, int count, uint8_t* cup);
 void launch_predict(hipStream_t st, const PredArgs& a);
+bool pred_run_applies(const PredArgs& a);        // mctf_pred.hip
+void launch_predict_run(hipStream_t st, const PredArgs& a);
+bool pred_fast_path(const PredArgs& a);          // launch_predict takes the mctf_pred.hip kernels (no interpolated chroma planes needed)
 // --block_overlaping >= 2: predict through per-block analysis + picture synthesis (two [nB][3][H][W] int16 work buffers)
 bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, int16_t* ppl1);
 void launch_pred_margin(hipStream_t st, const PredArgs& a);  // mctf_margin.hip (Q7)

@@ -574,10 +574,19 @@ bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, in
   return true;
 }
 
+bool pred_fast_path(const PredArgs& a) { return pred_run_applies(a) && getenv("QSVC_PRED_RUN") == nullptr; }
 void launch_predict(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
   if (!a.odd_out) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
   dim3 block(64, 4);
+  if (pred_fast_path(a)) {  // mctf_pred.hip: runs of 8 samples, chroma straight from the half-resolution planes
+    launch_predict_run(st, a);
+    size_t per_pic = (size_t)4 * g.BY * g.BX;
+    int nblk = (int)((per_pic + 255) / 256);
+    if (nblk > 64) nblk = 64;
+    hipLaunchKernelGGL(k_mv_hist, dim3(nblk, g.nB), dim3(256), 0, st, a.mv, per_pic, a.hist);
+    return;
+  }
   if (a.margin) launch_pred_margin(st, a);  // mctf_margin.hip
   if (g.bs % 8 == 0) hipLaunchKernelGGL(k_pred_luma8, dim3((g.W + 511) / 512, (g.H + 3) / 4, g.nB), block, 0, st, a);
   else hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);

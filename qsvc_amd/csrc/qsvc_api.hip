@@ -35,15 +35,16 @@ int qsvc_ctx::hipfail(hipError_t e, const char* what) {
 
 int DevBuf::ensure(qsvc_ctx* c, size_t n) {
   if (n <= cap) return QSVC_OK;
-  if (p) (void)hipFree(p);
-  p = nullptr; cap = 0;
-  hipError_t e = hipMalloc(&p, n);
-  if (e != hipSuccess) { p = nullptr; return c->fail(QSVC_ERR_NOMEM, "hipMalloc(%zu): %s", n, hipGetErrorString(e)); }
+  release();
+  void* base = nullptr;
+  hipError_t e = hipMalloc(&base, n + 2 * DEVBUF_PAD);
+  if (e != hipSuccess) return c->fail(QSVC_ERR_NOMEM, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
+  p = (uint8_t*)base + DEVBUF_PAD;
   cap = n;
   return QSVC_OK;
 }
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  if (p) (void)hipFree((uint8_t*)p - DEVBUF_PAD);
   p = nullptr; cap = 0;
 }
 
@@ -376,7 +377,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   }
   Prof pf;
   pf.begin(c, "predict");
-  if (!lv.ragged && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
+  if (!lv.ragged && !pred_fast_path(a) && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
   if (g.ov >= 2) {
     if ((r = predict_overlapped(c, g, a))) return r;
   } else launch_predict(c->st, a);

@@ -15,6 +15,9 @@
 
 struct qsvc_ctx;
 
+// p points DEVBUF_PAD bytes into the allocation and DEVBUF_PAD more follow the requested size: the MCTF kernels read whole
+// 8-byte runs whose unused tail (or head) bytes may lie a few bytes outside the plane they belong to.
+#define DEVBUF_PAD 256
 struct DevBuf {  // grow-only device allocation: steady-state stage calls never hipMalloc
   void* p = nullptr;
   size_t cap = 0;
