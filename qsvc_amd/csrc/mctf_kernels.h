@@ -20,6 +20,9 @@ bool pred_fast_path(const PredArgs& a);          // launch_predict takes the mct
 bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, int16_t* ppl1);
 void launch_pred_margin(hipStream_t st, const PredArgs& a);  // mctf_margin.hip (Q7)
 void launch_update(hipStream_t st, const UpdArgs& a);
+bool upd_run_applies(const UpdArgs& a);          // mctf_upd.hip
+void launch_update_run(hipStream_t st, const UpdArgs& a);
+bool upd_fast_path(const UpdArgs& a);            // launch_update takes the mctf_upd.hip kernels (no interpolated chroma planes needed)
 void launch_mv_maxabs(hipStream_t st, const int16_t* mv, size_t n, int* out);
 void launch_dwt53t_level(hipStream_t st, const int16_t* src, int16_t* dst, int stride, int ny, int nx, int inverse);
 }  // namespace qsvc

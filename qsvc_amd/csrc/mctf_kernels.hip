@@ -935,9 +935,16 @@ __global__ void __launch_bounds__(256) k_upd_chroma_tile(UpdArgs a) {
     a.low[(size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci] = (uint8_t)(int16_t)a53_low(col, cj, g.H);
   }
 }
+bool upd_fast_path(const UpdArgs& a) { return upd_run_applies(a) && getenv("QSVC_UPD_RUN") == nullptr; }
 void launch_update(hipStream_t st, const UpdArgs& a) {
   const LevelGeom& g = a.g;
   dim3 block(64, 4);
+  if (upd_fast_path(a)) {  // mctf_upd.hip: ordered gather by runs of 8 targets, chroma interpolated inside its tiles
+    const size_t n = (size_t)2 * (g.W / 2) * (g.H / 2);
+    hipLaunchKernelGGL(k_upd_chroma_copy, dim3((unsigned)((n / 16 + 256) / 256), g.nB + 1), dim3(256), 0, st, a);
+    launch_update_run(st, a);
+    return;
+  }
   const dim3 cgrid((g.W / 2 + PC_TW - 1) / PC_TW, (g.H / 2 + PC_TH - 1) / PC_TH, (g.nB + 1) * 2);
   hipLaunchKernelGGL(k_upd_luma_tile, dim3((g.W + UL_TW - 1) / UL_TW, (g.H + 4 * UL_TH - 1) / (4 * UL_TH), g.nB + 1), dim3(256), 0, st, a);
   if (a.cup && g.W % 8 == 0) {

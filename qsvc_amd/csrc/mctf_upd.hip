@@ -1,0 +1,200 @@
+// qsvc_amd/csrc/mctf_upd.hip -- the update step of a whole temporal level (update.cpp:85-146, 472-503, 632-643) as an ORDERED
+// GATHER BY RUNS OF 8 TARGETS, the form used when the block size is a power of two >= 8, the picture width a multiple of 8 and
+// the block grid tiles the picture (everything else: the tile kernels of mctf_kernels.hip).
+//
+// The reference scatters: every sample of every block of a B picture adds residue * update_factor into the even picture at its
+// displaced position, with a clamp after every addition, in raster order of blocks (H2: order matters where footprints overlap).
+// Here a lane owns 8 neighbouring targets of one row and walks the few blocks whose displaced footprint can meet them, in that
+// same raster order.  A block's footprint meets the run in an interval [lo, hi) of it, and the 8 source samples that land on the
+// run are ONE unaligned 8-byte load of the B picture's row (ty - dy) at column (tx - dx), masked to the interval.  As long as the
+// intervals of different blocks do not overlap -- everywhere except at motion discontinuities -- each target has at most one
+// source per side and the masked loads are simply OR-ed together (a zero residue changes nothing: clamp(v + 0) = v) and applied
+// once with update.cpp:93-115's float operations; a lane that sees two blocks on one target replays its blocks one by one.
+// Targets on the picture's border collect every source that clip() folds onto them: the border kernel (luma) and the border
+// pass of the chroma tile evaluate those cells with the ordered gather of mctf_core.h (update_gather) from the input picture.
+// Chroma: targets are the x2-interpolated planes (computed in the tile from the stored half-resolution plane), sources the
+// half-resolution residue in the top-left quadrant (Q3), and the stored result is the LL band of the updated tile.
+#include <hip/hip_runtime.h>
+#include "mctf_kernels.h"
+#include "mctf_runs.h"
+
+namespace qsvc {
+
+struct UpdSrc {
+  const uint8_t* high;   // plane of residue + 128
+  int stride, Hs, Ws;    // its row stride and the area that carries residues
+  const int16_t* mvx;
+  const int16_t* mvy;
+  int BX, lbs, nby, nbx;  // field stride, log2(block size), blocks that can carry a residue
+};
+__device__ __forceinline__ uint64_t run_mask(int lo, int hi) { return (~0ull << (8 * lo)) & (~0ull >> (64 - 8 * hi)); }
+// the 8 targets' values after one source run (signed residue bytes, 0 = no source)
+__device__ __forceinline__ uint64_t upd_apply8(uint64_t v, uint64_t r, float uf) {
+  uint64_t o = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int vk = (int)((v >> (8 * k)) & 255), rk = (int)(int8_t)(r >> (8 * k));
+    o |= (uint64_t)upd_one(vk, rk, uf) << (8 * k);
+  }
+  return o;
+}
+// One side's contribution to targets (ty, tx0 .. tx0+7).  SEQ = false: the sources OR-ed into one run (ovl reports a target with
+// two sources); SEQ = true: v updated block after block.
+template <bool SEQ>
+__device__ __forceinline__ uint64_t upd_side(const UpdSrc& s, int ty, int tx0, int R, float uf, uint64_t v, bool& ovl) {
+  const int bs = 1 << s.lbs;
+  const int by_lo = imax((ty - R) >> s.lbs, 0), by_hi = imin((ty + R) >> s.lbs, s.nby - 1);
+  const int bx_lo = imax((tx0 - R) >> s.lbs, 0), bx_hi = imin((tx0 + 7 + R) >> s.lbs, s.nbx - 1);
+  uint64_t acc = 0, accm = 0, clash = 0;
+  for (int by = by_lo; by <= by_hi; by++)
+    for (int bx = bx_lo; bx <= bx_hi; bx++) {
+      const int o = by * s.BX + bx;
+      const int sy = ty - s.mvy[o], sx0 = tx0 - s.mvx[o], b0 = bx << s.lbs;
+      const int lo = imax(0, b0 - sx0), hi = imin(8, imin(b0 + bs, s.Ws) - sx0);
+      if ((sy >> s.lbs) == by && sy < s.Hs && lo < hi) {
+        const uint64_t m = run_mask(lo, hi);
+        const uint64_t r = (ld8(s.high + (size_t)sy * s.stride + sx0) ^ 0x8080808080808080ull) & m;
+        if (SEQ) v = upd_apply8(v, r, uf);
+        else { clash |= accm & m; acc |= r; accm |= m; }
+      }
+    }
+  if (SEQ) return v;
+  ovl = clash != 0;
+  return acc;
+}
+__device__ __forceinline__ uint64_t upd_run(const UpdSrc& s, int ty, int tx0, int R, float uf, uint64_t v) {
+  bool ovl;
+  const uint64_t r = upd_side<false>(s, ty, tx0, R, uf, v, ovl);
+  if (ovl) return upd_side<true>(s, ty, tx0, R, uf, v, ovl);
+  return upd_apply8(v, r, uf);
+}
+__device__ __forceinline__ UpdSrc upd_src_luma(const LevelGeom& g, const UpdSide& sd) {
+  UpdSrc s;
+  s.high = sd.high; s.stride = g.W; s.Hs = g.H; s.Ws = g.W; s.mvx = sd.mvx; s.mvy = sd.mvy;
+  s.BX = g.BX; s.lbs = 31 - __builtin_clz(g.bs); s.nby = g.BY; s.nbx = g.BX;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// luma: a lane per run of 8 targets; picture-border cells are written by k_upd_luma_border afterwards
+__global__ void __launch_bounds__(256) k_upd_luma_run(UpdArgs a) {
+  const LevelGeom& g = a.g;
+  const int tx0 = (blockIdx.x * 64 + threadIdx.x) * 8, ty = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
+  if (tx0 >= g.W || ty >= g.H) return;
+  UpdSide sd[2];
+  upd_sides(a, j, sd);
+  uint64_t v = ld8(frame_y(a.frames, g, a.src_mul * j) + (size_t)ty * g.W + tx0);
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+    if (sd[q].high) v = upd_run(upd_src_luma(g, sd[q]), ty, tx0, a.reach, a.uf, v);
+  *(uint2*)(a.low + (size_t)(a.dst_mul * j) * g.F + (size_t)ty * g.W + tx0) = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+// the 2 W + 2 (H - 2) cells of the picture's border: everything clip() folds onto them, in order (update_gather)
+__global__ void __launch_bounds__(256) k_upd_luma_border(UpdArgs a) {
+  const LevelGeom& g = a.g;
+  const int k = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  int y, x;
+  if (k < g.W) { y = 0; x = k; }
+  else if (k < 2 * g.W) { y = g.H - 1; x = k - g.W; }
+  else if (k < 2 * g.W + (g.H - 2)) { y = 1 + k - 2 * g.W; x = 0; }
+  else if (k < 2 * g.W + 2 * (g.H - 2)) { y = 1 + k - 2 * g.W - (g.H - 2); x = g.W - 1; }
+  else return;
+  UpdSide sd[2];
+  upd_sides(a, j, sd);
+  if (!sd[0].high && !sd[1].high) return;  // k_upd_luma_run has copied the cell
+  int v = frame_y(a.frames, g, a.src_mul * j)[(size_t)y * g.W + x];
+  for (int q = 0; q < 2; q++)
+    if (sd[q].high) {
+      const uint8_t* h = sd[q].high;
+      auto R = [&](int sy, int sx) { return (int)h[(size_t)sy * g.W + sx] - 128; };
+      v = update_gather(v, R, sd[q].mvx, sd[q].mvy, g.BY, g.BX, g.bs, g.H, g.W, g.H, g.W, a.reach, y, x, a.uf);
+    }
+  a.low[(size_t)(a.dst_mul * j) * g.F + (size_t)y * g.W + x] = (uint8_t)v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// chroma: one 64 x 14 tile of one stored component per workgroup (only tiles an update can reach; the others were copied)
+__global__ void __launch_bounds__(256) k_upd_chroma_run(UpdArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t sP[PCT_FH][PCT_FW];
+  __shared__ __attribute__((aligned(16))) uint32_t sL[PCT_FH][PCT_W / 2];
+  const LevelGeom& g = a.g;
+  const int tid = threadIdx.x;
+  const int j = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
+  const int i0 = blockIdx.x * PCT_W, j0 = blockIdx.y * PCT_H;
+  const int cw = g.W >> 1, chh = g.H >> 1;
+  const int xb = 2 * i0 - 8, yb = 2 * j0 - 2;
+  UpdSide sd[2];
+  upd_sides(a, j, sd);
+  if ((!sd[0].high && !sd[1].high) || yb >= chh + a.reach || 2 * i0 - 2 >= cw + a.reach) return;  // workgroup-uniform
+  const size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh;
+  const uint8_t* u = frame_c(a.frames, g, a.src_mul * j, c);
+  UpdSrc s[2];
+  const int lbs = 31 - __builtin_clz(g.bs);
+  for (int q = 0; q < 2; q++) {
+    s[q].high = sd[q].high ? sd[q].high + coff : nullptr; s[q].stride = cw; s[q].Hs = chh; s[q].Ws = cw;
+    s[q].mvx = sd[q].mvx; s[q].mvy = sd[q].mvy; s[q].BX = g.BX; s[q].lbs = lbs;
+    s[q].nby = imin(g.BY, ((chh - 1) >> lbs) + 1); s[q].nbx = imin(g.BX, ((cw - 1) >> lbs) + 1);
+  }
+  // A. the footprint: interpolated stored chroma (update.cpp:472-503), then both sides' updates
+  for (int k = tid; k < PCT_FH * (PCT_FW / 8); k += 256) {
+    const int ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
+    uint64_t v = 0;
+    if ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) {
+      v = chroma_run8(u, g, yy, xx);
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (s[q].high) v = upd_run(s[q], yy, xx, a.reach, a.uf, v);
+    }
+    *(uint64_t*)&sP[ry][8 * run] = v;
+  }
+  __syncthreads();
+  // cells on the picture's border: the ordered gather over everything that clips onto them
+  {
+    auto border_cell = [&](int y, int x) {
+      int v = chroma_up(u, y, x, g.H, g.W);
+      for (int q = 0; q < 2; q++)
+        if (s[q].high) {
+          const uint8_t* h = s[q].high;
+          auto R = [&](int sy, int sx) { return (int)h[(size_t)sy * cw + sx] - 128; };
+          v = update_gather(v, R, s[q].mvx, s[q].mvy, g.BY, g.BX, g.bs, g.H, g.W, chh, cw, a.reach, y, x, a.uf);
+        }
+      sP[y - yb][x - xb] = (uint8_t)v;
+    };
+    for (int e = 0; e < 2; e++) {  // picture rows 0 and H-1
+      const int y = e ? g.H - 1 : 0, x = xb + tid;
+      if (y >= yb && y < yb + PCT_FH && tid < PCT_FW && x >= 0 && x < g.W) border_cell(y, x);
+    }
+    for (int e = 0; e < 2; e++) {  // picture columns 0 and W-1 (corners are done)
+      const int x = e ? g.W - 1 : 0, y = yb + tid;
+      if (x >= xb && x < xb + PCT_FW && tid < PCT_FH && y > 0 && y < g.H - 1) border_cell(y, x);
+    }
+  }
+  __syncthreads();
+  chroma_tile_lows(sP, sL, g, i0, xb, yb, tid);
+  if (tid < PCT_H * (PCT_W / 4)) {
+    const int jr = tid / (PCT_W / 4), gq = tid % (PCT_W / 4), cj = j0 + jr, ci = i0 + 4 * gq;
+    if (cj < chh && ci < cw) {
+      uint32_t ll[2];
+      chroma_tile_ll(sL, jr, gq, ll);
+      *(uint32_t*)(a.low + (size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci) = __builtin_amdgcn_perm(ll[1], ll[0], 0x06040200u);  // Q4 wrap
+    }
+  }
+}
+
+bool upd_run_applies(const UpdArgs& a) {
+  const LevelGeom& g = a.g;
+  return g.bs >= 8 && (g.bs & (g.bs - 1)) == 0 && g.W % 8 == 0 && g.H % 2 == 0 && g.H % g.bs == 0 && g.W % g.bs == 0 && g.H >= 8 && g.W >= 16 &&
+         a.reach <= 255;
+}
+void launch_update_run(hipStream_t st, const UpdArgs& a) {
+  const LevelGeom& g = a.g;
+  hipLaunchKernelGGL(k_upd_luma_run, dim3((g.W + 511) / 512, (g.H + 3) / 4, g.nB + 1), dim3(64, 4), 0, st, a);
+  hipLaunchKernelGGL(k_upd_luma_border, dim3((2 * g.W + 2 * (g.H - 2) + 255) / 256, g.nB + 1), dim3(256), 0, st, a);
+  // chroma: only the tiles an update can reach -- outputs whose footprint lies within `reach` of the top-left quadrant (Q3)
+  const int cw = g.W / 2, chh = g.H / 2;
+  const int gx = (cw + PCT_W - 1) / PCT_W, gy = (chh + PCT_H - 1) / PCT_H;
+  const int tx = imin(gx, ((cw + a.reach + 2) / 2 + PCT_W - 1) / PCT_W + 1), ty = imin(gy, ((chh + a.reach + 2) / 2 + PCT_H - 1) / PCT_H + 1);
+  hipLaunchKernelGGL(k_upd_chroma_run, dim3(tx, ty, (g.nB + 1) * 2), dim3(256), 0, st, a);
+}
+
+}  // namespace qsvc

@@ -461,7 +461,7 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   a.cup = nullptr;
   Prof pf;
   pf.begin(c, "update");
-  if ((r = make_cup(c, g, a.frames, a.src_mul, &a.cup))) return r;
+  if (!upd_fast_path(a) && (r = make_cup(c, g, a.frames, a.src_mul, &a.cup))) return r;
   launch_update(c->st, a);
   pf.end(c);
   c->cup_src = nullptr;  // low_t was written: nothing interpolated from pictures may be reused across this point
@@ -527,7 +527,7 @@ int qsvc_un_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   a.cup = nullptr;
   Prof pf;
   pf.begin(c, "un_update");
-  if ((r = make_cup(c, g, a.frames, a.src_mul, &a.cup))) return r;
+  if (!upd_fast_path(a) && (r = make_cup(c, g, a.frames, a.src_mul, &a.cup))) return r;
   launch_update(c->st, a);
   pf.end(c);
   c->cup_src = nullptr;
