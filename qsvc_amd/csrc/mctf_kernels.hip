@@ -22,18 +22,27 @@ __device__ __forceinline__ uint64_t ld8u(const uint8_t* p) {  // unaligned 8-byt
 // ME pyramid level: thread per coefficient, 64x4 tile per workgroup (row-contiguous stores).
 template <class T>
 __global__ void __launch_bounds__(256) k_pyr_level(const T* src, size_t src_pic_stride, int src_row_stride, int16_t* dst,
-                                                    size_t dst_pic_stride, int H, int W, int l, int R, int C) {
-  int x = blockIdx.x * 64 + threadIdx.x;
-  int y = blockIdx.y * 4 + threadIdx.y;
+                                                    size_t dst_pic_stride, int H, int W, int l, int R, int C, int ox, int oy) {
+  int x = ox + blockIdx.x * 64 + threadIdx.x;
+  int y = oy + blockIdx.y * 4 + threadIdx.y;
   pyr_thread<T>(src, src_pic_stride, src_row_stride, dst, dst_pic_stride, H, W, l, R, C, x, y, blockIdx.z);
 }
 void launch_pyr_level_u8(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int P, int R, int C) {
-  dim3 grid((C + 63) / 64, (R + 3) / 4, P), block(64, 4);
-  hipLaunchKernelGGL(k_pyr_level<uint8_t>, grid, block, 0, st, frames, F, W, dst, (size_t)H * W, H, W, 1, R, C);
+  dim3 block(64, 4);
+  if (pyr_tile_applies(W, H) && getenv("QSVC_PYR_TILE") == nullptr) {
+    // the LL quadrant out of LDS tiles (mctf_pyr.hip); what a block window reads beyond it, coefficient by coefficient
+    const int Rl = imin(R, H / 2), Cl = imin(C, W / 2);
+    launch_pyr_ll_tile(st, frames, F, W, H, dst, P, Rl, Cl);
+    if (R > Rl) hipLaunchKernelGGL(k_pyr_level<uint8_t>, dim3((C + 63) / 64, (R - Rl + 3) / 4, P), block, 0, st, frames, F, W, dst, (size_t)H * W, H, W, 1, R, C, 0, Rl);
+    if (C > Cl) hipLaunchKernelGGL(k_pyr_level<uint8_t>, dim3((C - Cl + 63) / 64, (Rl + 3) / 4, P), block, 0, st, frames, F, W, dst, (size_t)H * W, H, W, 1, Rl, C, Cl, 0);
+    return;
+  }
+  dim3 grid((C + 63) / 64, (R + 3) / 4, P);
+  hipLaunchKernelGGL(k_pyr_level<uint8_t>, grid, block, 0, st, frames, F, W, dst, (size_t)H * W, H, W, 1, R, C, 0, 0);
 }
 void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int l, int R, int C) {
   dim3 grid((C + 63) / 64, (R + 3) / 4, P), block(64, 4);
-  hipLaunchKernelGGL(k_pyr_level<int16_t>, grid, block, 0, st, src, (size_t)H * W, W, dst, (size_t)H * W, H, W, l, R, C);
+  hipLaunchKernelGGL(k_pyr_level<int16_t>, grid, block, 0, st, src, (size_t)H * W, W, dst, (size_t)H * W, H, W, l, R, C, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
