@@ -38,15 +38,29 @@ __global__ void __launch_bounds__(256) k_pred_luma_run(PredArgs a) {
     const size_t fld = (size_t)g.BY * g.BX;
     const int lbs = 31 - __builtin_clz(g.bs);  // block size is a power of two on this path
     const int bx = x >> lbs;
+    // the four rows' requests are issued together: vectors, then the three runs of every row, then the arithmetic
+    int yv[4], mv4[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      yv[rr] = imin(blockIdx.y * 16 + rr * 4 + threadIdx.y, g.H - 1);
+      const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)(yv[rr] >> lbs) * g.BX + bx;
+      mv4[rr][0] = m[0]; mv4[rr][1] = m[fld]; mv4[rr][2] = m[2 * fld]; mv4[rr][3] = m[3 * fld];
+    }
+    uint64_t l0[4], l1[4], ov[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      l0[rr] = luma_run8_ld(r0, g, yv[rr] + mv4[rr][1], x + mv4[rr][0]);
+      l1[rr] = luma_run8_ld(r1, g, yv[rr] + mv4[rr][3], x + mv4[rr][2]);
+      ov[rr] = ld8(od + (size_t)yv[rr] * g.W + x);
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
       const int y = blockIdx.y * 16 + rr * 4 + threadIdx.y;
       if (y >= g.H) break;
-      const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)(y >> lbs) * g.BX + bx;
-      const uint64_t p0 = luma_run8(r0, g, y + m[fld], x + m[0]);
-      const uint64_t p1 = luma_run8(r1, g, y + m[3 * fld], x + m[2 * fld]);
+      const uint64_t p0 = luma_run8_fin(l0[rr], r0, g, y + mv4[rr][1], x + mv4[rr][0]);
+      const uint64_t p1 = luma_run8_fin(l1[rr], r1, g, y + mv4[rr][3], x + mv4[rr][2]);
       const uint64_t p = avg8(p0, p1);                                   // decorrelate.cpp:99-107
-      const uint64_t o = ld8(od + (size_t)y * g.W + x);
+      const uint64_t o = ov[rr];
       const uint32_t h0 = residue4((uint32_t)o, (uint32_t)p), h1 = residue4((uint32_t)(o >> 32), (uint32_t)(p >> 32));
       const size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
       *(uint2*)(a.high + off) = make_uint2(h0, h1);
@@ -85,17 +99,36 @@ __global__ void __launch_bounds__(256) k_pred_chroma_run(PredArgs a) {
   const int lbs = 31 - __builtin_clz(g.bs);
   const uint8_t* u0 = frame_c(a.frames, g, 2 * i, c);
   const uint8_t* u1 = frame_c(a.frames, g, 2 * i + 2, c);
-  // A. full-resolution prediction of the footprint, one run per task
-  for (int k = tid; k < PCT_FH * (PCT_FW / 8); k += 256) {
-    const int ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
+  // A. full-resolution prediction of the footprint, one run per task; a thread's (up to three) tasks have their requests in
+  // flight together: vectors, then the two stored rows of both references, then the arithmetic
+  constexpr int NT = (PCT_FH * (PCT_FW / 8) + 255) / 256;
+  int ty_[NT], tx_[NT], mv4[NT][4];
+  bool in_[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int k = tid + 256 * t, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8);
+    ty_[t] = yb + ry; tx_[t] = xb + 8 * run;
+    in_[t] = k < PCT_FH * (PCT_FW / 8) && (unsigned)ty_[t] < (unsigned)g.H && (unsigned)tx_[t] < (unsigned)g.W;
+    const int16_t* m = a.mv + (size_t)i * 4 * fld + (in_[t] ? (size_t)(ty_[t] >> lbs) * g.BX + (tx_[t] >> lbs) : (size_t)0);
+    mv4[t][0] = m[0]; mv4[t][1] = m[fld]; mv4[t][2] = m[2 * fld]; mv4[t][3] = m[3 * fld];
+  }
+  ChromaLd c0[NT], c1[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    c0[t] = chroma_run8_ld(u0, g, ty_[t] + mv4[t][1], tx_[t] + mv4[t][0]);
+    c1[t] = chroma_run8_ld(u1, g, ty_[t] + mv4[t][3], tx_[t] + mv4[t][2]);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int k = tid + 256 * t;
+    if (k >= PCT_FH * (PCT_FW / 8)) break;
     uint64_t p = 0;
-    if ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) {
-      const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)(yy >> lbs) * g.BX + (xx >> lbs);
-      const uint64_t p0 = chroma_run8(u0, g, yy + m[fld], xx + m[0]);
-      const uint64_t p1 = chroma_run8(u1, g, yy + m[3 * fld], xx + m[2 * fld]);
+    if (in_[t]) {
+      const uint64_t p0 = chroma_run8_fin(c0[t], u0, g, ty_[t] + mv4[t][1], tx_[t] + mv4[t][0]);
+      const uint64_t p1 = chroma_run8_fin(c1[t], u1, g, ty_[t] + mv4[t][3], tx_[t] + mv4[t][2]);
       p = avg8(p0, p1);
     }
-    *(uint64_t*)&sP[ry][8 * run] = p;
+    *(uint64_t*)&sP[k / (PCT_FW / 8)][8 * (k % (PCT_FW / 8))] = p;
   }
   __syncthreads();
   chroma_tile_lows(sP, sL, g, i0, xb, yb, tid);

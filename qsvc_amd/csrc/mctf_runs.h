@@ -31,21 +31,38 @@ __device__ __forceinline__ uint64_t ld8(const uint8_t* p) { uint64_t v; __builti
 __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return (a & b) + (((a ^ b) & 0xFEFEFEFEu) >> 1); }  // per byte (a + b) >> 1
 __device__ __forceinline__ uint64_t avg8(uint64_t a, uint64_t b) { return (a & b) + (((a ^ b) & 0xFEFEFEFEFEFEFEFEull) >> 1); }
 
-// 8 samples of a row of the luma plane displaced by a vector, replicate border (Q1/Q2) when the run leaves the picture
-__device__ __forceinline__ uint64_t luma_run8(const uint8_t* r, const LevelGeom& g, int y, int x) {
-  if ((unsigned)y < (unsigned)g.H && x >= 0 && x + 8 <= g.W) return ld8(r + (size_t)y * g.W + x);
+// 8 samples of a row of the luma plane displaced by a vector, replicate border (Q1/Q2) when the run leaves the picture.
+// Two steps so that a caller can have the loads of several runs in flight: *_ld issues the load at a clamped (always valid)
+// position, *_fin returns it when the run lies inside the picture and walks the border rule otherwise.
+__device__ __forceinline__ bool luma_run8_in(const LevelGeom& g, int y, int x) { return (unsigned)y < (unsigned)g.H && x >= 0 && x + 8 <= g.W; }
+__device__ __forceinline__ uint64_t luma_run8_ld(const uint8_t* r, const LevelGeom& g, int y, int x) {
+  return ld8(r + (size_t)iclamp(y, 0, g.H - 1) * g.W + iclamp(x, 0, g.W - 8));
+}
+__device__ __forceinline__ uint64_t luma_run8_fin(uint64_t ld, const uint8_t* r, const LevelGeom& g, int y, int x) {
+  if (luma_run8_in(g, y, x)) return ld;
   const BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);
   uint64_t v = 0;
   for (int k = 0; k < 8; k++) v |= (uint64_t)luma_b(r, bg, y, x + k) << (8 * k);
   return v;
 }
-// 8 samples (y, x .. x+7) of the x2-interpolated chroma plane, computed from the stored half-resolution plane u
-__device__ __forceinline__ uint64_t chroma_run8(const uint8_t* u, const LevelGeom& g, int y, int x) {
+__device__ __forceinline__ uint64_t luma_run8(const uint8_t* r, const LevelGeom& g, int y, int x) {
+  return luma_run8_fin(luma_run8_ld(r, g, y, x), r, g, y, x);
+}
+// 8 samples (y, x .. x+7) of the x2-interpolated chroma plane, computed from the stored half-resolution plane u: the two stored
+// rows an output row is the mean of (odd rows; the last row repeats) -- same two-step form
+struct ChromaLd { uint64_t a, b; };
+__device__ __forceinline__ bool chroma_run8_in(const LevelGeom& g, int y, int x) { return (unsigned)y < (unsigned)g.H && x >= 0 && x + 8 < g.W; }
+__device__ __forceinline__ ChromaLd chroma_run8_ld(const uint8_t* u, const LevelGeom& g, int y, int x) {
   const int cw = g.W >> 1, chh = g.H >> 1;
-  if ((unsigned)y < (unsigned)g.H && x >= 0 && x + 8 < g.W) {
-    const int ja = y >> 1, jb = imin((y + 1) >> 1, chh - 1), k0 = x >> 1;  // odd rows: mean of two stored rows (the last row repeats)
-    const uint64_t a = ld8(u + (size_t)ja * cw + k0), b = ld8(u + (size_t)jb * cw + k0);
-    const uint64_t c = avg8(a, b);                                         // columns first (decorrelate.cpp:610-648)
+  const int yc = iclamp(y, 0, g.H - 1), k0 = iclamp(x, 0, g.W - 10) >> 1;
+  const int ja = yc >> 1, jb = imin((yc + 1) >> 1, chh - 1);
+  ChromaLd l;
+  l.a = ld8(u + (size_t)ja * cw + k0); l.b = ld8(u + (size_t)jb * cw + k0);
+  return l;
+}
+__device__ __forceinline__ uint64_t chroma_run8_fin(ChromaLd l, const uint8_t* u, const LevelGeom& g, int y, int x) {
+  if (chroma_run8_in(g, y, x)) {
+    const uint64_t c = avg8(l.a, l.b);                                     // columns first (decorrelate.cpp:610-648)
     const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32);
     const uint32_t cs = __builtin_amdgcn_alignbyte(c1, c0, 1);             // c[1..4]
     const uint32_t m = avg4(c0, cs);                                       // m[k] = (c[k] + c[k+1]) >> 1
@@ -58,6 +75,9 @@ __device__ __forceinline__ uint64_t chroma_run8(const uint8_t* u, const LevelGeo
   uint64_t v = 0;
   for (int k = 0; k < 8; k++) v |= (uint64_t)chroma_up_b(u, bg, y, x + k) << (8 * k);
   return v;
+}
+__device__ __forceinline__ uint64_t chroma_run8(const uint8_t* u, const LevelGeom& g, int y, int x) {
+  return chroma_run8_fin(chroma_run8_ld(u, g, y, x), u, g, y, x);
 }
 // clamp(o - p, -128, 127) + 128 of four samples
 __device__ __forceinline__ uint32_t residue4(uint32_t o, uint32_t p) {

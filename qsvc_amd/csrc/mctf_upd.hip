@@ -62,11 +62,76 @@ __device__ __forceinline__ uint64_t upd_side(const UpdSrc& s, int ty, int tx0, i
   ovl = clash != 0;
   return acc;
 }
-__device__ __forceinline__ uint64_t upd_run(const UpdSrc& s, int ty, int tx0, int R, float uf, uint64_t v) {
-  bool ovl;
-  const uint64_t r = upd_side<false>(s, ty, tx0, R, uf, v, ovl);
-  if (ovl) return upd_side<true>(s, ty, tx0, R, uf, v, ovl);
-  return upd_apply8(v, r, uf);
+// The same collection for NS sides at once with the memory requests batched: per block row, the NX candidates' vectors of every
+// side are loaded together, then their NX source runs (unconditionally, at a harmless address when the candidate misses), then
+// everything is masked and OR-ed -- two round trips to memory per block row instead of two per candidate.
+template <int NX, int NS>
+__device__ __forceinline__ void upd_collect(const UpdSrc* s, int ty, int tx0, int R, uint64_t* acc, bool* ovl) {
+  const int lbs = s[0].lbs, bs = 1 << lbs;
+  const int by_lo = imax((ty - R) >> lbs, 0), by_hi = imin((ty + R) >> lbs, s[0].nby - 1);
+  const int bx_lo = imax((tx0 - R) >> lbs, 0), bx_hi = imin((tx0 + 7 + R) >> lbs, s[0].nbx - 1);
+  uint64_t accm[NS], clash[NS];
+#pragma unroll
+  for (int q = 0; q < NS; q++) { acc[q] = 0; accm[q] = 0; clash[q] = 0; }
+  for (int by = by_lo; by <= by_hi; by++) {
+    int dy[NS][NX], dx[NS][NX];
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+      for (int b = 0; b < NX; b++) {
+        const int o = by * s[q].BX + imin(bx_lo + b, s[q].nbx - 1);
+        dy[q][b] = s[q].mvy[o]; dx[q][b] = s[q].mvx[o];
+      }
+    uint64_t r[NS][NX], m[NS][NX];
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+      for (int b = 0; b < NX; b++) {
+        const int sy = ty - dy[q][b], sx0 = tx0 - dx[q][b], b0 = (bx_lo + b) << lbs;
+        const int lo = imax(0, b0 - sx0), hi = imin(8, imin(b0 + bs, s[q].Ws) - sx0);
+        const bool ok = bx_lo + b <= bx_hi && (sy >> lbs) == by && sy < s[q].Hs && lo < hi;
+        m[q][b] = ok ? run_mask(lo, hi) : 0ull;
+        r[q][b] = ld8(s[q].high + (ok ? (size_t)sy * s[q].stride + sx0 : (size_t)0));
+      }
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+      for (int b = 0; b < NX; b++) {
+        clash[q] |= accm[q] & m[q][b];
+        acc[q] |= (r[q][b] ^ 0x8080808080808080ull) & m[q][b];
+        accm[q] |= m[q][b];
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < NS; q++) ovl[q] = clash[q] != 0;
+}
+// both sides of the update of targets (ty, tx0 .. tx0+7), in the reference's order: side 0, then side 1 (absent sides: high == nullptr).
+// NX = the most block columns a run's sources can come from (0: unknown, candidate by candidate)
+template <int NX>
+__device__ __forceinline__ uint64_t upd_run(const UpdSrc* s, int ty, int tx0, int R, float uf, uint64_t v) {
+  uint64_t acc[2] = {0, 0};
+  bool ovl[2] = {false, false};
+  const bool h0 = s[0].high != nullptr, h1 = s[1].high != nullptr;  // wave-uniform
+  if (NX == 0) {
+    if (h0) acc[0] = upd_side<false>(s[0], ty, tx0, R, uf, v, ovl[0]);
+    if (h1) acc[1] = upd_side<false>(s[1], ty, tx0, R, uf, v, ovl[1]);
+  } else if (h0 && h1) upd_collect<NX ? NX : 1, 2>(s, ty, tx0, R, acc, ovl);
+  else if (h0) upd_collect<NX ? NX : 1, 1>(s, ty, tx0, R, acc, ovl);
+  else if (h1) upd_collect<NX ? NX : 1, 1>(s + 1, ty, tx0, R, acc + 1, ovl + 1);
+  if (h0) v = ovl[0] ? upd_side<true>(s[0], ty, tx0, R, uf, v, ovl[0]) : upd_apply8(v, acc[0], uf);
+  if (h1) v = ovl[1] ? upd_side<true>(s[1], ty, tx0, R, uf, v, ovl[1]) : upd_apply8(v, acc[1], uf);
+  return v;
+}
+// the most block columns the sources of a run of 8 targets can come from (host side)
+static int upd_max_cols(int bs, int R) {
+  int lbs = 0;
+  while ((1 << (lbs + 1)) <= bs) lbs++;
+  int best = 1;
+  for (int c = 0; c < bs / 8 + 1; c++) {
+    const int lo = 8 * c + 1024 - R, hi = 8 * c + 1024 + 7 + R;  // offset by a multiple of every block size: shifts of non-negative numbers
+    best = imax(best, (hi >> lbs) - (lo >> lbs) + 1);
+  }
+  return best;
 }
 __device__ __forceinline__ UpdSrc upd_src_luma(const LevelGeom& g, const UpdSide& sd) {
   UpdSrc s;
@@ -77,6 +142,7 @@ __device__ __forceinline__ UpdSrc upd_src_luma(const LevelGeom& g, const UpdSide
 
 // ---------------------------------------------------------------------------------------------
 // luma: a lane per run of 8 targets; picture-border cells are written by k_upd_luma_border afterwards
+template <int NX>
 __global__ void __launch_bounds__(256) k_upd_luma_run(UpdArgs a) {
   const LevelGeom& g = a.g;
   const int tx0 = (blockIdx.x * 64 + threadIdx.x) * 8, ty = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
@@ -84,9 +150,8 @@ __global__ void __launch_bounds__(256) k_upd_luma_run(UpdArgs a) {
   UpdSide sd[2];
   upd_sides(a, j, sd);
   uint64_t v = ld8(frame_y(a.frames, g, a.src_mul * j) + (size_t)ty * g.W + tx0);
-#pragma unroll
-  for (int q = 0; q < 2; q++)
-    if (sd[q].high) v = upd_run(upd_src_luma(g, sd[q]), ty, tx0, a.reach, a.uf, v);
+  const UpdSrc s[2] = {upd_src_luma(g, sd[0]), upd_src_luma(g, sd[1])};
+  if (sd[0].high || sd[1].high) v = upd_run<NX>(s, ty, tx0, a.reach, a.uf, v);
   *(uint2*)(a.low + (size_t)(a.dst_mul * j) * g.F + (size_t)ty * g.W + tx0) = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 // the 2 W + 2 (H - 2) cells of the picture's border: everything clip() folds onto them, in order (update_gather)
@@ -114,6 +179,7 @@ __global__ void __launch_bounds__(256) k_upd_luma_border(UpdArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // chroma: one 64 x 14 tile of one stored component per workgroup (only tiles an update can reach; the others were copied)
+template <int NX>
 __global__ void __launch_bounds__(256) k_upd_chroma_run(UpdArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t sP[PCT_FH][PCT_FW];
   __shared__ __attribute__((aligned(16))) uint32_t sL[PCT_FH][PCT_W / 2];
@@ -140,10 +206,7 @@ __global__ void __launch_bounds__(256) k_upd_chroma_run(UpdArgs a) {
     const int ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
     uint64_t v = 0;
     if ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) {
-      v = chroma_run8(u, g, yy, xx);
-#pragma unroll
-      for (int q = 0; q < 2; q++)
-        if (s[q].high) v = upd_run(s[q], yy, xx, a.reach, a.uf, v);
+      v = upd_run<NX>(s, yy, xx, a.reach, a.uf, chroma_run8(u, g, yy, xx));
     }
     *(uint64_t*)&sP[ry][8 * run] = v;
   }
@@ -188,13 +251,26 @@ bool upd_run_applies(const UpdArgs& a) {
 }
 void launch_update_run(hipStream_t st, const UpdArgs& a) {
   const LevelGeom& g = a.g;
-  hipLaunchKernelGGL(k_upd_luma_run, dim3((g.W + 511) / 512, (g.H + 3) / 4, g.nB + 1), dim3(64, 4), 0, st, a);
+  const int nx = upd_max_cols(g.bs, a.reach);
+  const dim3 lgrid((g.W + 511) / 512, (g.H + 3) / 4, g.nB + 1), lblock(64, 4);
+  switch (nx) {
+    case 2: hipLaunchKernelGGL(k_upd_luma_run<2>, lgrid, lblock, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(k_upd_luma_run<3>, lgrid, lblock, 0, st, a); break;
+    case 5: hipLaunchKernelGGL(k_upd_luma_run<5>, lgrid, lblock, 0, st, a); break;
+    default: hipLaunchKernelGGL(k_upd_luma_run<0>, lgrid, lblock, 0, st, a); break;
+  }
   hipLaunchKernelGGL(k_upd_luma_border, dim3((2 * g.W + 2 * (g.H - 2) + 255) / 256, g.nB + 1), dim3(256), 0, st, a);
   // chroma: only the tiles an update can reach -- outputs whose footprint lies within `reach` of the top-left quadrant (Q3)
   const int cw = g.W / 2, chh = g.H / 2;
   const int gx = (cw + PCT_W - 1) / PCT_W, gy = (chh + PCT_H - 1) / PCT_H;
   const int tx = imin(gx, ((cw + a.reach + 2) / 2 + PCT_W - 1) / PCT_W + 1), ty = imin(gy, ((chh + a.reach + 2) / 2 + PCT_H - 1) / PCT_H + 1);
-  hipLaunchKernelGGL(k_upd_chroma_run, dim3(tx, ty, (g.nB + 1) * 2), dim3(256), 0, st, a);
+  const dim3 cgrid(tx, ty, (g.nB + 1) * 2);
+  switch (nx) {
+    case 2: hipLaunchKernelGGL(k_upd_chroma_run<2>, cgrid, dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(k_upd_chroma_run<3>, cgrid, dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(k_upd_chroma_run<5>, cgrid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_upd_chroma_run<0>, cgrid, dim3(256), 0, st, a); break;
+  }
 }
 
 }  // namespace qsvc
