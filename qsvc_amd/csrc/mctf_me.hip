@@ -26,12 +26,16 @@ template <> struct MePiece<uint8_t> {
       p[r][0] = (uint32_t)v; p[r][1] = (uint32_t)(v >> 32);
     }
   }
-  // row of the reference window: w[0] = samples -1..6, w[1] = 0..7, w[2] = 1..8
-  __device__ __forceinline__ void load_row(const uint8_t* s, uint32_t off, uint32_t w[3][2]) const {
-    uint64_t a, e;
-    __builtin_memcpy(&a, s + off, 8);
-    __builtin_memcpy(&e, s + off + 2, 8);
-    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), e0 = (uint32_t)e, e1 = (uint32_t)(e >> 32);
+  // row of the reference window: w[0] = samples -1..6, w[1] = 0..7, w[2] = 1..8 (two steps: the loads of several rows in flight)
+  struct Raw { uint64_t a, e; };
+  __device__ __forceinline__ Raw load_raw(const uint8_t* s, uint32_t off) const {
+    Raw r;
+    __builtin_memcpy(&r.a, s + off, 8);
+    __builtin_memcpy(&r.e, s + off + 2, 8);
+    return r;
+  }
+  __device__ __forceinline__ void windows(const Raw& r, uint32_t w[3][2]) const {
+    const uint32_t a0 = (uint32_t)r.a, a1 = (uint32_t)(r.a >> 32), e0 = (uint32_t)r.e, e1 = (uint32_t)(r.e >> 32);
     w[0][0] = a0; w[0][1] = a1;
     w[1][0] = __builtin_amdgcn_alignbyte(a1, a0, 1); w[1][1] = __builtin_amdgcn_alignbyte(e1, e0, 3);
     w[2][0] = e0; w[2][1] = e1;
@@ -54,10 +58,15 @@ template <> struct MePiece<int16_t> {
       for (int k = 0; k < 4; k++) p[r][k] = v.w[k] ^ 0x80008000u;
     }
   }
-  __device__ __forceinline__ void load_row(const int16_t* s, uint32_t off, uint32_t w[3][4]) const {
-    Q a, e;
-    __builtin_memcpy(&a, s + off, 16);      // samples -1..6
-    __builtin_memcpy(&e, s + off + 2, 16);  // samples 1..8
+  struct Raw { Q a, e; };
+  __device__ __forceinline__ Raw load_raw(const int16_t* s, uint32_t off) const {
+    Raw r;
+    __builtin_memcpy(&r.a, s + off, 16);      // samples -1..6
+    __builtin_memcpy(&r.e, s + off + 2, 16);  // samples 1..8
+    return r;
+  }
+  __device__ __forceinline__ void windows(const Raw& r, uint32_t w[3][4]) const {
+    Q a = r.a, e = r.e;
 #pragma unroll
     for (int k = 0; k < 4; k++) { a.w[k] ^= 0x80008000u; e.w[k] ^= 0x80008000u; }
 #pragma unroll
@@ -80,17 +89,24 @@ template <class T>
 __device__ __forceinline__ void me_piece_sums(const MePiece<T>& pc, const T* ref, int stride, int y, int x, int vy, int vx,
                                               uint32_t acc[3][3]) {
   uint32_t off = (uint32_t)((y + vy - 1) * stride + x + vx - 1);
+  constexpr int CH = sizeof(T) == 1 ? 10 : 5;  // window rows whose loads are in flight together
 #pragma unroll
-  for (int rr = -1; rr <= 8; rr++) {
-    uint32_t w[3][MePiece<T>::NW];
-    pc.load_row(ref, off, w);
-    off += (uint32_t)stride;
+  for (int c0 = -1; c0 <= 8; c0 += CH) {
+    typename MePiece<T>::Raw raw[CH];
 #pragma unroll
-    for (int wy = -1; wy <= 1; wy++) {
-      const int r = rr - wy;  // the piece's row that meets window row rr under vertical offset wy
-      if (r < 0 || r > 7) continue;
+    for (int q = 0; q < CH; q++) { raw[q] = pc.load_raw(ref, off); off += (uint32_t)stride; }
 #pragma unroll
-      for (int wx = 0; wx < 3; wx++) acc[wy + 1][wx] = pc.sad(r, w[wx], acc[wy + 1][wx]);
+    for (int q = 0; q < CH; q++) {
+      const int rr = c0 + q;
+      uint32_t w[3][MePiece<T>::NW];
+      pc.windows(raw[q], w);
+#pragma unroll
+      for (int wy = -1; wy <= 1; wy++) {
+        const int r = rr - wy;  // the piece's row that meets window row rr under vertical offset wy
+        if (r < 0 || r > 7) continue;
+#pragma unroll
+        for (int wx = 0; wx < 3; wx++) acc[wy + 1][wx] = pc.sad(r, w[wx], acc[wy + 1][wx]);
+      }
     }
   }
 }

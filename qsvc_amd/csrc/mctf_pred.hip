@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_pred_luma_run(PredArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // chroma: a workgroup produces a 64 x 14 tile of one half-resolution component.
-__global__ void __launch_bounds__(256) k_pred_chroma_run(PredArgs a) {
+__global__ void __launch_bounds__(PCT_T) k_pred_chroma_run(PredArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t sP[PCT_FH][PCT_FW];
   __shared__ __attribute__((aligned(16))) uint32_t sL[PCT_FH][PCT_W / 2];  // row-pass lows, two columns per word
   const LevelGeom& g = a.g;
@@ -101,12 +101,12 @@ __global__ void __launch_bounds__(256) k_pred_chroma_run(PredArgs a) {
   const uint8_t* u1 = frame_c(a.frames, g, 2 * i + 2, c);
   // A. full-resolution prediction of the footprint, one run per task; a thread's (up to three) tasks have their requests in
   // flight together: vectors, then the two stored rows of both references, then the arithmetic
-  constexpr int NT = (PCT_FH * (PCT_FW / 8) + 255) / 256;
+  constexpr int NT = (PCT_FH * (PCT_FW / 8) + PCT_T - 1) / PCT_T;
   int ty_[NT], tx_[NT], mv4[NT][4];
   bool in_[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
-    const int k = tid + 256 * t, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8);
+    const int k = tid + PCT_T * t, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8);
     ty_[t] = yb + ry; tx_[t] = xb + 8 * run;
     in_[t] = k < PCT_FH * (PCT_FW / 8) && (unsigned)ty_[t] < (unsigned)g.H && (unsigned)tx_[t] < (unsigned)g.W;
     const int16_t* m = a.mv + (size_t)i * 4 * fld + (in_[t] ? (size_t)(ty_[t] >> lbs) * g.BX + (tx_[t] >> lbs) : (size_t)0);
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_pred_chroma_run(PredArgs a) {
   }
 #pragma unroll
   for (int t = 0; t < NT; t++) {
-    const int k = tid + 256 * t;
+    const int k = tid + PCT_T * t;
     if (k >= PCT_FH * (PCT_FW / 8)) break;
     uint64_t p = 0;
     if (in_[t]) {
@@ -158,7 +158,7 @@ bool pred_run_applies(const PredArgs& a) {
 void launch_predict_run(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
   hipLaunchKernelGGL(k_pred_luma_run, dim3((g.W + 511) / 512, (g.H + 15) / 16, g.nB), dim3(64, 4), 0, st, a);
-  hipLaunchKernelGGL(k_pred_chroma_run, dim3((g.W / 2 + PCT_W - 1) / PCT_W, (g.H / 2 + PCT_H - 1) / PCT_H, g.nB * 2), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_pred_chroma_run, dim3((g.W / 2 + PCT_W - 1) / PCT_W, (g.H / 2 + PCT_H - 1) / PCT_H, g.nB * 2), dim3(PCT_T), 0, st, a);
 }
 
 }  // namespace qsvc

@@ -9,14 +9,14 @@
 
 namespace qsvc {
 
-__global__ void __launch_bounds__(256) k_pyr_ll_tile(const uint8_t* frames, size_t F, int W, int H, int16_t* dst, size_t dst_pic_stride, int R, int C) {
+__global__ void __launch_bounds__(PCT_T) k_pyr_ll_tile(const uint8_t* frames, size_t F, int W, int H, int16_t* dst, size_t dst_pic_stride, int R, int C) {
   __shared__ __attribute__((aligned(16))) uint8_t sP[PCT_FH][PCT_FW];
   __shared__ __attribute__((aligned(16))) uint32_t sL[PCT_FH][PCT_W / 2];
   const int tid = threadIdx.x, pic = blockIdx.z;
   const int i0 = blockIdx.x * PCT_W, j0 = blockIdx.y * PCT_H;
   const int xb = 2 * i0 - 8, yb = 2 * j0 - 2;
   const uint8_t* src = frames + (size_t)pic * F;
-  for (int k = tid; k < PCT_FH * (PCT_FW / 8); k += 256) {
+  for (int k = tid; k < PCT_FH * (PCT_FW / 8); k += PCT_T) {
     const int ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
     uint64_t v = 0;
     if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = *(const uint64_t*)(src + (size_t)yy * W + xx);
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) k_pyr_ll_tile(const uint8_t* frames, size
 bool pyr_tile_applies(int W, int H) { return W % 8 == 0 && H % 2 == 0 && W >= 16 && H >= 8; }
 // LL coefficients (rows < R, columns < C; R <= H/2, C <= W/2 rounded up to 4 by the caller within W/2) of level 1 of P pictures
 void launch_pyr_ll_tile(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int P, int R, int C) {
-  hipLaunchKernelGGL(k_pyr_ll_tile, dim3((C + PCT_W - 1) / PCT_W, (R + PCT_H - 1) / PCT_H, P), dim3(256), 0, st, frames, F, W, H, dst,
+  hipLaunchKernelGGL(k_pyr_ll_tile, dim3((C + PCT_W - 1) / PCT_W, (R + PCT_H - 1) / PCT_H, P), dim3(PCT_T), 0, st, frames, F, W, H, dst,
                      (size_t)H * W, R, C);
 }
 

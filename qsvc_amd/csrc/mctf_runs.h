@@ -89,11 +89,12 @@ __device__ __forceinline__ uint32_t residue4(uint32_t o, uint32_t p) {
 
 
 // ---------------------------------------------------------------------------------------------
-// chroma tile: a workgroup of 256 threads produces 64 x 14 half-resolution samples out of their full-resolution footprint
+// chroma tile: a workgroup of PCT_T threads produces 64 x 14 half-resolution samples out of their full-resolution footprint
 #define PCT_W 64                      // outputs per tile row
 #define PCT_H 14                      // output rows per tile
 #define PCT_FH (2 * PCT_H + 3)        // full-resolution rows 2 j0 - 2 .. 2 j0 + 2 PCT_H
 #define PCT_FW (2 * PCT_W + 16)       // full-resolution columns 2 i0 - 8 .. 2 i0 + 2 PCT_W + 7, in runs of 8
+#define PCT_T 576                     // threads per workgroup: one run of the footprint (31 x 18 = 558) per thread
 // sP (bytes, rows yb .., columns xb ..) -> sL: the row pass' low band, two adjacent columns per word.  Call with the footprint
 // written and a barrier passed; returns with sL complete (barrier included).
 __device__ __forceinline__ void chroma_tile_lows(uint8_t (*sP)[PCT_FW], uint32_t (*sL)[PCT_W / 2], const LevelGeom& g, int i0, int xb, int yb,
@@ -104,7 +105,7 @@ __device__ __forceinline__ void chroma_tile_lows(uint8_t (*sP)[PCT_FW], uint32_t
   if (xb + PCT_FW > g.W && g.W - xb >= 0 && tid >= 64 && tid < 64 + PCT_FH) sP[tid - 64][g.W - xb] = sP[tid - 64][g.W - xb - 2];
   __syncthreads();
   // B. row pass: lows of 4 outputs per task out of 4 words of the row
-  for (int k = tid; k < PCT_FH * (PCT_W / 4); k += 256) {
+  for (int k = tid; k < PCT_FH * (PCT_W / 4); k += PCT_T) {
     const int ry = k / (PCT_W / 4), gq = k % (PCT_W / 4), yy = yb + ry;
     if ((unsigned)yy >= (unsigned)g.H || i0 + 4 * gq >= cw) continue;
     const uint32_t* row = (const uint32_t*)&sP[ry][8 * gq + 4];

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) k_upd_luma_border(UpdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // chroma: one 64 x 14 tile of one stored component per workgroup (only tiles an update can reach; the others were copied)
 template <int NX>
-__global__ void __launch_bounds__(256) k_upd_chroma_run(UpdArgs a) {
+__global__ void __launch_bounds__(PCT_T) k_upd_chroma_run(UpdArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t sP[PCT_FH][PCT_FW];
   __shared__ __attribute__((aligned(16))) uint32_t sL[PCT_FH][PCT_W / 2];
   const LevelGeom& g = a.g;
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) k_upd_chroma_run(UpdArgs a) {
     s[q].nby = imin(g.BY, ((chh - 1) >> lbs) + 1); s[q].nbx = imin(g.BX, ((cw - 1) >> lbs) + 1);
   }
   // A. the footprint: interpolated stored chroma (update.cpp:472-503), then both sides' updates
-  for (int k = tid; k < PCT_FH * (PCT_FW / 8); k += 256) {
+  for (int k = tid; k < PCT_FH * (PCT_FW / 8); k += PCT_T) {
     const int ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
     uint64_t v = 0;
     if ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) {
@@ -266,10 +266,10 @@ void launch_update_run(hipStream_t st, const UpdArgs& a) {
   const int tx = imin(gx, ((cw + a.reach + 2) / 2 + PCT_W - 1) / PCT_W + 1), ty = imin(gy, ((chh + a.reach + 2) / 2 + PCT_H - 1) / PCT_H + 1);
   const dim3 cgrid(tx, ty, (g.nB + 1) * 2);
   switch (nx) {
-    case 2: hipLaunchKernelGGL(k_upd_chroma_run<2>, cgrid, dim3(256), 0, st, a); break;
-    case 3: hipLaunchKernelGGL(k_upd_chroma_run<3>, cgrid, dim3(256), 0, st, a); break;
-    case 5: hipLaunchKernelGGL(k_upd_chroma_run<5>, cgrid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(k_upd_chroma_run<0>, cgrid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_upd_chroma_run<2>, cgrid, dim3(PCT_T), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(k_upd_chroma_run<3>, cgrid, dim3(PCT_T), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(k_upd_chroma_run<5>, cgrid, dim3(PCT_T), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_upd_chroma_run<0>, cgrid, dim3(PCT_T), 0, st, a); break;
   }
 }
 
