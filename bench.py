@@ -162,10 +162,13 @@ def main():
     # (8 sessions x 8 workers x 8 ranks would be 512 threads); a caller's own setting wins
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     user_t2 = os.environ.get("QSVC_T2_THREADS")
-    os.environ.setdefault("QSVC_T2_THREADS", str(max(1, min(16 if S == 1 else 8, (os.cpu_count() or 8) // max(1, local_world * S)))))
+    ncpu = len(os.sched_getaffinity(0))  # the cores this process may use (a container's share, not the machine's count)
+    t2_timed = int(user_t2) if user_t2 else max(1, min(16 if S == 1 else 8, ncpu // max(1, local_world * S)))
     dev = os.environ.get("QSVC_BENCH_DEVICE")  # test hook: several ranks on one GPU (forces the host-staged exchange)
     devno = int(dev) if dev is not None else (local if world > 1 else 0)
     engs = [hip.Engine(devno) for _ in range(S)]
+    for e in engs:
+        e.set_tier2_threads(t2_timed)  # an explicit per-context setting (include/qsvc_hip.h), not an environment variable read mid-run
     eng = engs[0]
     real_exchange, exchange_kind = [None] * S, "none"
     if world > 1:
@@ -329,8 +332,10 @@ def main():
     if world == 1:  # ONE sequence alone on the chip: its latency, and every kernel group's ISOLATED duration (HIP events)
         if user_lds is None:
             os.environ.pop("QSVC_MQ_LDS", None)
-        if user_t2 is None:  # one sequence alone: its Tier-2 may use the cores the other sessions' would (read at every call)
-            os.environ["QSVC_T2_THREADS"] = str(max(1, min(16, (os.cpu_count() or 8) // max(1, local_world))))  # (16: 7.0 ms; 8: 7.6; 32: noisy)
+        t2_single = t2_timed
+        if user_t2 is None:  # one sequence alone: its Tier-2 may use the cores the other sessions' would
+            t2_single = max(1, min(16, ncpu // max(1, local_world)))  # (16: 7.0 ms; 8: 7.6; 32: noisy)
+            engs[0].set_tier2_threads(t2_single)
         step(0)
         engs[0].sync()
         engs[0].set_profiling(True)
@@ -426,7 +431,7 @@ def main():
                                    "64x64 code-blocks, SOP; clip=" + args.clip,
                        "pictures_per_step_total": pics_total, "sequences_in_flight_per_gpu": S,
                        "parallelism": f"gop-shard x{world}", "halo_exchange": exchange_kind,
-                       "tier2_threads_per_context": int(os.environ["QSVC_T2_THREADS"])},
+                       "tier2_threads_per_context": t2_timed, "host_cpus": len(os.sched_getaffinity(0))},
             "codeblocks_per_s": round(ncb_step * world * S * args.steps / dt, 1),
             "ebcot_codeblocks_per_s_kernel": round(ncb_step / (t1ms * 1e-3), 1) if t1ms else None,
             "codestream_bytes_per_step": int(nbytes), "codestream_bytes_per_step_all_sessions": int(sum(nbytes_of)), "mq_symbols_per_step": int(stats["symbols"]),
@@ -434,6 +439,7 @@ def main():
         }
         if serial_ms is not None:
             line["single_sequence"] = {"ms_per_encode": round(serial_ms, 3), "frames_per_s": round(17 / (serial_ms * 1e-3), 2),
+                                       "tier2_threads": t2_single,
                                        "kernels_ms_isolated": {k: round(v[0], 4) for k, v in iso.items()}}
         line["kernels_note"] = ("kernels{} are HIP-event durations on session 0's stream inside the timed region; with several sessions in "
                                 "flight kernels of different sessions overlap, so they do not sum to ms_per_step; host_stages{} are wall-clock "

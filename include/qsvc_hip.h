@@ -183,6 +183,12 @@ int qsvc_j2k_dwt(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, int reversib
  * share the transform (5/3 or 9/7).  Scope: one tile, LRCP, no precinct partition, code-block style 0. */
 int qsvc_j2k_decode_planes(qsvc_ctx* ctx, int nstreams, const uint8_t* const* streams, const size_t* lens, int max_layers,
                            void* out, size_t cap, size_t* offs, int* widths, int* heights);
+/* Host threads that write the code-streams of one qsvc_j2k_encode_* call (Tier-2: packet headers, tag trees, markers; the
+ * planes of a call are independent).  n >= 1 sets the count for this context; n = 0 returns to the default, which is the
+ * environment variable QSVC_T2_THREADS as it was when the context coded its first plane, else 8.  Never more threads than
+ * planes are used.  The reference runs one kdu_compress process per picture and component
+ * (texture_compress_fb_j2k.py:180-195); this is the knob for sharing a host's cores between several contexts. */
+int qsvc_set_tier2_threads(qsvc_ctx* ctx, int n);
 /* Statistics of the last qsvc_j2k_encode_* call: code-blocks coded, coding passes, MQ symbols. */
 int qsvc_j2k_stats(qsvc_ctx* ctx, uint64_t* codeblocks, uint64_t* passes, uint64_t* symbols);
 

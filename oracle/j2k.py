@@ -111,7 +111,11 @@ def own_decode(codestream: bytes, layers=0) -> np.ndarray:
     cs = bytes(codestream)
     W, H, prec, sg = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     # geometry first (SIZ is at a fixed place: SOC, SIZ marker, Lsiz, Rsiz, Xsiz, Ysiz)
+    if len(cs) < 44 or cs[:4] != b"\xff\x4f\xff\x51":
+        raise RuntimeError("not a JPEG 2000 code-stream (SOC/SIZ missing)")
     w, h = int.from_bytes(cs[8:12], "big"), int.from_bytes(cs[12:16], "big")
+    if not (1 <= w <= 16384 and 1 <= h <= 16384):
+        raise RuntimeError(f"code-stream announces a {w}x{h} picture")
     p16 = (cs[42] & 0x7F) + 1 > 8
     out = np.empty((h, w), dtype=np.int16 if p16 else np.uint8)
     r = _lib().qo_j2k_decode_plane(cs, len(cs), layers, out.ctypes.data, C.byref(W), C.byref(H), C.byref(prec), C.byref(sg))
@@ -141,3 +145,25 @@ def psnr(a, b) -> float:
     d = a.astype(np.float64) - b.astype(np.float64)
     m = float((d * d).mean())
     return 99.0 if m == 0 else 10 * np.log10(255.0 ** 2 / m)
+
+
+def corrupt_headers(cs: bytes):
+    """Malformed variants of a valid code-stream's main header (name, bytes): every one must be refused, none may crash."""
+    cs = bytes(cs)
+    cod = cs.index(b"\xff\x52")
+    qcd = cs.index(b"\xff\x5c")
+    sot = cs.index(b"\xff\x90")
+    out = []
+    out.append(("cut inside SIZ", cs[:30]))
+    out.append(("cut before SOT", cs[:sot]))
+    out.append(("Lsiz too short", cs[:4] + b"\x00\x0a" + cs[6:]))
+    out.append(("Lcod runs past the end", cs[:cod + 2] + b"\xff\xf0" + cs[cod + 4:]))
+    out.append(("code-block exponent 30", cs[:cod + 4 + 6] + b"\x1e" + cs[cod + 4 + 7:]))
+    out.append(("Lqcd too short for the subbands", cs[:qcd + 2] + b"\x00\x03" + cs[qcd + 4:qcd + 5] + cs[sot:]))
+    out.append(("zero width", cs[:8] + b"\x00\x00\x00\x00" + cs[12:]))
+    out.append(("width 1 << 20", cs[:8] + b"\x00\x10\x00\x00" + cs[12:]))
+    out.append(("zero layers", cs[:cod + 4 + 2] + b"\x00\x00" + cs[cod + 4 + 4:]))
+    out.append(("garbage where a marker should be", cs[:cod] + b"\x12\x34" + cs[cod + 2:]))
+    siz2 = b"\xff\x51" + cs[4:8] + (4096).to_bytes(4, "big") + (4096).to_bytes(4, "big") + cs[16:cod]
+    out.append(("a second SIZ announcing another size", cs[:sot] + siz2 + cs[sot:]))
+    return out

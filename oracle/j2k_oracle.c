@@ -1038,20 +1038,31 @@ static void idwt97_1d(float *x, int n, ptrdiff_t s, float *tmp) {
 int qo_j2k_decode_plane(const uint8_t *cs, size_t n, int max_layers, void *out, int *Wo, int *Ho, int *preco, int *sgndo) {
   if (n < 4 || cs[0] != 0xFF || cs[1] != 0x4F) return -1;
   size_t p = 2;
+  /* main header: segments inside the buffer and long enough for every field read; SIZ first; the first SIZ / COD / QCD count */
   const uint8_t *siz = NULL, *cod = NULL, *qcd = NULL;
+  size_t lsiz = 0, lcod = 0, lqcd = 0;
+  int sot = 0;
   while (p + 4 <= n) {
+    if (cs[p] != 0xFF) return -2;
     int mk = (cs[p] << 8) | cs[p + 1];
-    if (mk == 0xFF90) break;
-    int ln = (cs[p + 2] << 8) | cs[p + 3];
-    if (mk == 0xFF51) siz = cs + p + 4; else if (mk == 0xFF52) cod = cs + p + 4; else if (mk == 0xFF5C) qcd = cs + p + 4;
-    p += 2 + (size_t)ln;
+    if (mk == 0xFF90) { sot = 1; break; }
+    size_t ln = ((size_t)cs[p + 2] << 8) | cs[p + 3];
+    if (ln < 2 || p + 2 + ln > n) return -2;
+    if (mk == 0xFF51) { if (p != 2) return -2; if (!siz) { siz = cs + p + 4; lsiz = ln - 2; } }
+    else if (mk == 0xFF52) { if (!cod) { cod = cs + p + 4; lcod = ln - 2; } }
+    else if (mk == 0xFF5C) { if (!qcd) { qcd = cs + p + 4; lqcd = ln - 2; } }
+    p += 2 + ln;
   }
-  if (!siz || !cod || !qcd) return -2;
+  if (!siz || !cod || !qcd || !sot || p + 12 > n) return -2;
+  if (lsiz < 39 || lcod < 10 || lqcd < 1) return -2;
 #define U32(q) (((uint32_t)(q)[0] << 24) | ((uint32_t)(q)[1] << 16) | ((uint32_t)(q)[2] << 8) | (q)[3])
   int W = (int)U32(siz + 2), H = (int)U32(siz + 6);
+  if (W < 1 || H < 1 || W > 16384 || H > 16384 || ((siz[34] << 8) | siz[35]) != 1) return -3;
   int prec = (siz[36] & 0x7F) + 1, sgnd = siz[36] >> 7;
+  if (cod[6] > 4 || cod[7] > 4) return -3;
   int scod = cod[0], layers = (cod[2] << 8) | cod[3], L = cod[5], cbw = 1 << (cod[6] + 2), cbh = 1 << (cod[7] + 2), rev = cod[9] == 1;
-  if (cod[1] != 0 || cod[8] != 0 || cbw > 64 || cbh > 64 || L > MAX_LEVELS) return -3;
+  if (cod[1] != 0 || cod[8] != 0 || cbw > 64 || cbh > 64 || L > MAX_LEVELS || layers < 1) return -3;
+  if (lqcd < 1 + (size_t)(3 * L + 1) * ((qcd[0] & 31) == 0 ? 1 : 2)) return -2;
   int guard = qcd[0] >> 5, qstyle = qcd[0] & 31;
   subband sb[3 * MAX_LEVELS + 1];
   int nsb = subbands_prec(W, H, L, 1, 1.0f, prec, sb);   /* geometry; eps / mant / delta / Mb from QCD below */

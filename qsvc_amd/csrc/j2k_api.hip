@@ -655,10 +655,14 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   // host: Tier-2, one code-stream per plane; planes are independent.  First every stream's length (packet headers are built, no
   // byte is copied), which fixes the streams' positions in `out`; then, once the code bytes have arrived, the streams themselves.
   {
-    // QSVC_T2_THREADS is read at every call (a host gives ONE sequence more workers than each of many): the pool is rebuilt when it changes
-    const int t2_env = [] { const char* e = getenv("QSVC_T2_THREADS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
-    if (S.pool && S.pool->nworkers != t2_env - 1) { delete S.pool; S.pool = nullptr; }
-    if (!S.pool) { S.pool = new T2Pool(); S.pool->start(t2_env - 1); }
+    // worker count: qsvc_set_tier2_threads, else QSVC_T2_THREADS as it was at this context's first encode (read once: the
+    // environment is not consulted while other contexts' threads may be changing it), else 8; never more than planes
+    if (!c->t2_default) { const char* e = getenv("QSVC_T2_THREADS"); int v = e ? atoi(e) : 8; c->t2_default = v < 1 ? 1 : (v > 64 ? 64 : v); }
+    int t2_want = c->t2_threads > 0 ? c->t2_threads : c->t2_default;
+    if (t2_want > np) t2_want = np;
+    if (t2_want < 1) t2_want = 1;
+    if (S.pool && S.pool->nworkers != t2_want - 1) { delete S.pool; S.pool = nullptr; }  // rebuilt only when the count changes
+    if (!S.pool) { S.pool = new T2Pool(); S.pool->start(t2_want - 1); }
     const int nthreads = S.pool->nworkers + 1;
     std::vector<long> rc(np, 0);
     auto stream_of = [&](int p, uint8_t* dst, size_t dcap) {

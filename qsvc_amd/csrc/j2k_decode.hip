@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <exception>
 
 #include <algorithm>
 #include <vector>
@@ -92,20 +93,32 @@ uint32_t be32(const uint8_t* q) { return ((uint32_t)q[0] << 24) | ((uint32_t)q[1
 const char* parse_stream(const uint8_t* cs, size_t n, int max_layers, DecPlane& pl, std::vector<DecCb>& cbs, std::vector<uint8_t>& segs) {
   if (n < 4 || cs[0] != 0xFF || cs[1] != 0x4F) return "no SOC marker";
   size_t p = 2;
+  // main header: every marker segment must lie inside the buffer and be long enough for the fields read below; SIZ comes first
+  // (A.5.1) and only the first SIZ / COD / QCD count (a later duplicate must not replace a checked one)
   const uint8_t *siz = nullptr, *cod = nullptr, *qcd = nullptr;
+  size_t lsiz = 0, lcod = 0, lqcd = 0;
+  bool sot = false;
   while (p + 4 <= n) {
-    int mk = (cs[p] << 8) | cs[p + 1];
-    if (mk == 0xFF90) break;
-    int ln = (cs[p + 2] << 8) | cs[p + 3];
-    if (mk == 0xFF51) siz = cs + p + 4; else if (mk == 0xFF52) cod = cs + p + 4; else if (mk == 0xFF5C) qcd = cs + p + 4;
-    p += 2 + (size_t)ln;
+    if (cs[p] != 0xFF) return "corrupt main header (marker expected)";
+    const int mk = (cs[p] << 8) | cs[p + 1];
+    if (mk == 0xFF90) { sot = true; break; }
+    const size_t ln = ((size_t)cs[p + 2] << 8) | cs[p + 3];
+    if (ln < 2 || p + 2 + ln > n) return "marker segment runs past the end of the code-stream";
+    if (mk == 0xFF51) { if (p != 2) return "SIZ must follow SOC"; if (!siz) { siz = cs + p + 4; lsiz = ln - 2; } }
+    else if (mk == 0xFF52) { if (!cod) { cod = cs + p + 4; lcod = ln - 2; } }
+    else if (mk == 0xFF5C) { if (!qcd) { qcd = cs + p + 4; lqcd = ln - 2; } }
+    p += 2 + ln;
   }
-  if (!siz || !cod || !qcd || p + 12 > n) return "missing SIZ / COD / QCD / SOT";
+  if (!siz || !cod || !qcd || !sot || p + 12 > n) return "missing SIZ / COD / QCD / SOT";
+  if (lsiz < 39 || lcod < 10 || lqcd < 1) return "SIZ / COD / QCD segment too short";
   const int W = (int)be32(siz + 2), H = (int)be32(siz + 6);
   if (((siz[34] << 8) | siz[35]) != 1 || be32(siz + 10) || be32(siz + 14) || (int)be32(siz + 18) < W || (int)be32(siz + 22) < H)
     return "one component and one tile at the origin only";
+  if (W < 1 || H < 1 || W > 16384 || H > 16384) return "geometry outside this path";
   const int prec = (siz[36] & 0x7F) + 1, sgnd = siz[36] >> 7;
+  if (cod[6] > 4 || cod[7] > 4) return "code-blocks larger than 64x64 are not supported";  // also keeps the shifts below defined
   const int scod = cod[0], layers = (cod[2] << 8) | cod[3], L = cod[5], cbw = 1 << (cod[6] + 2), cbh = 1 << (cod[7] + 2), rev = cod[9] == 1;
+  if (layers < 1) return "no quality layers";
   if (cod[1] != 0) return "LRCP progression only";
   if (cod[8] != 0) return "code-block style 0 only";
   if (scod & 1) return "precinct partitions are not supported";
@@ -113,6 +126,7 @@ const char* parse_stream(const uint8_t* cs, size_t n, int max_layers, DecPlane& 
   if (!(prec == 8 && !sgnd) && !(prec == 16 && sgnd)) return "8-bit unsigned or 16-bit signed samples only";
   const int guard = qcd[0] >> 5, qstyle = qcd[0] & 31;
   if (qstyle != 0 && qstyle != 2) return "derived quantisation is not supported";
+  if (lqcd < 1 + (size_t)(3 * L + 1) * (qstyle == 0 ? 1 : 2)) return "QCD shorter than the subband count";
   pl.W = W; pl.H = H; pl.L = L; pl.rev = rev; pl.prec = prec; pl.sgnd = sgnd;
   // subbands in code-stream order
   struct Sb { int x0, y0, w, h, orient, Mb; float delta; int gx, gy, first; };
@@ -451,7 +465,12 @@ extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* 
   for (int i = 0; i < nstreams; i++) {
     planes[i].off = total; planes[i].out_off = out_total;
     if (!streams[i]) return c->fail(QSVC_ERR_INVALID, "code-stream %d is null", i);
-    const char* e = parse_stream(streams[i], lens[i], max_layers, planes[i], cbs, segs);
+    const char* e = nullptr;
+    try {  // the parser sizes containers from header fields: an allocation failure is an error code, never an exception across the C ABI
+      e = streams[i] ? parse_stream(streams[i], lens[i], max_layers, planes[i], cbs, segs) : "null stream";
+    } catch (const std::exception&) {
+      return c->fail(QSVC_ERR_NOMEM, "code-stream %d: out of host memory while parsing", i);
+    }
     if (e) return c->fail(QSVC_ERR_UNSUPPORTED, "code-stream %d: %s", i, e);
     if (planes[i].rev != planes[0].rev) return c->fail(QSVC_ERR_UNSUPPORTED, "the streams of one call must share the transform");
     total += (size_t)planes[i].W * planes[i].H;

@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(2 * L) k_t1_mq_pipe(const CbDesc* cbs, int ncb
     int c3[15][3];
 #pragma unroll
     for (int pl = 0; pl < 15; pl++) {
-      const int* src = cnt + (job0 + (pl < nbps ? pl : 0)) * 3;
+      // a block without bit-planes owns no job: its joboff is the NEXT block's first job, or njobs (one past the table) when it
+      // is the last one -- never form an address from it
+      const int* src = cnt + (nbps ? job0 + (pl < nbps ? pl : 0) : (size_t)0) * 3;
       c3[pl][0] = src[0]; c3[pl][1] = src[1]; c3[pl][2] = src[2];
     }
 #pragma unroll

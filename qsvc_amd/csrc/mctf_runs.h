@@ -94,7 +94,7 @@ __device__ __forceinline__ uint32_t residue4(uint32_t o, uint32_t p) {
 #define PCT_H 14                      // output rows per tile
 #define PCT_FH (2 * PCT_H + 3)        // full-resolution rows 2 j0 - 2 .. 2 j0 + 2 PCT_H
 #define PCT_FW (2 * PCT_W + 16)       // full-resolution columns 2 i0 - 8 .. 2 i0 + 2 PCT_W + 7, in runs of 8
-#define PCT_T 576                     // threads per workgroup: one run of the footprint (31 x 18 = 558) per thread
+#define PCT_T 256                     // threads per workgroup (576 = one footprint run per thread was measured: slower, fewer workgroups per CU)
 // sP (bytes, rows yb .., columns xb ..) -> sL: the row pass' low band, two adjacent columns per word.  Call with the footprint
 // written and a barrier passed; returns with sL complete (barrier included).
 __device__ __forceinline__ void chroma_tile_lows(uint8_t (*sP)[PCT_FW], uint32_t (*sL)[PCT_W / 2], const LevelGeom& g, int i0, int xb, int yb,

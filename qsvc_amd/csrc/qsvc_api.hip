@@ -405,7 +405,9 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   }
   // frame_types_t on the device for `update` (page-locked source: nothing the caller can touch is read after this call returns)
   lv.types_d_ok = false;
-  if (g.nB && lv.types_pin.ensure((size_t)g.nB) && lv.types_d.ensure(c, (size_t)g.nB + 16) == QSVC_OK) {
+  if (g.nB) {
+    if (!lv.types_pin.ensure((size_t)g.nB)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%d)", g.nB);
+    if ((r = lv.types_d.ensure(c, (size_t)g.nB + 16))) return r;
     memcpy(lv.types_pin.p, lv.types.data(), (size_t)g.nB);
     HIPCHK(c, hipMemcpyAsync(lv.types_d.p, lv.types_pin.p, (size_t)g.nB, hipMemcpyHostToDevice, c->st));
     lv.types_d_ok = true;
@@ -735,6 +737,12 @@ int qsvc_dwt53_trunc(qsvc_ctx* c, int16_t* plane, int H, int W, int stride, int 
 }
 
 // ---- profiling ------------------------------------------------------------------------------------
+int qsvc_set_tier2_threads(qsvc_ctx* c, int n) {
+  if (!c) return QSVC_ERR_INVALID;
+  if (n < 0 || n > 64) return c->fail(QSVC_ERR_INVALID, "tier-2 threads %d (0 = default, 1..64)", n);
+  c->t2_threads = n;
+  return QSVC_OK;
+}
 int qsvc_set_profiling(qsvc_ctx* c, int on) {
   if (!c) return QSVC_ERR_INVALID;
   (void)hipStreamSynchronize(c->st);

@@ -93,6 +93,8 @@ struct qsvc_ctx {
   PinBuf hhist;                  // the B pictures' histograms on the host: [nB][3][256] u32
   std::string err;
   int profiling = 0;
+  int t2_threads = 0;            // qsvc_set_tier2_threads: 0 = default (QSVC_T2_THREADS at the context's first encode, else 8)
+  int t2_default = 0;            // that default, once read
   std::vector<Seg> segs;
   std::vector<HostSeg> hsegs;
   void host_time(const char* name, double ms);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "qsvc_get_frame_types", "qsvc_get_histograms", "qsvc_motion_estimate", "qsvc_decorrelate", "qsvc_update",
     "qsvc_analyze_step", "qsvc_un_update", "qsvc_correlate", "qsvc_synthesize_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_dwt53_trunc",
-    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_stats", "qsvc_set_profiling", "qsvc_get_timings",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_stats", "qsvc_set_tier2_threads", "qsvc_set_profiling", "qsvc_get_timings",
 ]
 
 
@@ -87,6 +87,7 @@ def load_library() -> C.CDLL:
     L.qsvc_j2k_decode_planes.argtypes = [vp, i, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i, vp, C.c_size_t, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.qsvc_j2k_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.qsvc_set_tier2_threads.argtypes = [vp, i]
     L.qsvc_set_profiling.argtypes = [vp, i]
     L.qsvc_get_timings.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), i]
     _lib = L
@@ -311,7 +312,10 @@ class Engine:
         for cs in streams:  # SOC, SIZ marker, Lsiz, Rsiz, Xsiz, Ysiz ... Ssiz at byte 42
             if len(cs) < 44 or cs[:4] != b"\xff\x4f\xff\x51":
                 raise QsvcError(-1, "not a JPEG 2000 code-stream (SOC/SIZ missing)")
-            geo.append((int.from_bytes(cs[8:12], "big"), int.from_bytes(cs[12:16], "big"), (cs[42] & 0x7F) + 1 > 8))
+            w, h = int.from_bytes(cs[8:12], "big"), int.from_bytes(cs[12:16], "big")
+            if not (1 <= w <= 16384 and 1 <= h <= 16384):  # the output buffer below is sized from these header fields
+                raise QsvcError(-1, f"code-stream announces a {w}x{h} picture: outside this path")
+            geo.append((w, h, (cs[42] & 0x7F) + 1 > 8))
         cap = sum(w * h * (2 if p16 else 1) + 2 for (w, h, p16) in geo) + 64
         out = np.empty(cap, dtype=np.uint8)
         ptrs = (C.c_char_p * n)(*streams)
@@ -329,6 +333,10 @@ class Engine:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.L.qsvc_j2k_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(codeblocks=a.value, passes=b.value, symbols=c.value)
+
+    def set_tier2_threads(self, n: int):
+        """Host threads writing the code-streams of one encode call (0 = default: QSVC_T2_THREADS at the first encode, else 8)."""
+        self._chk(self.L.qsvc_set_tier2_threads(self.h, int(n)))
 
     # ---- profiling
     def set_profiling(self, on=True):

@@ -146,6 +146,24 @@ def test_all_zero_planes_have_empty_packets(eng):
     np.testing.assert_array_equal(J.decode(cs), pl)
 
 
+def test_trailing_blocks_without_bit_planes(eng):
+    """The last code-blocks of the batch are all zero while earlier ones are not: such a block owns no Tier-1 job and its first-job
+    index equals the job count (one past the tables) -- the MQ kernel's pass-table prefetch must not form an address from it."""
+    from qsvc_amd import hip
+    for (H, W, levels) in ((128, 128, 1), (192, 256, 2), (64, 320, 0)):
+        y = np.full((H, W), 128, dtype=np.uint8)
+        y[:40, :40] = _luma("noise", 40, 40, 9)  # texture in the top-left corner only: the high bands' last blocks stay empty
+        for pipe in ("1", "0"):
+            import os
+            os.environ["QSVC_MQ_PIPE"] = pipe
+            try:
+                cs = eng.j2k_encode_plane(y, hip.j2k_params(reversible=True, levels=levels))
+            finally:
+                os.environ.pop("QSVC_MQ_PIPE", None)
+            assert cs == J.encode_plane(y, reversible=True, levels=levels)
+            np.testing.assert_array_equal(J.decode(cs), y)
+
+
 def test_plane_groups_do_not_change_the_streams(eng):
     """QSVC_T1_BUDGET_GB bounds the Tier-1 working set by coding the planes in groups; the streams are the same bytes."""
     import os

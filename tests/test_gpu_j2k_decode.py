@@ -108,3 +108,14 @@ def test_1080p_sequence_round_trip_and_expand_tool(eng, tmp_path):
     assert second[:F + W * H] == want[:F + W * H]                          # picture 0 and the luma of picture 1
     assert second[F + W * H:F + 2 * W * H] == bytes([128]) * (W * H)       # missing U: luma-sized neutral block (:170-176)
     assert second[F + 2 * W * H:] == want[F + W * H + W * H // 4:]
+
+
+def test_corrupt_main_headers_are_refused(eng):
+    """The same malformed headers as the CPU test, through the C ABI: QsvcError, no fault, and the context stays usable."""
+    from qsvc_amd import hip
+    y = make_clip("pan", 1, 96, 64, 5)[0][:96 * 64].reshape(64, 96)
+    cs = J.encode_plane(y, reversible=True, levels=3)
+    for name, bad in J.corrupt_headers(cs):
+        with pytest.raises(hip.QsvcError):
+            eng.j2k_decode_planes([bad])
+    np.testing.assert_array_equal(eng.j2k_decode_planes([cs])[0], y)

@@ -62,3 +62,14 @@ def test_motion_planes_decode():
     np.testing.assert_array_equal(J.own_decode(J.encode_plane_s16(r)), r)
     z = np.zeros((17, 30), dtype=np.int16)
     np.testing.assert_array_equal(J.own_decode(J.encode_plane_s16(z)), z)
+
+
+def test_corrupt_main_headers_are_refused():
+    """Short, truncated or inconsistent SIZ / COD / QCD segments (the decoder reads code-streams from files): an error, not a read
+    past the buffer; a later duplicate SIZ is refused, not allowed to replace the checked one."""
+    y = _luma("pan", 96, 64, 5)
+    cs = J.encode_plane(y, reversible=True, levels=3)
+    np.testing.assert_array_equal(J.own_decode(cs), y)
+    for name, bad in J.corrupt_headers(cs):
+        with pytest.raises(RuntimeError):
+            J.own_decode(bad)
