@@ -30,23 +30,45 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 sys.path.insert(0, ROOT)
 
-W, H, TRLS, GOPS, BS, S0, SRLS = 1920, 1080, 4, 2, 8, 4, 5
+# BASELINE.json configs[2] (the judged default) and configs[3] ("4K 32-frame GOP, 9/7 irreversible, 4 temporal + 5 spatial levels"):
+# geometry, TRLs, GOPs, block size, first search range, SRLs, pictures per GPU window, default transform, sessions in flight, PMC file
+CONFIGS = {
+    3: dict(W=1920, H=1080, TRLS=4, GOPS=2, BS=8, S0=4, SRLS=5, G=16, reversible=1, sessions=12, pmc="r03_pmc_hbm.json", name="1080p"),
+    4: dict(W=3840, H=2160, TRLS=5, GOPS=2, BS=16, S0=4, SRLS=6, G=32, reversible=0, sessions=4, pmc="r03_cfg4_pmc_hbm.json", name="4K"),
+}
+W, H, TRLS, GOPS, BS, S0, SRLS = 1920, 1080, 4, 2, 8, 4, 5   # overwritten from CONFIGS[--config] in main()
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = "r02_pmc_hbm.json"  # tools/refresh_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, one sequence in flight
+PMC_FILE = "r03_pmc_hbm.json"  # tools/refresh_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, one sequence in flight
+
+
+def codeblocks_per_frame(w, h, levels, cb=64):
+    """64x64 code-blocks of one 4:2:0 picture coded as three single-component streams with `levels` DWT levels (T.800 B.5/B.7)."""
+    def plane(pw, ph):
+        n, ws, hs = 0, [pw], [ph]
+        for _ in range(levels):
+            ws.append((ws[-1] + 1) // 2); hs.append((hs[-1] + 1) // 2)
+        blocks = lambda bw, bh: ((bw + cb - 1) // cb) * ((bh + cb - 1) // cb) if bw > 0 and bh > 0 else 0
+        n += blocks(ws[levels], hs[levels])
+        for d in range(levels, 0, -1):
+            lw, lh, hw, hh = ws[d], hs[d], ws[d - 1] - ws[d], hs[d - 1] - hs[d]
+            n += blocks(hw, lh) + blocks(lw, hh) + blocks(hw, hh)
+        return n
+    return plane(w, h) + 2 * plane(w // 2, h // 2)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline():
+def cpu_baseline(reversible=True, frames=None):
     """The CPU path on the SAME workload as one GPU step's sequence (17 pictures, 3 MCTF levels, 17 subband pictures coded), one
     core.  MCTF: the reference's own tools (oracle/_ref, compiled from /root/reference at build time) when present, else the
     restatement; JPEG 2000: the T.800 restatement (the reference's Kakadu does not exist here), hence kind "port"."""
     from oracle import oracle as O
     from oracle import j2k as J
     from qsvc_amd.synth import make_clip
-    frames = 17
+    full = GOPS * 2 ** (TRLS - 1) + 1
+    frames = full  # the pictures of one GPU step's sequence
     clip = make_clip("pan_noise", frames, W, H, 43)
     t0 = time.perf_counter()
     if O.have_ref():
@@ -61,12 +83,13 @@ def cpu_baseline():
     ncb = 0
     for f in pics:
         for pl in (f[:W * H].reshape(H, W), f[W * H:W * H + W * H // 4].reshape(H // 2, W // 2), f[W * H + W * H // 4:].reshape(H // 2, W // 2)):
-            _, st = J.encode_plane(pl, reversible=True, levels=SRLS - 1, want_stats=True)
+            _, st = J.encode_plane(pl, reversible=bool(reversible), levels=SRLS - 1, want_stats=True)
             ncb += st["codeblocks"]
     t2 = time.perf_counter()
     return {"value": round(frames / (t2 - t0), 4), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"the whole {frames}-picture sequence of one step: 3 MCTF levels via {mctf_kind} ({t1 - t0:.2f} s) + 5/3 DWT/EBCOT of "
-                      f"the {frames} subband pictures via the T.800 restatement ({t2 - t1:.2f} s, {ncb} code-blocks); single thread",
+            "sample": f"the whole {frames}-picture sequence of one step: {TRLS - 1} MCTF levels via {mctf_kind} ({t1 - t0:.2f} s) + "
+                      f"{'5/3' if reversible else '9/7'} DWT/EBCOT of the {frames} subband pictures via the T.800 restatement "
+                      f"({t2 - t1:.2f} s, {ncb} code-blocks); single thread",
             "mctf_s": round(t1 - t0, 3), "j2k_s": round(t2 - t1, 3), "codeblocks_per_s": round(ncb / (t2 - t1), 1)}
 
 
@@ -124,10 +147,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clip", default="pan_noise")
-    ap.add_argument("--sessions", type=int, default=12,
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration: 3 = 1080p 16-picture GOP pair, 5/3 lossless (the judged default); "
+                         "4 = 4K 32-picture GOP pair, 9/7, TRLs 5, SRLs 6, one layer")
+    ap.add_argument("--reversible", type=int, default=None, choices=(0, 1),
+                    help="1 = 5/3 reversible lossless, 0 = 9/7 irreversible, one layer (default: 1 for config 3, 0 for config 4)")
+    ap.add_argument("--sessions", type=int, default=None,
                     help="17-picture sequences encoded concurrently per GPU (one encoder context + host thread each); "
                          "a step = every session finishing one whole encode")
     args = ap.parse_args()
+    global W, H, TRLS, GOPS, BS, S0, SRLS, PMC_FILE
+    cfg = CONFIGS[args.config]
+    W, H, TRLS, GOPS, BS, S0, SRLS, PMC_FILE = cfg["W"], cfg["H"], cfg["TRLS"], cfg["GOPS"], cfg["BS"], cfg["S0"], cfg["SRLS"], cfg["pmc"]
+    if args.reversible is None:
+        args.reversible = cfg["reversible"]
+    if args.sessions is None:
+        args.sessions = cfg["sessions"]
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -199,7 +234,7 @@ def main():
             exchange_kind = "gloo-host"
 
     prm = CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=TRLS, GOPs=GOPS, block_size=BS, block_size_min=BS,
-                         search_range=S0, SRLs=SRLS, lossless=True)
+                         search_range=S0, SRLs=SRLS, lossless=bool(args.reversible), reversible=bool(args.reversible), nLayers=1)
 
     class Lockstep:
         """All sessions of this rank reach the level's exchange point together; ONE thread then runs the sessions'
@@ -234,7 +269,8 @@ def main():
     comp = comps[0]
     P = comp.pictures
     # weak scaling: rank r holds pictures [16r, 16r+16] of one long synthetic sequence (boundary picture shared)
-    G = 16
+    G = cfg["G"]
+    assert P == G + 1
     seq_local = make_clip(args.clip, G * world + 1, W, H, 43)[G * rank:G * rank + P].copy()
 
     def variant(clip, k):
@@ -349,86 +385,92 @@ def main():
         engs[0].set_profiling(False)
 
     if rank == 0:
-        pics_total = (G * world + 1) * S   # unique pictures per step: S independent sequences of 16*N+1 pictures
+        pics_total = (G * world + 1) * S   # unique pictures per step: S independent sequences of G*N+1 pictures
         ms_step = dt / args.steps * 1e3
         fps = pics_total * args.steps / dt
         F = W * H * 3 // 2
-        ncb_frame = 921
-        ncb_step = ncb_frame * 17  # per rank
+        ncb_frame = codeblocks_per_frame(W, H, SRLS - 1)
+        ncb_step = ncb_frame * P  # per rank
         # ---- algorithmic bytes per STEP of this rank's session 0 (F = 1.5 W H, N = W H) -----------------
-        nB = [8, 4, 2]
+        nB = [lv[1] // 2 for lv in comp.levels]      # B pictures per temporal level
         N = W * H
-        t1_bytes = ncb_step * 8192 + nbytes           # EBCOT T1: 4096 x 2 B of int16 coefficients per 64x64 block + emitted bytes
+        dwt_key = "j2k_dwt53" if args.reversible else "j2k_dwt97"
+        coef_bytes = 2 if args.reversible else 4      # Tier-1 input: int16 (5/3) / 32-bit quantiser indices (9/7), SURVEY.md 8d
+        t1_bytes = ncb_step * 4096 * coef_bytes + nbytes   # EBCOT T1: 4096 coefficients per 64x64 block + emitted bytes
         alg = {
             "j2k_t1_mq": t1_bytes, "j2k_t1_cm": t1_bytes,
             "predict": sum(nB) * 4 * F,                # per B picture: read 2 even + 1 odd, write high
-            "update": sum(n + 1 for n in nB) * 4 * F - 3 * 2 * F,   # per even picture <= 4 F (ends 3 F)
+            "update": sum(n + 1 for n in nB) * 4 * F - len(nB) * 2 * F,   # per even picture <= 4 F (the two ends of a level 3 F)
             "me_search_l0": sum(nB) * (3 * N + 8 * (H // BS) * (W // BS)),
-            "j2k_dwt53": int(17 * 1.5 * N * (3 + 4 / 3)),  # u8 in, int16 out, L levels
+            dwt_key: int(P * 1.5 * N * ((3 + 4 / 3) if args.reversible else (5 + 8 / 3))),  # u8 in, int16 / float32 out, L levels
         }
         per, host = {}, {}
         for k, (ms, n) in timings.items():
             d = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": n // max(args.steps, 1)}
             (host if k.startswith("host_") else per)[k] = d
         pmc = {}
-        try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+        try:  # HBM bytes per encode from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
         except Exception:
             pass
 
-        def traffic_of(kernels):
-            """HBM bytes per step of a kernel group: sum of launches x (FETCH_SIZE + WRITE_SIZE) from the PMC passes.  RAW sums: none
-            of these kernels reads 16 bytes per lane in long streams (the one pattern MI355X_MICROARCH.md says FETCH_SIZE halves);
-            calibration on a known byte count in our own access widths: k_chroma_up (1-byte loads, 4-byte stores) reads
-            (nB+1) x 2 x W/2 x H/2 and writes (nB+1) x 2 x W x H bytes per launch, and both counters return exactly that."""
+        def traffic_of(prefixes):
+            """HBM bytes per step (= one encode of one sequence) of a kernel group: FETCH_SIZE + WRITE_SIZE of every kernel whose
+            name starts with one of `prefixes`, summed over the launches of one encode (tools/pmc_summary.py: hbm_bytes_per_step_raw).
+            RAW sums: none of these kernels reads 16 bytes per lane in long streams (the one pattern MI355X_MICROARCH.md says
+            FETCH_SIZE halves); calibration on a kernel with exactly known byte counts is described in DESIGN.md 6."""
             tot, seen = 0, False
-            for kn, launches in kernels:
-                e = pmc.get(kn)
-                if e:
+            for kn, e in pmc.items():
+                if any(kn.startswith(px) for px in prefixes) and "hbm_bytes_per_step_raw" in e:
                     seen = True
-                    tot += launches * e["hbm_bytes_per_launch_raw"]
+                    tot += e["hbm_bytes_per_step_raw"]
             return int(tot) if seen else None
 
         dom = "j2k_t1_mq"
         a = alg[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e9 if dom in per and per[dom]["ms_per_step"] > 0 else 0.0
+        mq_traffic = traffic_of([mq_symbol]) or traffic_of(["k_t1_mq_pipe<64, 4, 196, 144>"])
         roof = {"kernel": dom, "kernel_symbol": mq_symbol, "bound": "hbm", "achieved": round(a, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(a / HBM_PEAK_GBS, 6),
-                "traffic": traffic_of([(mq_symbol, 1)]) or traffic_of([("k_t1_mq_pipe<64, 4, 196, 144>", 1)]),
-                "traffic_source": "profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE per launch, separate passes, one sequence in flight: the "
-                                  "pipeline in its default form, the same loads and stores as the small-LDS form)",
+                "traffic": mq_traffic,
+                "traffic_source": ("profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE per launch, separate passes, one sequence in flight: the "
+                                   "pipeline in its default form, the same loads and stores as the small-LDS form)") if mq_traffic is not None
+                                  else "missing (kernel symbol not in profiles/" + PMC_FILE + ")",
                 "launch_ms": per.get(dom, {}).get("ms_per_step"), "algorithmic_bytes_per_launch": int(alg[dom]),
-                "algorithmic_bytes": "SURVEY.md 8d: 15 657 code-blocks x 8 KB (int16 coefficients) + emitted code bytes, one launch per step",
+                "algorithmic_bytes": f"SURVEY.md 8d: {ncb_step} code-blocks x 4096 coefficients x {coef_bytes} B + emitted code bytes, one launch per step",
                 "note": "the launch with the largest share of the step; EBCOT Tier-1 is serial-dependency bound, not HBM bound (SURVEY.md H4/8d): "
                         "the fraction is quoted for completeness, the streaming kernels are in roofline_streaming"}
         # the kernels the HBM roofline is meaningful for, ISOLATED (one sequence in flight, measured live after the timed region)
         streaming = None
         if iso:
             groups = {
-                "j2k_dwt53": [("k_dwt_tile<true, true, false>", 1), ("k_dwt_tile<true, false, false>", 3), ("k_t1_nbps", 1)],
-                "predict": [("k_chroma_up", 3), ("k_pred_luma8", 3), ("k_pred_chroma8", 3), ("k_mv_hist", 3)],
-                "update": [("k_chroma_up", 3), ("k_upd_luma_tile", 3), ("k_upd_chroma_tile", 3)],
-                "me_search_l0": [("k_me_search8<unsigned char>", 3)],
+                dwt_key: ["k_dwt_tile", "k_t1_nbps"],
+                "predict": ["k_pred_", "k_mv_hist", "k_chroma_up"],
+                "update": ["k_upd_"],
+                "me_search_l0": ["k_me_piece<unsigned char", "k_me_search8<unsigned char", "k_me_search<unsigned char"],
             }
             streaming = {}
-            for k, kernels in groups.items():
+            for k, prefixes in groups.items():
                 if k not in iso or iso[k][0] <= 0:
                     continue
                 g = alg[k] / (iso[k][0] * 1e-3) / 1e9
                 streaming[k] = {"ms_per_step_isolated": round(iso[k][0], 4), "launch_groups_per_step": iso[k][1],
                                 "algorithmic_bytes_per_step": int(alg[k]), "achieved_GBs": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4),
-                                "traffic": traffic_of(kernels)}
+                                "traffic": traffic_of(prefixes)}
             streaming["note"] = ("isolated = one sequence in flight, HIP events on the context's stream around each kernel group; traffic = HBM bytes "
-                                 "per step from profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE, raw, calibrated on k_chroma_up's known byte "
-                                 "counts; k_chroma_up launches are counted in both predict and update, which each run it); ME is ALU-bound by "
-                                 "design (SURVEY.md 8d), its fraction is quoted for completeness")
+                                 "per step from profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE, raw; null = not in that file); ME is ALU-bound "
+                                 "by design (SURVEY.md 8d), its fraction is quoted for completeness")
         t1ms = sum(per.get(k, {}).get("ms_per_step", 0) for k in ("j2k_t1_cm", "j2k_t1_mq"))
         line = {
-            "metric": "1080p encode fps (MCTF + 5/3 DWT + EBCOT)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
+            "metric": f"{cfg['name']} encode fps (MCTF + {'5/3' if args.reversible else '9/7'} DWT + EBCOT)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int16 (int32 5/3 lifting in LDS, u16 MQ coder)", "data": "synthetic",
-            "config": {"workload": "1920x1080 4:2:0, 17 pictures per GPU (16-picture GOP window + shared boundary), TRLs=4 "
-                                   "(ME+predict+update, block 8, search 4/8/16), JPEG 2000 5/3 reversible lossless, Clevels=4, "
-                                   "64x64 code-blocks, SOP; clip=" + args.clip,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int16 (int32 5/3 lifting in LDS, u16 MQ coder)" if args.reversible else "u8/int16 MCTF, f32 9/7 lifting, u16 MQ coder",
+            "data": "synthetic",
+            "config": {"workload": f"{W}x{H} 4:2:0, {P} pictures per GPU ({G}-picture GOP window + shared boundary), TRLs={TRLS} "
+                                   f"(ME+predict+update, block {BS}, search {'/'.join(str(lv[2]) for lv in comp.levels)}), JPEG 2000 "
+                                   + ("5/3 reversible lossless" if args.reversible else "9/7 irreversible, one layer at the reference's slope")
+                                   + f", Clevels={SRLS - 1}, 64x64 code-blocks, SOP; clip=" + args.clip,
+                       "baseline_config": args.config,
                        "pictures_per_step_total": pics_total, "sequences_in_flight_per_gpu": S,
                        "parallelism": f"gop-shard x{world}", "halo_exchange": exchange_kind,
                        "tier2_threads_per_context": t2_timed, "host_cpus": len(os.sched_getaffinity(0))},
@@ -438,7 +480,7 @@ def main():
             "kernels": per, "host_stages": host, "roofline": roof, "roofline_streaming": streaming,
         }
         if serial_ms is not None:
-            line["single_sequence"] = {"ms_per_encode": round(serial_ms, 3), "frames_per_s": round(17 / (serial_ms * 1e-3), 2),
+            line["single_sequence"] = {"ms_per_encode": round(serial_ms, 3), "frames_per_s": round(P / (serial_ms * 1e-3), 2),
                                        "tier2_threads": t2_single,
                                        "kernels_ms_isolated": {k: round(v[0], 4) for k, v in iso.items()}}
         line["kernels_note"] = ("kernels{} are HIP-event durations on session 0's stream inside the timed region; with several sessions in "
@@ -446,7 +488,7 @@ def main():
                                 "milliseconds of the CPU stages of session 0 (rate allocation, Tier-2)")
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline()
+                line["cpu_baseline"] = cpu_baseline(args.reversible)
             except Exception as ex:  # the baseline is a reported extra; never fail the GPU measurement on it
                 line["cpu_baseline"] = {"error": repr(ex)}
         sys.stdout.flush()

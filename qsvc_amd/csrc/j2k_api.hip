@@ -741,6 +741,7 @@ extern "C" {
 
 static int add_sequence(qsvc_ctx* c, int kind, int t, int first, int count, const qsvc_j2k_params* prm, std::vector<PlaneSrc>& src) {
   if (t < 0 || t > QSVC_MAX_T) return c->fail(QSVC_ERR_INVALID, "temporal subband %d out of range", t);
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }  // pending I/B decisions of the temporal levels (qsvc_api.hip)
   Level& lv = c->lv[t];
   DevBuf* b; int n;
   switch (kind) {

@@ -78,7 +78,9 @@ static void free_seq(qsvc_ctx* c) {
     l.low_n = l.high_n = l.pred_n = 0; l.mv_raw_n = l.mv_filt_n = 0; l.mv_bs = 0; l.types.clear();
     l.types_d.release(); l.types_pin.release(); l.types_d_ok = false; l.mv_bound = -1;
     l.halo[0] = l.halo[1] = nullptr;
+    l.pending = false; l.hhist.release();
   }
+  c->pending.clear(); c->calls.clear();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,12 +123,15 @@ const char* qsvc_last_error(qsvc_ctx* c) { return c ? c->err.c_str() : "null con
 void* qsvc_stream(qsvc_ctx* c) { return c ? (void*)c->st : nullptr; }
 int qsvc_sync(qsvc_ctx* c) {
   if (!c) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   HIPCHK(c, hipStreamSynchronize(c->st));
   return QSVC_OK;
 }
 
 int qsvc_seq_config(qsvc_ctx* c, int W, int H, int keep_prediction) {
   if (!c) return QSVC_ERR_INVALID;
+  c->pending.clear(); c->calls.clear();  // the state the pending decisions belong to is about to be freed
+  for (auto& l_ : c->lv) l_.pending = false;
   if (W < 16 || H < 16 || W > 16384 || H > 16384) return c->fail(QSVC_ERR_INVALID, "bad geometry %dx%d", W, H);
   if ((W & 1) || (H & 1)) return c->fail(QSVC_ERR_UNSUPPORTED, "odd picture size %dx%d (4:2:0 needs even sizes)", W, H);
   (void)hipSetDevice(c->dev);
@@ -150,6 +155,7 @@ static int seq_sel(qsvc_ctx* c, int kind, int t, DevBuf** buf, int** cnt) {
 
 int qsvc_put_frames(qsvc_ctx* c, int kind, int t, int first, int count, int total, const uint8_t* src) {
   if (!c || !src) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
   DevBuf* b; int* n;
   int r = seq_sel(c, kind, t, &b, &n);
@@ -164,6 +170,7 @@ int qsvc_put_frames(qsvc_ctx* c, int kind, int t, int first, int count, int tota
 }
 int qsvc_get_frames(qsvc_ctx* c, int kind, int t, int first, int count, uint8_t* dst) {
   if (!c || !dst) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   DevBuf* b; int* n;
   int r = seq_sel(c, kind, t, &b, &n);
   if (r) return r;
@@ -175,6 +182,7 @@ int qsvc_get_frames(qsvc_ctx* c, int kind, int t, int first, int count, uint8_t*
 
 int qsvc_put_motion(qsvc_ctx* c, int kind, int t, int nB, int bs, const int16_t* mv) {
   if (!c || !mv || t < 1 || t > QSVC_MAX_T || bs <= 0 || nB < 0) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   Level& l = c->lv[t];
   size_t bytes = (size_t)nB * 4 * (c->H / bs) * (c->W / bs) * sizeof(int16_t);
   DevBuf& b = kind == QSVC_MOTION_RAW ? l.mv_raw : l.mv_filt;
@@ -189,6 +197,7 @@ int qsvc_put_motion(qsvc_ctx* c, int kind, int t, int nB, int bs, const int16_t*
 }
 int qsvc_get_motion(qsvc_ctx* c, int kind, int t, int b_pictures, int block_size, int16_t* mv) {
   if (!c || !mv || t < 1 || t > QSVC_MAX_T || b_pictures < 0) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   Level& l = c->lv[t];
   int nB = kind == QSVC_MOTION_RAW ? l.mv_raw_n : l.mv_filt_n;
   if (!l.mv_bs) return c->fail(QSVC_ERR_STATE, "no motion for t=%d", t);
@@ -204,12 +213,14 @@ int qsvc_get_motion(qsvc_ctx* c, int kind, int t, int b_pictures, int block_size
 }
 int qsvc_put_frame_types(qsvc_ctx* c, int t, int nB, const char* types) {
   if (!c || !types || t < 1 || t > QSVC_MAX_T || nB < 0) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   c->lv[t].types.assign(types, types + nB);
   c->lv[t].types_d_ok = false;
   return QSVC_OK;
 }
 int qsvc_get_frame_types(qsvc_ctx* c, int t, int b_pictures, char* types) {
   if (!c || !types || t < 1 || t > QSVC_MAX_T || b_pictures < 0) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   if ((size_t)b_pictures > c->lv[t].types.size())
     return c->fail(QSVC_ERR_STATE, "frame_types_%d holds %zu entries (asked for %d)", t, c->lv[t].types.size(), b_pictures);
   memcpy(types, c->lv[t].types.data(), (size_t)b_pictures);
@@ -217,6 +228,7 @@ int qsvc_get_frame_types(qsvc_ctx* c, int t, int b_pictures, char* types) {
 }
 int qsvc_get_histograms(qsvc_ctx* c, int t, int b_pictures, uint32_t* hist) {
   if (!c || !hist || t < 1 || t > QSVC_MAX_T || b_pictures < 0) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   Level& l = c->lv[t];
   if (!l.hist.p) return c->fail(QSVC_ERR_STATE, "no histograms for t=%d", t);
   if (b_pictures > l.high_n) return c->fail(QSVC_ERR_STATE, "histograms of t=%d cover %d pictures (asked for %d)", t, l.high_n, b_pictures);
@@ -250,6 +262,7 @@ static int level_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g) {
 
 int qsvc_set_mctf_options(qsvc_ctx* c, int block_overlaping, int border_size, int subpixel_accuracy) {
   if (!c) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   if (block_overlaping < 0 || border_size < 0 || subpixel_accuracy < 0) return c->fail(QSVC_ERR_INVALID, "negative MCTF option");
   if (subpixel_accuracy != 0)
     return c->fail(QSVC_ERR_UNSUPPORTED, "subpixel_accuracy %d: sub-pixel motion (motion_estimate.cpp:361-412, decorrelate.cpp:656-686) is not implemented on this path", subpixel_accuracy);
@@ -268,6 +281,7 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   if (r) return r;
   int lg = ilog2_exact(S);
   if (lg < 0 || S > 128) return c->fail(QSVC_ERR_UNSUPPORTED, "search_range %d is not a power of two <= 128", S);
+  if (!c->pending.empty() && !c->resolving) c->calls.push_back({0, t, P, bs, S, 0, 0.0f});
   int L = lg - 1 < 0 ? 0 : lg - 1;  // motion_estimate.cpp:277
   // the level-l search state equals the l-level analysis only while every intermediate size is even (Q5)
   if ((g.H % (1 << L)) || (g.W % (1 << L)))
@@ -349,6 +363,87 @@ static float entropy256(const uint32_t* count) {
   return -e;
 }
 
+// decorrelate.cpp:964-979 on one picture's three histograms: 'I' if the picture itself looks cheaper than residue + motion
+static bool picture_is_I(const uint32_t* h, int H, int W, int BY, int BX) {
+  float predicted_entropy = entropy256(h), residue_entropy = entropy256(h + 256), motion_entropy = entropy256(h + 512);
+  int predicted_size = (int)(predicted_entropy * (float)H * (float)W);
+  int residue_size = (int)(residue_entropy * (float)H * (float)W);
+  int motion_size = (int)(motion_entropy * (float)BY * (float)BX);
+  return predicted_size <= residue_size + motion_size;
+}
+// 'I' pictures of level t (decorrelate.cpp:982-1000): the odd picture itself is the "high" picture, its motion is zero
+static int apply_I_pictures(qsvc_ctx* c, int t) {
+  Level& lv = c->lv[t];
+  const uint8_t* frames = (const uint8_t*)c->lv[t - 1].low.p;
+  const size_t fld = (size_t)lv.dec_BY * lv.dec_BX;
+  for (int i = 0; i < lv.dec_nB; i++)
+    if (lv.types[i] == 'I') {
+      HIPCHK(c, hipMemcpyAsync((uint8_t*)lv.high.p + (size_t)i * c->F, frames + (size_t)(2 * i + 1) * c->F, c->F, hipMemcpyDeviceToDevice, c->st));
+      HIPCHK(c, hipMemsetAsync((int16_t*)lv.mv_filt.p + (size_t)i * 4 * fld, 0, 4 * fld * sizeof(int16_t), c->st));
+    }
+  return QSVC_OK;
+}
+static int types_to_device_pinned(qsvc_ctx* c, Level& lv, int nB) {
+  lv.types_d_ok = false;
+  if (!nB) return QSVC_OK;
+  if (!lv.types_pin.ensure((size_t)nB)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%d)", nB);
+  int r = lv.types_d.ensure(c, (size_t)nB + 16);
+  if (r) return r;
+  memcpy(lv.types_pin.p, lv.types.data(), (size_t)nB);
+  HIPCHK(c, hipMemcpyAsync(lv.types_d.p, lv.types_pin.p, (size_t)nB, hipMemcpyHostToDevice, c->st));
+  lv.types_d_ok = true;
+  return QSVC_OK;
+}
+// ---- deferred decisions -------------------------------------------------------------------------------------------------
+// The reference decides I or B per picture with a float entropy estimate (decorrelate.cpp:945-979) whose log() must be the
+// host's to stay bit-exact, so the decision cannot move to the device.  It does not have to stall the device either: nearly
+// every picture is 'B', so decorrelate queues the histograms' copy to the host and the level chain carries on with 'B'
+// (update, the next level's search, ...) without a single host round trip.  The first call that needs a decision's outcome --
+// reading frame types, pictures or motion, a halo export, the JPEG 2000 stage, qsvc_sync -- lands here: one synchronisation,
+// the entropy rule for every pending level in order, and, if a picture turns out 'I', the reference's 'I' handling followed by a
+// replay of every stage call that consumed the speculative state (with immediate decisions).  Results are those of the
+// immediate path in every case; only the number of host round trips differs.
+int qsvc_resolve(qsvc_ctx* c) {
+  if (!c) return QSVC_ERR_INVALID;
+  if (c->resolving) return QSVC_OK;
+  if (c->pending.empty()) { c->calls.clear(); return QSVC_OK; }
+  (void)hipSetDevice(c->dev);
+  HIPCHK(c, hipStreamSynchronize(c->st));
+  c->resolving = true;
+  int redo_level = 0, r = QSVC_OK;
+  for (size_t k = 0; k < c->pending.size() && !redo_level; k++) {
+    const int t = c->pending[k];
+    Level& lv = c->lv[t];
+    lv.pending = false;
+    bool anyI = false;
+    for (int i = 0; i < lv.dec_nB; i++)
+      if (picture_is_I((const uint32_t*)lv.hhist.p + (size_t)i * 3 * 256, c->H, c->W, lv.dec_BY, lv.dec_BX)) { lv.types[i] = 'I'; anyI = true; }
+    if (anyI) {
+      redo_level = t;
+      if (!r) r = apply_I_pictures(c, t);
+      if (!r) r = types_to_device_pinned(c, lv, lv.dec_nB);
+    }
+  }
+  for (int t : c->pending) c->lv[t].pending = false;
+  c->pending.clear();
+  std::vector<StageCall> calls;
+  calls.swap(c->calls);
+  if (redo_level && !r) {
+    // everything queued after level redo_level's decorrelate used the speculative 'B' state: run it again, deciding at once
+    size_t from = calls.size();
+    for (size_t k = 0; k < calls.size(); k++)
+      if (calls[k].kind == 1 && calls[k].t == redo_level) { from = k + 1; break; }
+    for (size_t k = from; k < calls.size() && !r; k++) {
+      const StageCall& q = calls[k];
+      if (q.kind == 0) r = qsvc_motion_estimate(c, q.t, q.P, q.bs, q.S);
+      else if (q.kind == 1) r = qsvc_decorrelate(c, q.t, q.P, q.bs, q.S, q.always_B);
+      else r = qsvc_update(c, q.t, q.P, q.bs, q.uf);
+    }
+  }
+  c->resolving = false;
+  return r;
+}
+
 int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   if (!c) return QSVC_ERR_INVALID;
   (void)hipSetDevice(c->dev);
@@ -358,6 +453,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   if (S < 1 || S > 128) return c->fail(QSVC_ERR_INVALID, "search_range %d", S);
   Level& lv = c->lv[t];
   if (lv.mv_raw_n < g.nB || lv.mv_bs != bs) return c->fail(QSVC_ERR_STATE, "motion_%d missing (run motion_estimate first)", t);
+  if (!c->pending.empty() && !c->resolving) c->calls.push_back({1, t, P, bs, S, always_B, 0.0f});
   size_t fld = (size_t)g.BY * g.BX, mvbytes = (size_t)g.nB * 4 * fld * sizeof(int16_t);
   if ((r = lv.high.ensure(c, (size_t)(g.nB ? g.nB : 1) * g.F))) return r;
   if ((r = lv.mv_filt.ensure(c, mvbytes ? mvbytes : 16))) return r;
@@ -383,7 +479,18 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   } else launch_predict(c->st, a);
   pf.end(c);
   HIPCHK(c, hipMemcpyAsync(lv.mv_filt.p, lv.mv_raw.p, mvbytes, hipMemcpyDeviceToDevice, c->st));
-  if (!always_B) {
+  static const bool defer_env = [] { const char* e = getenv("QSVC_DEFER_IB"); return !(e && e[0] == '0'); }();
+  const bool defer = !always_B && c->defer_ok && defer_env && !c->resolving;
+  if (defer) {
+    // deferred decision: the histograms travel to the host behind the kernels, the level goes on as if every picture were 'B'
+    // (what it almost always is); qsvc_resolve applies decorrelate.cpp:964-1000 at the next point that needs the outcome
+    const size_t hbytes = (size_t)g.nB * 3 * 256 * 4;
+    if (!lv.hhist.ensure(hbytes)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%zu)", hbytes);
+    HIPCHK(c, hipMemcpyAsync(lv.hhist.p, lv.hist.p, hbytes, hipMemcpyDeviceToHost, c->st));
+    lv.pending = true; lv.dec_nB = g.nB; lv.dec_BY = g.BY; lv.dec_BX = g.BX;
+    if (c->pending.empty()) c->calls.push_back({1, t, P, bs, S, always_B, 0.0f});  // (otherwise logged on entry)
+    c->pending.push_back(t);
+  } else if (!always_B) {
     // host-side I/B rule (decorrelate.cpp:964-979) on the three device histograms
     const size_t hbytes = (size_t)g.nB * 3 * 256 * 4;
     if (!c->hhist.ensure(hbytes)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%zu)", hbytes);
@@ -391,11 +498,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
     HIPCHK(c, hipStreamSynchronize(c->st));
     for (int i = 0; i < g.nB; i++) {
       const uint32_t* h = (const uint32_t*)c->hhist.p + (size_t)i * 3 * 256;
-      float predicted_entropy = entropy256(h), residue_entropy = entropy256(h + 256), motion_entropy = entropy256(h + 512);
-      int predicted_size = (int)(predicted_entropy * (float)g.H * (float)g.W);
-      int residue_size = (int)(residue_entropy * (float)g.H * (float)g.W);
-      int motion_size = (int)(motion_entropy * (float)g.BY * (float)g.BX);
-      if (predicted_size <= residue_size + motion_size) {  // 'I': the odd picture itself, zero motion
+      if (picture_is_I(h, g.H, g.W, g.BY, g.BX)) {  // 'I': the odd picture itself, zero motion
         lv.types[i] = 'I';
         HIPCHK(c, hipMemcpyAsync((uint8_t*)lv.high.p + (size_t)i * g.F, a.frames + (size_t)(2 * i + 1) * g.F, g.F,
                                  hipMemcpyDeviceToDevice, c->st));
@@ -432,6 +535,13 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   // reach >= max |mv| over everything an update may touch.  Motion that motion_estimate produced in this context has a known
   // bound and frame_types_t is on the device since decorrelate: then no host round trip stands between predict and update.
   const bool have_halo = lv.halo[0] || lv.halo[1];
+  if ((have_halo || lv.mv_bound < 0 || !lv.types_d_ok) && !c->pending.empty()) {  // this path reads frame_types_t on the host
+    if ((r = qsvc_resolve(c))) return r;
+  }
+  if (!c->pending.empty() && !c->resolving) {
+    c->calls.push_back({2, t, P, bs, 0, 0, uf});
+    if (c->calls.size() > 4096 && (r = qsvc_resolve(c))) return r;
+  }
   const bool resident = lv.mv_bound >= 0 && lv.types_d_ok && !have_halo;
   int reach = resident ? lv.mv_bound : 0;
   uint8_t halo_types[2][16] = {{0}, {0}};
@@ -504,6 +614,7 @@ static int types_to_device(qsvc_ctx* c, const Level& lv, int nB) {
 
 int qsvc_un_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   if (!c) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   (void)hipSetDevice(c->dev);
   LevelGeom g;
   int r = synth_geom(c, t, P, bs, 0, &g, true);
@@ -540,6 +651,7 @@ int qsvc_un_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
 
 int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   if (!c) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   (void)hipSetDevice(c->dev);
   LevelGeom g;
   int r = synth_geom(c, t, P, bs, S, &g, false);
@@ -591,6 +703,7 @@ static int halo_ragged(qsvc_ctx* c, int t) {
                                    "on every earlier picture of the level, the sequence cannot be split across GPUs", c->W, c->H) : QSVC_OK;
 }
 static int halo_pack(qsvc_ctx* c, int t, int side) {
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   if (int rr = halo_ragged(c, t)) return rr;
   Level& lv = c->lv[t];
   int nB = lv.high_n;
@@ -619,6 +732,7 @@ int qsvc_halo_export_host(qsvc_ctx* c, int t, int side, void* dst) {
 int qsvc_halo_import_host(qsvc_ctx* c, int t, int side, const void* src) {
   if (!c || t < 1 || t > QSVC_MAX_T || (side != 0 && side != 1)) return QSVC_ERR_INVALID;
   (void)hipSetDevice(c->dev);
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   Level& lv = c->lv[t];
   if (!src) { lv.halo[side] = nullptr; return QSVC_OK; }
   if (!lv.mv_bs) return c->fail(QSVC_ERR_STATE, "halo import before decorrelate of t=%d", t);

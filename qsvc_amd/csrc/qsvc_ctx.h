@@ -51,6 +51,16 @@ struct Level {  // the device-resident "files" of temporal subband t
   int mv_bound = -1;             // >= 0: no component of motion_t / motion_filtered_t exceeds it (set by motion_estimate, cleared by put_motion)
   const void* halo[2] = {nullptr, nullptr};
   bool ragged = false;           // Q7: decorrelate ran on a picture the block grid does not tile
+  // Deferred I/B decision (qsvc_api.hip, "deferred decisions"): decorrelate has queued the histograms' way to `hhist` and gone
+  // on as if every picture were 'B'; the float entropy rule runs on the host at the next point that needs its outcome.
+  bool pending = false;
+  PinBuf hhist;                  // [nB][3][256] u32 on the host
+  int dec_nB = 0, dec_BY = 0, dec_BX = 0;
+};
+struct StageCall {  // a stage call made while decisions were pending: replayed if one of them turns out 'I'
+  int kind;         // 0 motion_estimate, 1 decorrelate, 2 update
+  int t, P, bs, S, always_B;
+  float uf;
 };
 
 struct Seg {
@@ -90,7 +100,11 @@ struct qsvc_ctx {
   uint8_t halo_tb[2][16];
   void* comm = nullptr;            // ncclComm_t (RCCL), line topology
   int rank = 0, nranks = 1;
-  PinBuf hhist;                  // the B pictures' histograms on the host: [nB][3][256] u32
+  PinBuf hhist;                  // the B pictures' histograms on the host: [nB][3][256] u32 (immediate decisions)
+  bool defer_ok = true;          // decorrelate may defer its I/B decisions (off while a replay runs; QSVC_DEFER_IB=0 turns it off)
+  bool resolving = false;
+  std::vector<int> pending;      // levels with pending decisions, in the order decorrelate was called
+  std::vector<StageCall> calls;  // stage calls since the first pending decision
   std::string err;
   int profiling = 0;
   int t2_threads = 0;            // qsvc_set_tier2_threads: 0 = default (QSVC_T2_THREADS at the context's first encode, else 8)
@@ -104,5 +118,8 @@ struct qsvc_ctx {
   int hipfail(hipError_t e, const char* what);
 };
 
+// Take every pending I/B decision (one stream synchronisation); if a picture turns out 'I', redo what was computed from the
+// speculative 'B'.  Every entry point that reads or replaces level state calls this first; returns QSVC_OK or an error.
+extern "C" int qsvc_resolve(qsvc_ctx* c);  // internal (not in include/qsvc_hip.h)
 void j2k_release(qsvc_ctx* c);
 void j2k_decode_release(qsvc_ctx* c);

@@ -48,6 +48,31 @@ def test_hip_matches_reference_goldens(eng, name):
     check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "frame_types", "high", "low", "prediction"))
 
 
+@pytest.mark.parametrize("name", ["sat_360x200", "deep_pan_256x192", "cif_binary", "cif_pan"])
+def test_chained_levels_with_deferred_decisions(eng, name):
+    """The whole level chain queued without reading anything in between (what `mctf compress` does): decorrelate defers its I/B
+    decisions and the chain runs on as if every picture were 'B'; the first read takes the decisions and, where a picture is 'I'
+    (sat_360x200: level 3; deep_pan: levels 5, 6 and 7 one after the other), replays what consumed the speculative state.
+    Everything must equal the reference's files as in the level-by-level test."""
+    from qsvc_amd import hip
+    z, m = load_golden(name)
+    clip = golden_input(z, m)
+    W, H, bs = m["W"], m["H"], m["bs"]
+    eng.seq_config(W, H, True)
+    eng.put_frames(hip.LOW, 0, clip)
+    P, S, sched = clip.shape[0], m["S"], []
+    for t in range(1, m["TRLs"]):
+        eng.motion_estimate(t, P, bs, S)
+        eng.decorrelate(t, P, bs, S, 0)
+        eng.update(t, P, bs, 0.25)
+        sched.append((t, P // 2))
+        P, S = (P + 1) // 2, min(2 * S, 128)
+    levels = [dict(motion=eng.get_motion(hip.MOTION_RAW, t, nB, bs), motion_filtered=eng.get_motion(hip.MOTION_FILTERED, t, nB, bs),
+                   frame_types=eng.get_frame_types(t, nB), high=eng.get_frames(hip.HIGH, t, 0, nB), low=eng.get_frames(hip.LOW, t, 0, nB + 1),
+                   prediction=eng.get_frames(hip.PRED, t, 0, nB)) for (t, nB) in sched]
+    check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "frame_types", "high", "low", "prediction"))
+
+
 @pytest.mark.parametrize("name", SUPPORTED)
 def test_hip_inverse_chain_matches_reference_goldens(eng, name):
     """un_update + correlate (+ merge = the layout) down from the coarsest level, on the device-resident analysis outputs:
