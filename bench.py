@@ -152,6 +152,9 @@ def main():
                          "4 = 4K 32-picture GOP pair, 9/7, TRLs 5, SRLs 6, one layer")
     ap.add_argument("--reversible", type=int, default=None, choices=(0, 1),
                     help="1 = 5/3 reversible lossless, 0 = 9/7 irreversible, one layer (default: 1 for config 3, 0 for config 4)")
+    ap.add_argument("--host-cores", type=int, default=0,
+                    help="pin this rank to K host cores (cores [local_rank*K, local_rank*K + K)) before any GPU call: what one rank of an "
+                         "8-rank node gets of the host (Tier-2, launches) -- e.g. --gpus 1 --host-cores 32 on a 256-core host")
     ap.add_argument("--sessions", type=int, default=None,
                     help="17-picture sequences encoded concurrently per GPU (one encoder context + host thread each); "
                          "a step = every session finishing one whole encode")
@@ -167,6 +170,11 @@ def main():
         ap.error("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
+    if args.host_cores > 0:  # before anything touches the GPU runtime (its helper threads inherit the mask)
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        avail = sorted(os.sched_getaffinity(0))
+        mine = avail[(lr * args.host_cores) % len(avail):][:args.host_cores] or avail[:args.host_cores]
+        os.sched_setaffinity(0, set(mine))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: refusing to measure a different job than asked for")
         sys.exit(2)
@@ -346,6 +354,40 @@ def main():
     small = os.environ.get("QSVC_MQ_LDS") == "small"
     mq_symbol = (("k_t1_mq_pipe<64, 2, 116, 48>" if small else "k_t1_mq_pipe<64, 4, 196, 144>") if os.environ.get("QSVC_MQ_PIPE", "1") != "0"
                  else "k_t1_mq<%s>" % os.environ.get("QSVC_MQ_LANES", "64"))
+    shard_check = None
+    if world > 1:
+        # Self-validation of the multi-GPU path, once, before anything is timed: one step with the halo exchange (every rank, in
+        # lock-step), then THIS rank analyses on its own the window of its shard plus one GOP on either side, without any exchange
+        # (a boundary picture of level t depends on fewer than 2^t pictures on either side, less than one GOP), and the shard's
+        # high_t / low_t / frame_types_t must equal the middle of that window byte for byte -- a wrong, missing or mis-ordered halo
+        # record changes the boundary pictures of low_t.
+        import hashlib
+        run_steps(1)
+        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        got = [(sha(engs[0].get_frames(hip.HIGH, t, 0, Pt // 2)), sha(engs[0].get_frames(hip.LOW, t, 0, Pt // 2 + 1)),
+                bytes(engs[0].get_frame_types(t, Pt // 2))) for (t, Pt, St, bst) in comp.levels]
+        lo, hi = max(0, G * (rank - 1)), min(G * world, G * (rank + 2))
+        wide = make_clip(args.clip, G * world + 1, W, H, 43)[lo:hi + 1].copy()
+        chk = hip.Engine(devno)
+        chk.seq_config(W, H)
+        chk.put_frames(hip.LOW, 0, wide)
+        Pw, off, bad = wide.shape[0], G * rank - lo, []
+        for (t, Pt, St, bst), (h_sha, l_sha, types) in zip(comp.levels, got):
+            chk.analyze_step(t, Pw, bst, St)
+            off //= 2
+            nBw, nB = Pw // 2, Pt // 2
+            if sha(chk.get_frames(hip.HIGH, t, 0, nBw)[off:off + nB]) != h_sha: bad.append(f"high_{t}")
+            if sha(chk.get_frames(hip.LOW, t, 0, nBw + 1)[off:off + nB + 1]) != l_sha: bad.append(f"low_{t}")
+            if bytes(chk.get_frame_types(t, nBw))[off:off + nB] != types: bad.append(f"frame_types_{t}")
+            Pw = (Pw + 1) // 2
+        chk.close()
+        flag = torch.tensor([0 if bad else 1])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if bad:
+            log(f"[rank {rank}] shard check FAILED: {bad} differ from the locally analysed window (halo exchange: {exchange_kind})")
+        if flag.item() != 1:
+            os._exit(1)  # no JSON line for a run whose shards are wrong
+        shard_check = "ok"
     run_steps(args.warmup)
     for e in engs:
         e.set_profiling(True)
@@ -473,6 +515,8 @@ def main():
                        "baseline_config": args.config,
                        "pictures_per_step_total": pics_total, "sequences_in_flight_per_gpu": S,
                        "parallelism": f"gop-shard x{world}", "halo_exchange": exchange_kind,
+                       "rccl_ranks": world if exchange_kind == "rccl" else 0, "shard_check": shard_check,
+                       "host_cores_pinned": args.host_cores or None,
                        "tier2_threads_per_context": t2_timed, "host_cpus": len(os.sched_getaffinity(0))},
             "codeblocks_per_s": round(ncb_step * world * S * args.steps / dt, 1),
             "ebcot_codeblocks_per_s_kernel": round(ncb_step / (t1ms * 1e-3), 1) if t1ms else None,

@@ -68,3 +68,17 @@ def test_unsupported_options_are_refused():
             e.set_mctf_options(block_overlaping=3)
     finally:
         e.close()
+
+
+def test_subpixel_probe_record():
+    """--subpixel_accuracy > 0 stays refused.  The committed record of what the reference's own tools do with it
+    (tests/golden/make_subpel_probe.py -> subpel_probe.json): repeatable under default malloc, but motion_t itself changes with the
+    heap's fill pattern (MALLOC_PERTURB_) on every clip -- the search reads plane borders nothing ever wrote."""
+    import json, os
+    from helpers import GOLDEN
+    rec = json.load(open(os.path.join(GOLDEN, "subpel_probe.json")))
+    assert len(rec) >= 8
+    for r in rec:
+        assert r["exit_codes"] == [0, 0, 0, 0] and r["repeat_identical"]
+        assert "motion_1" in r["files_depending_on_heap_fill"]
+        assert r["malloc_perturb_165"]["motion_1"] != r["default_malloc"]["motion_1"]

@@ -1,20 +1,34 @@
-import sys, time
+"""Host-side cost of the MCTF stage calls of one sequence (tools, GPU box): how long each C-ABI call takes to RETURN (its launches
+queued, nothing awaited) and how long the GPU then needs.  python tools/time_host.py [cfg3|cfg4] [iters]"""
+import sys, time, numpy as np
 sys.path.insert(0, '.')
 from qsvc_amd import hip
-from qsvc_amd.pipeline import CompressParams, Compressor
 from qsvc_amd.synth import make_clip
-W, H = 1920, 1080
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+W, H, bs, P, TRLs = (1920, 1080, 8, 17, 4) if cfg == "cfg3" else (3840, 2160, 16, 33, 5)
+clip = make_clip("pan_noise", P, W, H, 43)
 e = hip.Engine(0)
-c = Compressor(e, CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=4, GOPs=2, block_size=8, block_size_min=8, search_range=4, SRLs=5, lossless=True))
-c.configure(); c.load(make_clip("pan_noise", 17, W, H, 43))
-c.analyze(); c.texture(); e.sync()
-e.set_profiling(True)
-N = 5
-ta = tt = 0
-for _ in range(N):
-    t0 = time.perf_counter(); c.analyze(); e.sync(); t1 = time.perf_counter(); c.texture(copy=False); t2 = time.perf_counter()
-    ta += t1 - t0; tt += t2 - t1
-tm = e.timings()
-mctf = sum(ms for k, (ms, n) in tm.items() if not k.startswith("j2k")) / N
-j2k = sum(ms for k, (ms, n) in tm.items() if k.startswith("j2k")) / N
-print(f"analyze wall {ta/N*1e3:.2f} ms (kernels {mctf:.2f});  texture wall {tt/N*1e3:.2f} ms (kernels {j2k:.2f})")
+e.seq_config(W, H)
+e.put_frames(hip.LOW, 0, clip)
+acc = {}
+def tick(name, t0):
+    acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+def run(measure):
+    p, S = P, 4
+    for t in range(1, TRLs):
+        t0 = time.perf_counter(); e.motion_estimate(t, p, bs, S)
+        if measure: tick("motion_estimate (return)", t0)
+        t0 = time.perf_counter(); e.decorrelate(t, p, bs, S, 0)
+        if measure: tick("decorrelate (return)", t0)
+        t0 = time.perf_counter(); e.update(t, p, bs, 0.25)
+        if measure: tick("update (return)", t0)
+        p = (p + 1) // 2; S *= 2
+    t0 = time.perf_counter(); e.sync()
+    if measure: tick("sync (GPU drains, decisions resolved)", t0)
+for _ in range(3): run(False)
+t0 = time.perf_counter()
+for _ in range(iters): run(True)
+dt = (time.perf_counter() - t0) / iters
+print("%s MCTF wall %.3f ms per sequence (profiling off)" % (cfg, dt * 1e3))
+for k, v in acc.items(): print(f"  {k:40s} {v / iters * 1e3:8.3f} ms")
