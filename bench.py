@@ -103,7 +103,7 @@ def spawn_ranks(n):
         have = torch.cuda.device_count()
     except Exception:  # noqa: BLE001
         have = None
-    if have is not None and have < n:
+    if have is not None and have < n and os.environ.get("QSVC_BENCH_DEVICE") is None:  # (test hook: all ranks on one GPU)
         log(f"bench.py: --gpus {n} asked for, {have} visible: refusing (a silent fall-back to fewer GPUs would mislabel the result)")
         return 2
     with socket.socket() as so:
@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the non-headline decode extra")
     ap.add_argument("--clip", default="pan_noise")
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
                     help="BASELINE.json configuration: 3 = 1080p 16-picture GOP pair, 5/3 lossless (the judged default); "
@@ -416,15 +417,67 @@ def main():
             engs[0].set_tier2_threads(t2_single)
         step(0)
         engs[0].sync()
-        engs[0].set_profiling(True)
+        ISO_N = 5  # the latency of one sequence: nothing else on the chip, no profiling events in its stream
         t1 = time.perf_counter()
-        ISO_N = 3
         for _ in range(ISO_N):
             step(0)
         engs[0].sync()
         serial_ms = (time.perf_counter() - t1) / ISO_N * 1e3
+        engs[0].set_profiling(True)  # then the kernel groups' isolated durations (HIP events around each group)
+        ISO_N = 3
+        for _ in range(ISO_N):
+            step(0)
+        engs[0].sync()
         iso = {k: (ms / ISO_N, n // ISO_N) for k, (ms, n) in engs[0].timings().items()}
         engs[0].set_profiling(False)
+
+    decode_extra = None
+    if world == 1 and not args.no_decode:
+        # Non-headline extra: the same sequence back from its code-streams -- JPEG 2000 decode of every subband
+        # picture (one batch), then the inverse temporal levels (un_update, correlate; synthesize.py) down to low_0, in a fresh
+        # context that holds nothing but the streams, the filtered motion and the frame types.  Wall clock from streams in host
+        # memory to low_0 in HBM; the decoded planes make the host round trip the C ABI's decode entry point implies.
+        try:
+            e0 = engs[0]
+            comp.analyze()
+            out = comp.texture(0, copy=True)
+            side = {t: (e0.get_motion(hip.MOTION_FILTERED, t, Pt // 2, bst), bytes(e0.get_frame_types(t, Pt // 2))) for (t, Pt, St, bst) in comp.levels}
+            items = [(hip.HIGH, t, Pt // 2) for (t, Pt, St, bst) in comp.levels] + [(hip.LOW, comp.levels[-1][0], comp.levels[-1][1] // 2 + 1)]
+            streams = [cs for (kind, t, n) in items for cs in out[(kind, t)]]
+            dec = hip.Engine(devno)
+            dec.seq_config(W, H)
+
+            def decode_once():
+                planes = dec.j2k_decode_planes(streams)
+                k = 0
+                for (kind, t, n) in items:
+                    fr = np.empty((n, W * H * 3 // 2), dtype=np.uint8)
+                    for i in range(n):
+                        fr[i] = np.concatenate([planes[k].reshape(-1), planes[k + 1].reshape(-1), planes[k + 2].reshape(-1)])
+                        k += 3
+                    dec.put_frames(kind, t, fr)
+                for (t, Pt, St, bst) in comp.levels:
+                    dec.put_motion(hip.MOTION_FILTERED, t, side[t][0], bst)
+                    dec.put_frame_types(t, side[t][1])
+                for (t, Pt, St, bst) in reversed(comp.levels):
+                    dec.synthesize_step(t, Pt, bst, St)
+                dec.sync()
+            decode_once()
+            DN = 3
+            t1 = time.perf_counter()
+            for _ in range(DN):
+                decode_once()
+            dms = (time.perf_counter() - t1) / DN * 1e3
+            back = dec.get_frames(hip.LOW, 0, 0, P)
+            exact = bool(np.array_equal(back, variant(seq_local, 0)))
+            err = float(np.abs(back.astype(np.int16) - variant(seq_local, 0).astype(np.int16)).mean())
+            dec.close()
+            decode_extra = {"ms_per_sequence": round(dms, 3), "frames_per_s": round(P / (dms * 1e-3), 1), "pictures": P,
+                            "bit_exact_reconstruction": exact, "mean_abs_error": round(err, 4),
+                            "what": "JPEG 2000 decode of all subband pictures (one batch) + inverse MCTF to low_0; one sequence, streams in host "
+                                    "memory -> pictures in HBM; first correct form of the decoder (not tuned)"}
+        except Exception as ex:  # an extra: never fail the headline on it
+            decode_extra = {"error": repr(ex)}
 
     if rank == 0:
         pics_total = (G * world + 1) * S   # unique pictures per step: S independent sequences of G*N+1 pictures
@@ -527,6 +580,8 @@ def main():
             line["single_sequence"] = {"ms_per_encode": round(serial_ms, 3), "frames_per_s": round(P / (serial_ms * 1e-3), 2),
                                        "tier2_threads": t2_single,
                                        "kernels_ms_isolated": {k: round(v[0], 4) for k, v in iso.items()}}
+        if decode_extra is not None:
+            line["decode"] = decode_extra
         line["kernels_note"] = ("kernels{} are HIP-event durations on session 0's stream inside the timed region; with several sessions in "
                                 "flight kernels of different sessions overlap, so they do not sum to ms_per_step; host_stages{} are wall-clock "
                                 "milliseconds of the CPU stages of session 0 (rate allocation, Tier-2)")

@@ -948,9 +948,7 @@ bool upd_fast_path(const UpdArgs& a) { return upd_run_applies(a) && getenv("QSVC
 void launch_update(hipStream_t st, const UpdArgs& a) {
   const LevelGeom& g = a.g;
   dim3 block(64, 4);
-  if (upd_fast_path(a)) {  // mctf_upd.hip: ordered gather by runs of 8 targets, chroma interpolated inside its tiles
-    const size_t n = (size_t)2 * (g.W / 2) * (g.H / 2);
-    hipLaunchKernelGGL(k_upd_chroma_copy, dim3((unsigned)((n / 16 + 256) / 256), g.nB + 1), dim3(256), 0, st, a);
+  if (upd_fast_path(a)) {  // mctf_upd.hip: ordered gather by runs of 8 targets, chroma interpolated inside its tiles; one launch
     launch_update_run(st, a);
     return;
   }

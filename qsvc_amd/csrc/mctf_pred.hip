@@ -23,14 +23,14 @@ namespace qsvc {
 // ---------------------------------------------------------------------------------------------
 // luma: a thread owns one run of 8 samples in each of 4 rows; LDS histograms of the odd picture and of residue + 128
 #define PL_K 16   // histogram copies per bin
-__global__ void __launch_bounds__(256) k_pred_luma_run(PredArgs a) {
-  __shared__ unsigned hs[2][256 * PL_K];
-  const int tid = threadIdx.y * 64 + threadIdx.x;
+__device__ __forceinline__ void pred_luma_body(const PredArgs& a, uint8_t* smem, const int bx_, const int by_, const int bz_, const int tx_, const int ty_) {
+  unsigned (*hs)[256 * PL_K] = (unsigned (*)[256 * PL_K])smem;
+  const int tid = ty_ * 64 + tx_;
   for (int k = tid; k < 2 * 256 * PL_K; k += 256) (&hs[0][0])[k] = 0;
   __syncthreads();
   const LevelGeom& g = a.g;
-  const int x = (blockIdx.x * 64 + threadIdx.x) * 8, i = blockIdx.z;
-  const unsigned cp = threadIdx.x & (PL_K - 1);
+  const int x = (bx_ * 64 + tx_) * 8, i = bz_;
+  const unsigned cp = tx_ & (PL_K - 1);
   if (x < g.W) {
     const uint8_t* r0 = frame_y(a.frames, g, 2 * i);
     const uint8_t* r1 = frame_y(a.frames, g, 2 * i + 2);
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_pred_luma_run(PredArgs a) {
     int yv[4], mv4[4][4];
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
-      yv[rr] = imin(blockIdx.y * 16 + rr * 4 + threadIdx.y, g.H - 1);
+      yv[rr] = imin(by_ * 16 + rr * 4 + ty_, g.H - 1);
       const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)(yv[rr] >> lbs) * g.BX + bx;
       mv4[rr][0] = m[0]; mv4[rr][1] = m[fld]; mv4[rr][2] = m[2 * fld]; mv4[rr][3] = m[3 * fld];
     }
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) k_pred_luma_run(PredArgs a) {
     }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
-      const int y = blockIdx.y * 16 + rr * 4 + threadIdx.y;
+      const int y = by_ * 16 + rr * 4 + ty_;
       if (y >= g.H) break;
       const uint64_t p0 = luma_run8_fin(l0[rr], r0, g, y + mv4[rr][1], x + mv4[rr][0]);
       const uint64_t p1 = luma_run8_fin(l1[rr], r1, g, y + mv4[rr][3], x + mv4[rr][2]);
@@ -86,13 +86,12 @@ __global__ void __launch_bounds__(256) k_pred_luma_run(PredArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // chroma: a workgroup produces a 64 x 14 tile of one half-resolution component.
-__global__ void __launch_bounds__(PCT_T) k_pred_chroma_run(PredArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t sP[PCT_FH][PCT_FW];
-  __shared__ __attribute__((aligned(16))) uint32_t sL[PCT_FH][PCT_W / 2];  // row-pass lows, two columns per word
+__device__ __forceinline__ void pred_chroma_body(const PredArgs& a, uint8_t* smem, const int bx_, const int by_, const int bz_, const int tid) {
+  uint8_t (*sP)[PCT_FW] = (uint8_t (*)[PCT_FW])smem;
+  uint32_t (*sL)[PCT_W / 2] = (uint32_t (*)[PCT_W / 2])(smem + PCT_SP_BYTES);  // row-pass lows, two columns per word
   const LevelGeom& g = a.g;
-  const int tid = threadIdx.x;
-  const int i = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
-  const int i0 = blockIdx.x * PCT_W, j0 = blockIdx.y * PCT_H;
+  const int i = bz_ >> 1, c = 1 + (bz_ & 1);
+  const int i0 = bx_ * PCT_W, j0 = by_ * PCT_H;
   const int cw = g.W >> 1, chh = g.H >> 1;
   const int xb = 2 * i0 - 8, yb = 2 * j0 - 2;
   const size_t fld = (size_t)g.BY * g.BX;
@@ -155,10 +154,24 @@ bool pred_run_applies(const PredArgs& a) {
   return !a.odd_out && !a.margin && g.ov < 2 && g.bs % 8 == 0 && (g.bs & (g.bs - 1)) == 0 && g.W % 8 == 0 && g.H % 2 == 0 && g.H % g.bs == 0 && g.W % g.bs == 0 &&
          g.H >= 8 && g.W >= 16;
 }
+// One launch per level: the chroma tiles (the longer workgroups) first, then the luma strips; a workgroup's role follows from
+// its index.  256 threads, 32 KB of LDS (the luma histograms; a chroma tile needs 8.4 KB of it).
+__global__ void __launch_bounds__(256) k_pred_level(PredArgs a, int ncx, int ncy, int nlx, int nly) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 256 * PL_K * 4];
+  static_assert(sizeof(smem) >= PCT_SMEM_BYTES, "chroma tile fits");
+  int b = blockIdx.x;
+  const int nchroma = ncx * ncy * a.g.nB * 2;
+  if (b < nchroma) {
+    pred_chroma_body(a, smem, b % ncx, (b / ncx) % ncy, b / (ncx * ncy), threadIdx.x);
+  } else {
+    b -= nchroma;
+    pred_luma_body(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x & 63, threadIdx.x >> 6);
+  }
+}
 void launch_predict_run(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
-  hipLaunchKernelGGL(k_pred_luma_run, dim3((g.W + 511) / 512, (g.H + 15) / 16, g.nB), dim3(64, 4), 0, st, a);
-  hipLaunchKernelGGL(k_pred_chroma_run, dim3((g.W / 2 + PCT_W - 1) / PCT_W, (g.H / 2 + PCT_H - 1) / PCT_H, g.nB * 2), dim3(PCT_T), 0, st, a);
+  const int nlx = (g.W + 511) / 512, nly = (g.H + 15) / 16, ncx = (g.W / 2 + PCT_W - 1) / PCT_W, ncy = (g.H / 2 + PCT_H - 1) / PCT_H;
+  hipLaunchKernelGGL(k_pred_level, dim3((unsigned)(ncx * ncy * g.nB * 2 + nlx * nly * g.nB)), dim3(256), 0, st, a, ncx, ncy, nlx, nly);
 }
 
 }  // namespace qsvc

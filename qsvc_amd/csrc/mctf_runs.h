@@ -94,6 +94,8 @@ __device__ __forceinline__ uint32_t residue4(uint32_t o, uint32_t p) {
 #define PCT_H 14                      // output rows per tile
 #define PCT_FH (2 * PCT_H + 3)        // full-resolution rows 2 j0 - 2 .. 2 j0 + 2 PCT_H
 #define PCT_FW (2 * PCT_W + 16)       // full-resolution columns 2 i0 - 8 .. 2 i0 + 2 PCT_W + 7, in runs of 8
+#define PCT_SP_BYTES (((PCT_FH * PCT_FW) + 15) & ~15)          // the footprint (bytes) ...
+#define PCT_SMEM_BYTES (PCT_SP_BYTES + PCT_FH * (PCT_W / 2) * 4)  // ... and the row pass' low band behind it
 #define PCT_T 256                     // threads per workgroup (576 = one footprint run per thread was measured: slower, fewer workgroups per CU)
 // sP (bytes, rows yb .., columns xb ..) -> sL: the row pass' low band, two adjacent columns per word.  Call with the footprint
 // written and a barrier passed; returns with sL complete (barrier included).

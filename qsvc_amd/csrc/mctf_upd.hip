@@ -141,23 +141,30 @@ __device__ __forceinline__ UpdSrc upd_src_luma(const LevelGeom& g, const UpdSide
 }
 
 // ---------------------------------------------------------------------------------------------
-// luma: a lane per run of 8 targets; picture-border cells are written by k_upd_luma_border afterwards
+// luma: a lane per run of 8 targets.  Cells on the picture's border belong to the border role (below): this role never
+// stores them, so both can run in one launch.
 template <int NX>
-__global__ void __launch_bounds__(256) k_upd_luma_run(UpdArgs a) {
+__device__ __forceinline__ void upd_luma_body(const UpdArgs& a, const int bx_, const int by_, const int j, const int tx_, const int ty_) {
   const LevelGeom& g = a.g;
-  const int tx0 = (blockIdx.x * 64 + threadIdx.x) * 8, ty = blockIdx.y * 4 + threadIdx.y, j = blockIdx.z;
+  const int tx0 = (bx_ * 64 + tx_) * 8, ty = by_ * 4 + ty_;
   if (tx0 >= g.W || ty >= g.H) return;
   UpdSide sd[2];
   upd_sides(a, j, sd);
   uint64_t v = ld8(frame_y(a.frames, g, a.src_mul * j) + (size_t)ty * g.W + tx0);
   const UpdSrc s[2] = {upd_src_luma(g, sd[0]), upd_src_luma(g, sd[1])};
-  if (sd[0].high || sd[1].high) v = upd_run<NX>(s, ty, tx0, a.reach, a.uf, v);
-  *(uint2*)(a.low + (size_t)(a.dst_mul * j) * g.F + (size_t)ty * g.W + tx0) = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+  const bool any = sd[0].high || sd[1].high;
+  if (any) v = upd_run<NX>(s, ty, tx0, a.reach, a.uf, v);
+  uint8_t* d = a.low + (size_t)(a.dst_mul * j) * g.F + (size_t)ty * g.W + tx0;
+  const bool edge = any && (ty == 0 || ty == g.H - 1 || tx0 == 0 || tx0 + 8 == g.W);
+  if (!edge) *(uint2*)d = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+  else if (ty != 0 && ty != g.H - 1) {  // the first / last run of an inner row: everything but the border cell
+    for (int k = 0; k < 8; k++)
+      if (tx0 + k != 0 && tx0 + k != g.W - 1) d[k] = (uint8_t)(v >> (8 * k));
+  }
 }
 // the 2 W + 2 (H - 2) cells of the picture's border: everything clip() folds onto them, in order (update_gather)
-__global__ void __launch_bounds__(256) k_upd_luma_border(UpdArgs a) {
+__device__ __forceinline__ void upd_border_body(const UpdArgs& a, const int k, const int j) {
   const LevelGeom& g = a.g;
-  const int k = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
   int y, x;
   if (k < g.W) { y = 0; x = k; }
   else if (k < 2 * g.W) { y = g.H - 1; x = k - g.W; }
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(256) k_upd_luma_border(UpdArgs a) {
   else return;
   UpdSide sd[2];
   upd_sides(a, j, sd);
-  if (!sd[0].high && !sd[1].high) return;  // k_upd_luma_run has copied the cell
+  if (!sd[0].high && !sd[1].high) return;  // the luma role has copied the cell
   int v = frame_y(a.frames, g, a.src_mul * j)[(size_t)y * g.W + x];
   for (int q = 0; q < 2; q++)
     if (sd[q].high) {
@@ -178,22 +185,29 @@ __global__ void __launch_bounds__(256) k_upd_luma_border(UpdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// chroma: one 64 x 14 tile of one stored component per workgroup (only tiles an update can reach; the others were copied)
+// chroma: one 64 x 14 tile of one stored component per workgroup.  Tiles no update can reach (Q3: sources exist in the top-left
+// quadrant only) and pictures without a contributing B picture keep the stored chroma: analysis(synthesis(u)) == u exactly.
 template <int NX>
-__global__ void __launch_bounds__(PCT_T) k_upd_chroma_run(UpdArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t sP[PCT_FH][PCT_FW];
-  __shared__ __attribute__((aligned(16))) uint32_t sL[PCT_FH][PCT_W / 2];
+__device__ __forceinline__ void upd_chroma_body(const UpdArgs& a, uint8_t* smem, const int bx_, const int by_, const int bz_, const int tid) {
+  uint8_t (*sP)[PCT_FW] = (uint8_t (*)[PCT_FW])smem;
+  uint32_t (*sL)[PCT_W / 2] = (uint32_t (*)[PCT_W / 2])(smem + PCT_SP_BYTES);
   const LevelGeom& g = a.g;
-  const int tid = threadIdx.x;
-  const int j = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
-  const int i0 = blockIdx.x * PCT_W, j0 = blockIdx.y * PCT_H;
+  const int j = bz_ >> 1, c = 1 + (bz_ & 1);
+  const int i0 = bx_ * PCT_W, j0 = by_ * PCT_H;
   const int cw = g.W >> 1, chh = g.H >> 1;
   const int xb = 2 * i0 - 8, yb = 2 * j0 - 2;
   UpdSide sd[2];
   upd_sides(a, j, sd);
-  if ((!sd[0].high && !sd[1].high) || yb >= chh + a.reach || 2 * i0 - 2 >= cw + a.reach) return;  // workgroup-uniform
   const size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh;
   const uint8_t* u = frame_c(a.frames, g, a.src_mul * j, c);
+  uint8_t* dst = a.low + (size_t)(a.dst_mul * j) * g.F + coff;
+  if ((!sd[0].high && !sd[1].high) || yb >= chh + a.reach || 2 * i0 - 2 >= cw + a.reach) {  // workgroup-uniform: a plain copy
+    if (tid < PCT_H * (PCT_W / 4)) {
+      const int cj = j0 + tid / (PCT_W / 4), ci = i0 + 4 * (tid % (PCT_W / 4));
+      if (cj < chh && ci < cw) *(uint32_t*)(dst + (size_t)cj * cw + ci) = *(const uint32_t*)(u + (size_t)cj * cw + ci);
+    }
+    return;
+  }
   UpdSrc s[2];
   const int lbs = 31 - __builtin_clz(g.bs);
   for (int q = 0; q < 2; q++) {
@@ -239,9 +253,24 @@ __global__ void __launch_bounds__(PCT_T) k_upd_chroma_run(UpdArgs a) {
     if (cj < chh && ci < cw) {
       uint32_t ll[2];
       chroma_tile_ll(sL, jr, gq, ll);
-      *(uint32_t*)(a.low + (size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci) = __builtin_amdgcn_perm(ll[1], ll[0], 0x06040200u);  // Q4 wrap
+      *(uint32_t*)(dst + (size_t)cj * cw + ci) = __builtin_amdgcn_perm(ll[1], ll[0], 0x06040200u);  // Q4 wrap
     }
   }
+}
+
+// One launch per level: the chroma tiles first (the longest workgroups), then the luma strips, then the border cells.
+template <int NX>
+__global__ void __launch_bounds__(256) k_upd_level(UpdArgs a, int ncx, int ncy, int nlx, int nly) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[PCT_SMEM_BYTES];
+  const int np = a.g.nB + 1;
+  int b = blockIdx.x;
+  const int nchroma = ncx * ncy * np * 2, nluma = nlx * nly * np;
+  if (b < nchroma) { upd_chroma_body<NX>(a, smem, b % ncx, (b / ncx) % ncy, b / (ncx * ncy), threadIdx.x); return; }
+  b -= nchroma;
+  if (b < nluma) { upd_luma_body<NX>(a, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x & 63, threadIdx.x >> 6); return; }
+  b -= nluma;
+  const int nbb = (2 * a.g.W + 2 * (a.g.H - 2) + 255) / 256;
+  upd_border_body(a, (b % nbb) * 256 + threadIdx.x, b / nbb);
 }
 
 bool upd_run_applies(const UpdArgs& a) {
@@ -251,25 +280,15 @@ bool upd_run_applies(const UpdArgs& a) {
 }
 void launch_update_run(hipStream_t st, const UpdArgs& a) {
   const LevelGeom& g = a.g;
-  const int nx = upd_max_cols(g.bs, a.reach);
-  const dim3 lgrid((g.W + 511) / 512, (g.H + 3) / 4, g.nB + 1), lblock(64, 4);
+  const int np = g.nB + 1, nx = upd_max_cols(g.bs, a.reach);
+  const int nlx = (g.W + 511) / 512, nly = (g.H + 3) / 4, ncx = (g.W / 2 + PCT_W - 1) / PCT_W, ncy = (g.H / 2 + PCT_H - 1) / PCT_H;
+  const int nbb = (2 * g.W + 2 * (g.H - 2) + 255) / 256;
+  const dim3 grid((unsigned)(ncx * ncy * np * 2 + nlx * nly * np + nbb * np)), block(256);
   switch (nx) {
-    case 2: hipLaunchKernelGGL(k_upd_luma_run<2>, lgrid, lblock, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(k_upd_luma_run<3>, lgrid, lblock, 0, st, a); break;
-    case 5: hipLaunchKernelGGL(k_upd_luma_run<5>, lgrid, lblock, 0, st, a); break;
-    default: hipLaunchKernelGGL(k_upd_luma_run<0>, lgrid, lblock, 0, st, a); break;
-  }
-  hipLaunchKernelGGL(k_upd_luma_border, dim3((2 * g.W + 2 * (g.H - 2) + 255) / 256, g.nB + 1), dim3(256), 0, st, a);
-  // chroma: only the tiles an update can reach -- outputs whose footprint lies within `reach` of the top-left quadrant (Q3)
-  const int cw = g.W / 2, chh = g.H / 2;
-  const int gx = (cw + PCT_W - 1) / PCT_W, gy = (chh + PCT_H - 1) / PCT_H;
-  const int tx = imin(gx, ((cw + a.reach + 2) / 2 + PCT_W - 1) / PCT_W + 1), ty = imin(gy, ((chh + a.reach + 2) / 2 + PCT_H - 1) / PCT_H + 1);
-  const dim3 cgrid(tx, ty, (g.nB + 1) * 2);
-  switch (nx) {
-    case 2: hipLaunchKernelGGL(k_upd_chroma_run<2>, cgrid, dim3(PCT_T), 0, st, a); break;
-    case 3: hipLaunchKernelGGL(k_upd_chroma_run<3>, cgrid, dim3(PCT_T), 0, st, a); break;
-    case 5: hipLaunchKernelGGL(k_upd_chroma_run<5>, cgrid, dim3(PCT_T), 0, st, a); break;
-    default: hipLaunchKernelGGL(k_upd_chroma_run<0>, cgrid, dim3(PCT_T), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_upd_level<2>, grid, block, 0, st, a, ncx, ncy, nlx, nly); break;
+    case 3: hipLaunchKernelGGL(k_upd_level<3>, grid, block, 0, st, a, ncx, ncy, nlx, nly); break;
+    case 5: hipLaunchKernelGGL(k_upd_level<5>, grid, block, 0, st, a, ncx, ncy, nlx, nly); break;
+    default: hipLaunchKernelGGL(k_upd_level<0>, grid, block, 0, st, a, ncx, ncy, nlx, nly); break;
   }
 }
 

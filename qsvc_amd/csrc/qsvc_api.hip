@@ -59,15 +59,18 @@ void Prof::begin(qsvc_ctx* c, const char* name) {
   Seg* s = nullptr;
   for (auto& x : c->segs) if (x.name == name) { s = &x; break; }
   if (!s) { c->segs.push_back(Seg()); s = &c->segs.back(); s->name = name; }
-  hipEvent_t a, b;
-  hipEventCreate(&a); hipEventCreate(&b);
-  hipEventRecord(a, c->st);
-  s->ev.push_back({a, b});
+  if (s->used == s->ev.size()) {  // the pool grows to the largest number of launches between two qsvc_set_profiling calls
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    s->ev.push_back({a, b});
+  }
+  hipEventRecord(s->ev[s->used].first, c->st);
+  s->used++;
   cur = s;
 }
 void Prof::end(qsvc_ctx* c) {
   if (!c->profiling || !cur) return;
-  hipEventRecord(cur->ev.back().second, c->st);
+  hipEventRecord(cur->ev[cur->used - 1].second, c->st);
   cur = nullptr;
 }
 
@@ -860,8 +863,7 @@ int qsvc_set_tier2_threads(qsvc_ctx* c, int n) {
 int qsvc_set_profiling(qsvc_ctx* c, int on) {
   if (!c) return QSVC_ERR_INVALID;
   (void)hipStreamSynchronize(c->st);
-  for (auto& s : c->segs) for (auto& p : s.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  c->segs.clear();
+  for (auto& s : c->segs) s.used = 0;  // the event pairs stay (creating events costs more than the kernels they bracket)
   c->hsegs.clear();
   c->profiling = on;
   return QSVC_OK;
@@ -872,9 +874,10 @@ int qsvc_get_timings(qsvc_ctx* c, const char** names, float* ms, int* launches, 
   int n = 0;
   for (auto& s : c->segs) {
     if (n >= cap) break;
+    if (!s.used) continue;
     float tot = 0;
-    for (auto& p : s.ev) { float m = 0; if (hipEventElapsedTime(&m, p.first, p.second) == hipSuccess) tot += m; }
-    names[n] = s.name.c_str(); ms[n] = tot; if (launches) launches[n] = (int)s.ev.size();
+    for (size_t k = 0; k < s.used; k++) { float m = 0; if (hipEventElapsedTime(&m, s.ev[k].first, s.ev[k].second) == hipSuccess) tot += m; }
+    names[n] = s.name.c_str(); ms[n] = tot; if (launches) launches[n] = (int)s.used;
     n++;
   }
   for (auto& h : c->hsegs) {  // host wall time of the stages that run on the CPU (names start with "host_")

@@ -65,7 +65,8 @@ struct StageCall {  // a stage call made while decisions were pending: replayed 
 
 struct Seg {
   std::string name;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // event pairs, created once and reused
+  size_t used = 0;                                    // pairs recorded since profiling was (re)enabled
 };
 struct Prof {
   Seg* cur = nullptr;
