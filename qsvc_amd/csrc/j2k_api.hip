@@ -269,6 +269,9 @@ struct J2kState {
   std::vector<DwtSb> sbtab;
   uint8_t* gath_h = nullptr; size_t gath_h_cap = 0;
   hipEvent_t copied[4] = {nullptr, nullptr, nullptr, nullptr};  // the code bytes reach the host in up to four pieces
+  // Tier-1 in parts (longest blocks first): the MQ coder of part k runs on its own stream beside the context modelling of part k+1
+  hipStream_t mq_st[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t cm_done[3] = {nullptr, nullptr, nullptr}, mq_done[3] = {nullptr, nullptr, nullptr};
   std::vector<PlaneDesc> planes;
   std::vector<CbDesc> cbs;
   Pinned<CbOut> res;
@@ -287,6 +290,11 @@ void j2k_release(qsvc_ctx* c) {
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   for (auto& e : s->copied) if (e) (void)hipEventDestroy(e);
+  for (int k = 0; k < 3; k++) {
+    if (s->cm_done[k]) (void)hipEventDestroy(s->cm_done[k]);
+    if (s->mq_done[k]) (void)hipEventDestroy(s->mq_done[k]);
+    if (s->mq_st[k]) (void)hipStreamDestroy(s->mq_st[k]);
+  }
   s->h_nbps.release(); s->h_joboff.release(); s->res.release(); s->plen.release(); s->pdist.release(); s->h_err.release();
   delete s->pool;
   delete s;
@@ -552,16 +560,47 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     if ((r = S.segs_d.ensure(c, (njobs ? njobs : 1) * (size_t)T1_SEG_BYTES))) return r;
     if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
     if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
-    if (njobs) {  // one context-modelling wave per block, its bit-planes one after the other (plane p = job joboff[block] + p)
-      pf.begin(c, "j2k_t1_cm");
-      launch_t1_cm2(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p,
-                    (const unsigned long long*)S.mags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p, want_dist ? 1 : 0);
-      pf.end(c);
+    // Tier-1 in parts.  The MQ coder is a serial chain per code-block: its kernel lasts as long as its longest block, whatever
+    // else the chip does.  Context modelling, on the other hand, fills the chip.  So the slot table (longest blocks first) is cut
+    // into up to four parts of growing size; the blocks of part k are modelled (main stream), then their MQ coder starts on a
+    // stream of its own while the main stream models part k + 1: the long chains start early and the later, shorter ones end
+    // before them.  QSVC_T1_PARTS = 1 .. 4 (read per call; 1: one launch each, back to back -- what many sequences in flight use).
+    int nparts = [] { const char* e = getenv("QSVC_T1_PARTS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    if (!mq_sort || nslots < 64 * 16) nparts = 1;
+    int cut[5] = {0, 0, 0, 0, 0};
+    {
+      static const int frac[4][4] = {{100, 0, 0, 0}, {25, 100, 0, 0}, {8, 30, 100, 0}, {5, 15, 40, 100}};
+      const int nwg = nslots / MQW;
+      for (int k = 0; k < nparts; k++) cut[k + 1] = k == nparts - 1 ? nslots : MQW * ((nwg * frac[nparts - 1][k] + 99) / 100);
+      for (int k = 1; k <= nparts; k++) if (cut[k] < cut[k - 1]) cut[k] = cut[k - 1];
     }
-    pf.begin(c, "j2k_t1_mq");
-    launch_t1_mq(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p, (const int*)S.order_d.p, nslots,
-                 (const uint8_t*)S.segs_d.p, (const int*)S.cnt_d.p, (const long long*)S.dist_d.p, (uint8_t*)S.outbuf.p, J2K_OUTCAP,
-                 (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, (int*)S.err_d.p);
+    for (int k = 0; k + 1 < nparts; k++) {
+      if (!S.mq_st[k]) HIPCHK(c, hipStreamCreateWithFlags(&S.mq_st[k], hipStreamNonBlocking));
+      if (!S.cm_done[k]) HIPCHK(c, hipEventCreateWithFlags(&S.cm_done[k], hipEventDisableTiming));
+      if (!S.mq_done[k]) HIPCHK(c, hipEventCreateWithFlags(&S.mq_done[k], hipEventDisableTiming));
+    }
+    auto mq_part = [&](hipStream_t st, int k) {
+      if (cut[k + 1] > cut[k])
+        launch_t1_mq(st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p, (const int*)S.order_d.p + cut[k], cut[k + 1] - cut[k],
+                     (const uint8_t*)S.segs_d.p, (const int*)S.cnt_d.p, (const long long*)S.dist_d.p, (uint8_t*)S.outbuf.p, J2K_OUTCAP,
+                     (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, (int*)S.err_d.p);
+    };
+    pf.begin(c, "j2k_t1_cm");
+    for (int k = 0; k < nparts; k++) {
+      if (njobs && cut[k + 1] > cut[k])  // one context-modelling wave per block, its bit-planes one after the other (plane p = job joboff[block] + p)
+        launch_t1_cm2(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p, (const int*)S.order_d.p + cut[k],
+                      cut[k + 1] - cut[k], (const unsigned long long*)S.mags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p, want_dist ? 1 : 0);
+      if (k + 1 < nparts) {
+        HIPCHK(c, hipEventRecord(S.cm_done[k], c->st));
+        HIPCHK(c, hipStreamWaitEvent(S.mq_st[k], S.cm_done[k], 0));
+        mq_part(S.mq_st[k], k);
+        HIPCHK(c, hipEventRecord(S.mq_done[k], S.mq_st[k]));
+      }
+    }
+    pf.end(c);
+    pf.begin(c, "j2k_t1_mq");  // (with parts: what of the MQ stage is left after the last part's context modelling)
+    mq_part(c->st, nparts - 1);
+    for (int k = 0; k + 1 < nparts; k++) HIPCHK(c, hipStreamWaitEvent(c->st, S.mq_done[k], 0));
     pf.end(c);
   }
   // (the per-pass lengths and distortions only matter when some layer leaves passes out: lossless single-layer streams take every pass)

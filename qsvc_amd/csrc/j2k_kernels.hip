@@ -381,7 +381,7 @@ void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneD
 }
 
 #define CM2_OUT_BYTES 10240  // the largest pass segment (clean-up: 10 decisions per stripe column at most)
-__global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff,
+__global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff, const int* order,
                                                 const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist) {
   __shared__ uint32_t s_cw[18][66];
   __shared__ uint32_t s_sp[64];
@@ -389,7 +389,9 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
   __shared__ __attribute__((aligned(16))) uint8_t s_out[CM2_OUT_BYTES + 16];  // zeroed per plane; the streams OR whole words into it
   __shared__ uint8_t s_sign[256];
   __shared__ uint64_t s_rowM[64];
-  const int lane = threadIdx.x, b = blockIdx.x;
+  // order != nullptr: workgroup k models block order[k] (the MQ stage's slot table: longest blocks first; ncb = an idle slot)
+  const int lane = threadIdx.x, b = order ? order[blockIdx.x] : (int)blockIdx.x;
+  if (b >= ncb) return;
   const CbDesc cb = cbs[b];
   const int w = cb.w, h = cb.h, nstr = (h + 3) >> 2, orient = cb.orient;
   const int nb = nbps_in[b] > 15 ? 15 : nbps_in[b];
@@ -650,9 +652,11 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads();  // the next plane rewrites the column words and the streams
   }  // planes
 }
-void launch_t1_cm2(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const unsigned long long* mags,
-                   uint8_t* segs, int* cnt, long long* dist, int want_dist) {
-  if (ncb > 0) hipLaunchKernelGGL(k_t1_cm2, dim3(ncb), dim3(64), 0, st, cbs, ncb, nbps, joboff, mags, segs, cnt, dist, want_dist);
+// order == nullptr: every block, in index order; else the `count` slots order[0 .. count)
+void launch_t1_cm2(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int count,
+                   const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist) {
+  const int n = order ? count : ncb;
+  if (n > 0) hipLaunchKernelGGL(k_t1_cm2, dim3(n), dim3(64), 0, st, cbs, ncb, nbps, joboff, order, mags, segs, cnt, dist, want_dist);
 }
 
 // gather: segment of block b (bytes 1..len of its lane buffer) -> dst + offs[b]

@@ -10,7 +10,7 @@ void launch_pyr_ll_tile(hipStream_t st, const uint8_t* frames, size_t F, int W, 
 void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int l, int R, int C);
 void launch_me_search(hipStream_t st, const MeArgs& a, int mv_bound);
 bool me_piece_applies(const MeArgs& a);          // mctf_me.hip
-void launch_me_piece(hipStream_t st, const MeArgs& a);
+void launch_me_piece(hipStream_t st, const MeArgs& a, int ring_blocks);  // a.ring set: the ring role rides in the same launch
 // chroma x2 interpolation (decorrelate.cpp:610-648, update.cpp:472-503) of pictures frames[mul*k], k < count, both components,
 // into cup[k][c][H][W]: computed once per even picture instead of inside every prediction / update footprint
 void launch_chroma_up(hipStream_t st, const uint8_t* frames, const LevelGeom& g, int mul, int count, uint8_t* cup);

@@ -10,6 +10,7 @@
 // mctf_kernels.hip, which enumerate only the ring of the block grid where such blocks can lie (MeArgs::ring).
 #include <hip/hip_runtime.h>
 #include "mctf_kernels.h"
+#include "mctf_me_ring.h"
 
 namespace qsvc {
 
@@ -112,12 +113,22 @@ __device__ __forceinline__ void me_piece_sums(const MePiece<T>& pc, const T* ref
 }
 
 // SUB = bs / 8 pieces per block side; LPB = SUB * SUB lanes per block, 64 / LPB blocks per wave, 4 waves per workgroup
+// Workgroups [0, npx * nby * nB): the piece role; the rest: the ring role, a wave per group of ring blocks (8 blocks of 8x8 per
+// wave, or one larger block per wave), which skips the blocks the piece role takes (MeArgs::ring).
 template <class T, int SUB>
-__global__ void __launch_bounds__(256) k_me_piece(MeArgs a) {
+__global__ void __launch_bounds__(256) k_me_piece(MeArgs a, int npx, int ring_groups) {
   constexpr int LPB = SUB * SUB, BPW = 64 / LPB;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int npiece = npx * a.nby * a.g.nB;
+  if ((int)blockIdx.x >= npiece) {
+    const int r = (int)blockIdx.x - npiece, per_pic = (ring_groups + 3) / 4, gi = (r % per_pic) * 4 + wv;
+    if (gi >= ring_groups) return;
+    if (SUB == 1) me_search8_body<T>(a, gi, 0, r / per_pic, lane);
+    else me_search_body<T, 64>(a, gi, 0, r / per_pic, lane);
+    return;
+  }
   const int grp = lane / LPB, li = lane % LPB;
-  const int bx = (blockIdx.x * 4 + wv) * BPW + grp, by = blockIdx.y, i = blockIdx.z;
+  const int bx = ((int)(blockIdx.x % npx) * 4 + wv) * BPW + grp, by = (int)(blockIdx.x / npx) % a.nby, i = (int)blockIdx.x / (npx * a.nby);
   const int bs = a.g.bs, H = a.g.H, W = a.g.W;
   int pvx = 0, pvy = 0, nvx = 0, nvy = 0;
   bool go = bx < a.nbx;
@@ -168,14 +179,17 @@ __global__ void __launch_bounds__(256) k_me_piece(MeArgs a) {
 }
 
 template <class T>
-static void launch_piece(hipStream_t st, const MeArgs& a) {
+static void launch_piece(hipStream_t st, const MeArgs& a, int ring_blocks) {
   const int sub = a.g.bs / 8, bpw = 64 / (sub * sub);
-  dim3 grid((a.nbx + 4 * bpw - 1) / (4 * bpw), a.nby, a.g.nB), block(256);
+  const int npx = (a.nbx + 4 * bpw - 1) / (4 * bpw);
+  const int ring_groups = sub == 1 ? (ring_blocks + 7) / 8 : ring_blocks;      // waves the ring needs per picture
+  const unsigned nwg = (unsigned)(npx * a.nby * a.g.nB + ((ring_groups + 3) / 4) * a.g.nB);
+  dim3 grid(nwg), block(256);
   switch (sub) {
-    case 1: hipLaunchKernelGGL((k_me_piece<T, 1>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_me_piece<T, 2>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((k_me_piece<T, 4>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((k_me_piece<T, 8>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_me_piece<T, 1>), grid, block, 0, st, a, npx, ring_groups); break;
+    case 2: hipLaunchKernelGGL((k_me_piece<T, 2>), grid, block, 0, st, a, npx, ring_groups); break;
+    case 4: hipLaunchKernelGGL((k_me_piece<T, 4>), grid, block, 0, st, a, npx, ring_groups); break;
+    default: hipLaunchKernelGGL((k_me_piece<T, 8>), grid, block, 0, st, a, npx, ring_groups); break;
   }
 }
 bool me_piece_applies(const MeArgs& a) {
@@ -183,9 +197,9 @@ bool me_piece_applies(const MeArgs& a) {
   // 32-bit sample offsets inside a plane; the search windows of a piece are read without any border rule
   return a.g.bord == 0 && (bs == 8 || bs == 16 || bs == 32 || bs == 64) && (size_t)a.g.H * a.g.W < (1u << 30);
 }
-void launch_me_piece(hipStream_t st, const MeArgs& a) {
-  if (a.l == 0) launch_piece<uint8_t>(st, a);
-  else launch_piece<int16_t>(st, a);
+void launch_me_piece(hipStream_t st, const MeArgs& a, int ring_blocks) {
+  if (a.l == 0) launch_piece<uint8_t>(st, a, ring_blocks);
+  else launch_piece<int16_t>(st, a, ring_blocks);
 }
 
 }  // namespace qsvc
