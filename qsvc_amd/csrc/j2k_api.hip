@@ -560,12 +560,14 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     if ((r = S.segs_d.ensure(c, (njobs ? njobs : 1) * (size_t)T1_SEG_BYTES))) return r;
     if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
     if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
-    // Tier-1 in parts.  The MQ coder is a serial chain per code-block: its kernel lasts as long as its longest block, whatever
-    // else the chip does.  Context modelling, on the other hand, fills the chip.  So the slot table (longest blocks first) is cut
-    // into up to four parts of growing size; the blocks of part k are modelled (main stream), then their MQ coder starts on a
-    // stream of its own while the main stream models part k + 1: the long chains start early and the later, shorter ones end
-    // before them.  QSVC_T1_PARTS = 1 .. 4 (read per call; 1: one launch each, back to back -- what many sequences in flight use).
-    int nparts = [] { const char* e = getenv("QSVC_T1_PARTS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    // Tier-1 in parts (an experiment kept behind QSVC_T1_PARTS = 2 .. 4; default 1 = one launch each, back to back).  The MQ
+    // coder is a serial chain per code-block: its kernel lasts as long as its longest block, whatever else the chip does, while
+    // context modelling fills the chip.  The idea: cut the slot table (longest blocks first) into parts of growing size, model
+    // part k on the main stream and start its MQ coder on a stream of its own beside the modelling of part k + 1.  MEASURED
+    // (profiles/r03_*): no gain -- the modelling workgroups (11 KB of LDS each, 14 per CU) leave no room for an MQ
+    // workgroup (25-40 KB) on any CU until they drain, so the side streams' kernels start when the modelling ends anyway
+    // (single sequence 6.35 -> 6.77 ms with 4 parts, 12 sequences in flight 5200 -> 4280 fps).
+    int nparts = [] { const char* e = getenv("QSVC_T1_PARTS"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
     if (!mq_sort || nslots < 64 * 16) nparts = 1;
     int cut[5] = {0, 0, 0, 0, 0};
     {
