@@ -68,14 +68,16 @@ def cpu_baseline(reversible=True, frames=None):
     from oracle import j2k as J
     from qsvc_amd.synth import make_clip
     full = GOPS * 2 ** (TRLS - 1) + 1
-    frames = full  # the pictures of one GPU step's sequence
+    # a bounded sample (about 10-30 s of one core): the whole sequence of one GPU step at 1080p (17 pictures, 3 levels); at 4K the
+    # first 5 pictures through 2 temporal levels (the per-picture cost of a level does not depend on the level count)
+    frames, trls = (full, TRLS) if W * H <= 1920 * 1088 else (5, 3)
     clip = make_clip("pan_noise", frames, W, H, 43)
     t0 = time.perf_counter()
     if O.have_ref():
-        lv = O.ref_analyze(clip, W, H, TRLS, BS, S0)
+        lv = O.ref_analyze(clip, W, H, trls, BS, S0)
         mctf_kind = "reference tools (oracle/_ref)"
     else:
-        lv = O.analyze(clip, W, H, TRLS, BS, S0)
+        lv = O.analyze(clip, W, H, trls, BS, S0)
         mctf_kind = "restatement (oracle/mctf_oracle.c)"
     t1 = time.perf_counter()
     pics = [f for l in lv for f in l["high"]] + list(lv[-1]["low"])
@@ -87,7 +89,7 @@ def cpu_baseline(reversible=True, frames=None):
             ncb += st["codeblocks"]
     t2 = time.perf_counter()
     return {"value": round(frames / (t2 - t0), 4), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"the whole {frames}-picture sequence of one step: {TRLS - 1} MCTF levels via {mctf_kind} ({t1 - t0:.2f} s) + "
+            "sample": f"{'the whole' if frames == full else 'the first'} {frames}{'' if frames == full else ' of ' + str(full)} pictures of one step's sequence: {trls - 1} MCTF levels via {mctf_kind} ({t1 - t0:.2f} s) + "
                       f"{'5/3' if reversible else '9/7'} DWT/EBCOT of the {frames} subband pictures via the T.800 restatement "
                       f"({t2 - t1:.2f} s, {ncb} code-blocks); single thread",
             "mctf_s": round(t1 - t0, 3), "j2k_s": round(t2 - t1, 3), "codeblocks_per_s": round(ncb / (t2 - t1), 1)}
