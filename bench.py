@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the non-headline decode extra")
+    ap.add_argument("--no-iso", action="store_true", help="skip the single-sequence pass (profiling runs: exactly warmup + steps encodes per session)")
     ap.add_argument("--clip", default="pan_noise")
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
                     help="BASELINE.json configuration: 3 = 1080p 16-picture GOP pair, 5/3 lossless (the judged default); "
@@ -410,7 +411,7 @@ def main():
     for e in engs:
         e.set_profiling(False)
     serial_ms, iso = None, {}
-    if world == 1:  # ONE sequence alone on the chip: its latency, and every kernel group's ISOLATED duration (HIP events)
+    if world == 1 and not args.no_iso:  # ONE sequence alone on the chip: its latency, and every kernel group's ISOLATED duration (HIP events)
         if user_lds is None:
             os.environ.pop("QSVC_MQ_LDS", None)
         t2_single = t2_timed

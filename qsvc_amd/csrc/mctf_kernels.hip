@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(64) k_me_search8(MeArgs a) { me_search8_body<T
 void launch_me_search(hipStream_t st, const MeArgs& a0, int mv_bound) {
   MeArgs a = a0;
   a.ring = 0;
+  if (!(me_piece_applies(a) && getenv("QSVC_ME_PIECE") == nullptr)) a.zero_words = nullptr;  // only the piece launch zeroes
   a.rby_lo = a.rby_hi = a.rbx_lo = a.rbx_hi = 0;
   if (me_piece_applies(a) && getenv("QSVC_ME_PIECE") == nullptr) {
     // one launch: inner blocks (one lane per 8x8 samples, no border rule) and, as a second role of the same grid, the ring of the
@@ -465,16 +466,12 @@ bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, in
 bool pred_fast_path(const PredArgs& a) { return pred_run_applies(a) && getenv("QSVC_PRED_RUN") == nullptr; }
 void launch_predict(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
-  if (!a.odd_out) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
   dim3 block(64, 4);
-  if (pred_fast_path(a)) {  // mctf_pred.hip: runs of 8 samples, chroma straight from the half-resolution planes
+  if (pred_fast_path(a)) {  // mctf_pred.hip: one launch (chroma tiles, luma strips, motion histogram + motion_filtered copy)
     launch_predict_run(st, a);
-    size_t per_pic = (size_t)4 * g.BY * g.BX;
-    int nblk = (int)((per_pic + 255) / 256);
-    if (nblk > 64) nblk = 64;
-    hipLaunchKernelGGL(k_mv_hist, dim3(nblk, g.nB), dim3(256), 0, st, a.mv, per_pic, a.hist);
     return;
   }
+  if (!a.odd_out) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
   if (a.margin) launch_pred_margin(st, a);  // mctf_margin.hip
   if (g.bs % 8 == 0) hipLaunchKernelGGL(k_pred_luma8, dim3((g.W + 511) / 512, (g.H + 3) / 4, g.nB), block, 0, st, a);
   else hipLaunchKernelGGL(k_pred_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a);

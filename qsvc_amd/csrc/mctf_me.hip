@@ -120,6 +120,8 @@ __global__ void __launch_bounds__(256) k_me_piece(MeArgs a, int npx, int ring_gr
   constexpr int LPB = SUB * SUB, BPW = 64 / LPB;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int npiece = npx * a.nby * a.g.nB;
+  if (a.zero_words)  // (the predict kernel that follows on the stream adds into these histograms)
+    for (int k = (int)blockIdx.x * 256 + (int)threadIdx.x; k < a.zero_count; k += (int)gridDim.x * 256) a.zero_words[k] = 0;
   if ((int)blockIdx.x >= npiece) {
     const int r = (int)blockIdx.x - npiece, per_pic = (ring_groups + 3) / 4, gi = (r % per_pic) * 4 + wv;
     if (gi >= ring_groups) return;

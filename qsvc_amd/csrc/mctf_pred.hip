@@ -156,22 +156,38 @@ bool pred_run_applies(const PredArgs& a) {
 }
 // One launch per level: the chroma tiles (the longer workgroups) first, then the luma strips; a workgroup's role follows from
 // its index.  256 threads, 32 KB of LDS (the luma histograms; a chroma tile needs 8.4 KB of it).
-__global__ void __launch_bounds__(256) k_pred_level(PredArgs a, int ncx, int ncy, int nlx, int nly) {
+__global__ void __launch_bounds__(256) k_pred_level(PredArgs a, int ncx, int ncy, int nlx, int nly, int nmh) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 256 * PL_K * 4];
   static_assert(sizeof(smem) >= PCT_SMEM_BYTES, "chroma tile fits");
   int b = blockIdx.x;
-  const int nchroma = ncx * ncy * a.g.nB * 2;
-  if (b < nchroma) {
-    pred_chroma_body(a, smem, b % ncx, (b / ncx) % ncy, b / (ncx * ncy), threadIdx.x);
-  } else {
-    b -= nchroma;
-    pred_luma_body(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x & 63, threadIdx.x >> 6);
+  const int nchroma = ncx * ncy * a.g.nB * 2, nluma = nlx * nly * a.g.nB;
+  if (b < nchroma) { pred_chroma_body(a, smem, b % ncx, (b / ncx) % ncy, b / (ncx * ncy), threadIdx.x); return; }
+  b -= nchroma;
+  if (b < nluma) { pred_luma_body(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x & 63, threadIdx.x >> 6); return; }
+  b -= nluma;
+  // last role: the histogram of the motion components + 128 (decorrelate.cpp:805-812), nmh workgroups per picture, which also
+  // copy their share of motion_t into motion_filtered_t
+  const int i = b / nmh, part = b % nmh, tid = threadIdx.x;
+  unsigned* h = (unsigned*)smem;
+  h[tid] = 0;
+  __syncthreads();
+  const size_t per_pic = (size_t)4 * a.g.BY * a.g.BX;
+  const int16_t* m = a.mv + (size_t)i * per_pic;
+  for (size_t k = (size_t)part * 256 + tid; k < per_pic; k += (size_t)nmh * 256) {
+    const int16_t v = m[k];
+    atomicAdd(&h[(v + 128) & 255], 1u);
+    if (a.mv_copy) a.mv_copy[(size_t)i * per_pic + k] = v;
   }
+  __syncthreads();
+  if (h[tid]) atomicAdd(&a.hist[((size_t)i * 3 + 2) * 256 + tid], h[tid]);
 }
 void launch_predict_run(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
   const int nlx = (g.W + 511) / 512, nly = (g.H + 15) / 16, ncx = (g.W / 2 + PCT_W - 1) / PCT_W, ncy = (g.H / 2 + PCT_H - 1) / PCT_H;
-  hipLaunchKernelGGL(k_pred_level, dim3((unsigned)(ncx * ncy * g.nB * 2 + nlx * nly * g.nB)), dim3(256), 0, st, a, ncx, ncy, nlx, nly);
+  int nmh = (int)(((size_t)4 * g.BY * g.BX + 255) / 256);
+  if (nmh > 64) nmh = 64;
+  if (!a.hist_is_zero) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
+  hipLaunchKernelGGL(k_pred_level, dim3((unsigned)(ncx * ncy * g.nB * 2 + nlx * nly * g.nB + nmh * g.nB)), dim3(256), 0, st, a, ncx, ncy, nlx, nly, nmh);
 }
 
 }  // namespace qsvc

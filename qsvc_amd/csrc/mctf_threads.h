@@ -63,6 +63,8 @@ struct MeArgs {
   // ring != 0: the border-rule kernels enumerate only that ring and skip its inner blocks.
   int ring;
   int rby_lo, rby_hi, rbx_lo, rbx_hi;
+  unsigned* zero_words;    // mctf_me.hip: the level-0 launch also zeroes this many words (the level's histograms), or nullptr
+  int zero_count;
 };
 // every sample the nine candidates of both directions read lies inside the picture (no border rule needed)
 QHD bool me_inner(int H, int W, int bs, int y0, int x0, int pvy, int pvx, int nvy, int nvx) {
@@ -138,6 +140,8 @@ struct PredArgs {
   uint8_t* odd_out;       // nullptr = analysis
   const uint8_t* types;   // [nB] 'I' / 'B' (synthesis only)
   const uint8_t* cup;     // [nB+1][2][H][W] u8: chroma x2 interpolation of every even picture (launch_chroma_up), or nullptr
+  int16_t* mv_copy;       // mctf_pred.hip only: motion_filtered_t starts as a copy of motion_t (decorrelate.cpp:1005-1025), or nullptr
+  int hist_is_zero;       // mctf_pred.hip only: the histograms were zeroed by the motion search's last launch (no memset needed)
 };
 // what correlate stores for one sample: the picture itself for 'I', clip(residue + prediction) for 'B'
 QHD int correlate_sample(int h, int p, int type) { return type == 'I' ? h : iclamp(h - 128 + p, 0, 255); }

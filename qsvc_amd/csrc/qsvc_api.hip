@@ -319,11 +319,17 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
     a.g = g; a.frames = frames; a.snap = l ? c->snap[l].p : nullptr; a.snap_pic_stride = N;
     a.mv_prev = prev; a.mv_out = l == 0 ? (int16_t*)lv.mv_raw.p : (int16_t*)c->mvtmp[l & 1].p;
     a.l = l; a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l);
+    a.zero_words = nullptr; a.zero_count = 0;
+    if (l == 0 && me_piece_applies(a)) {  // the level-0 launch also zeroes the level's histograms for the predict kernel behind it
+      if ((r = lv.hist.ensure(c, (size_t)g.nB * 3 * 256 * 4))) return r;
+      a.zero_words = (unsigned*)lv.hist.p; a.zero_count = g.nB * 3 * 256;
+    }
     pf.begin(c, l == 0 ? "me_search_l0" : "me_search_coarse");
     launch_me_search(c->st, a, bound);
     pf.end(c);
     prev = a.mv_out;
     bound = imin(2 * (bound + 1), S);
+    if (l == 0) lv.hist_zeroed = a.zero_words != nullptr && getenv("QSVC_ME_PIECE") == nullptr;
   }
   HIPCHK(c, hipGetLastError());
   return QSVC_OK;
@@ -469,6 +475,8 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   a.g = g; a.frames = (const uint8_t*)c->lv[t - 1].low.p; a.mv = (const int16_t*)lv.mv_raw.p;
   a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = (unsigned*)lv.hist.p;
   a.margin = nullptr; a.odd_out = nullptr; a.types = nullptr; a.cup = nullptr;
+  a.mv_copy = nullptr; a.hist_is_zero = lv.hist_zeroed ? 1 : 0;
+  lv.hist_zeroed = false;
   lv.ragged = (g.H % bs || g.W % bs);
   if (lv.ragged) {  // Q7: the chroma margins carry state from picture to picture
     if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
@@ -476,12 +484,14 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   }
   Prof pf;
   pf.begin(c, "predict");
-  if (!lv.ragged && !pred_fast_path(a) && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
+  const bool fast = !lv.ragged && g.ov < 2 && pred_fast_path(a);
+  if (fast) a.mv_copy = (int16_t*)lv.mv_filt.p;   // the fused launch also writes motion_filtered_t = motion_t
+  if (!lv.ragged && !fast && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
   if (g.ov >= 2) {
     if ((r = predict_overlapped(c, g, a))) return r;
   } else launch_predict(c->st, a);
   pf.end(c);
-  HIPCHK(c, hipMemcpyAsync(lv.mv_filt.p, lv.mv_raw.p, mvbytes, hipMemcpyDeviceToDevice, c->st));
+  if (!fast) HIPCHK(c, hipMemcpyAsync(lv.mv_filt.p, lv.mv_raw.p, mvbytes, hipMemcpyDeviceToDevice, c->st));
   static const bool defer_env = [] { const char* e = getenv("QSVC_DEFER_IB"); return !(e && e[0] == '0'); }();
   const bool defer = !always_B && c->defer_ok && defer_env && !c->resolving;
   if (defer) {
@@ -670,6 +680,7 @@ int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   a.g = g; a.frames = (const uint8_t*)out.low.p; a.mv = (const int16_t*)lv.mv_filt.p;
   a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = nullptr;
   a.margin = nullptr; a.odd_out = (uint8_t*)out.low.p; a.types = (const uint8_t*)c->tmp16[0].p; a.cup = nullptr;
+  a.mv_copy = nullptr; a.hist_is_zero = 0;
   if (g.H % bs || g.W % bs) {  // Q7 applies to the decoder's prediction planes as well
     if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
     a.margin = (int16_t*)c->margin.p;

@@ -53,6 +53,7 @@ struct Level {  // the device-resident "files" of temporal subband t
   bool ragged = false;           // Q7: decorrelate ran on a picture the block grid does not tile
   // Deferred I/B decision (qsvc_api.hip, "deferred decisions"): decorrelate has queued the histograms' way to `hhist` and gone
   // on as if every picture were 'B'; the float entropy rule runs on the host at the next point that needs its outcome.
+  bool hist_zeroed = false;      // motion_estimate's last launch has zeroed `hist` for this level's B pictures (consumed by decorrelate)
   bool pending = false;
   PinBuf hhist;                  // [nB][3][256] u32 on the host
   int dec_nB = 0, dec_BY = 0, dec_BX = 0;

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes, MI355X_MICROARCH.md 'HBM') per kernel.
 usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [encodes profiled]
-(encodes profiled: how many whole sequence encodes the profiled command ran -- bench.py --sessions 1 --steps 2 --warmup 1 runs
-1 + 2 in the timed part and 1 + 3 in its single-sequence pass = 7; gives hbm_bytes_per_step_raw = bytes per encode)
+(encodes profiled: how many whole sequence encodes the profiled command ran -- bench.py --sessions 1 --steps 4 --warmup 1
+--no-decode --no-iso runs 1 + 4 = 5; gives hbm_bytes_per_step_raw = bytes per encode)
 Units: the counters are in KiB.  On gfx950 FETCH_SIZE reads exactly half of a wide coalesced stream's bytes and is
 uncalibrated for other access widths, so both the raw sum and the 'fetch doubled' figure are kept."""
 import collections, csv, json, sys
@@ -18,7 +18,7 @@ def load(path, cname):
 
 
 f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-steps = int(sys.argv[4]) if len(sys.argv) > 4 else 7
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 out = {}
 for k in f:
     n = len(f[k])

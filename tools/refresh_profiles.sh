@@ -11,18 +11,18 @@ tag=$1; cfg=${2:-3}
 R=$PWD
 export TMPDIR=/tmp PYTHONPATH=$R
 mkdir -p gpurun_out
-rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${tag}_pmc_f -o p --output-format csv -- python3 bench.py --config $cfg --sessions 1 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${tag}_pmc_w -o p --output-format csv -- python3 bench.py --config $cfg --sessions 1 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_pmc_w.log 2>&1
-# 7 = the encodes that command runs: 1 warm-up + 2 timed + (1 + 3) of the single-sequence pass
-python3 tools/pmc_summary.py $(find gpurun_out/${tag}_pmc_f -name "*counter_collection.csv") $(find gpurun_out/${tag}_pmc_w -name "*counter_collection.csv") gpurun_out/${tag}_pmc_hbm.json 7 > /dev/null
+rocprofv3 --pmc FETCH_SIZE -d gpurun_out/${tag}_pmc_f -o p --output-format csv -- python3 bench.py --config $cfg --sessions 1 --steps 4 --warmup 1 --no-cpu-baseline --no-decode --no-iso > gpurun_out/${tag}_pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d gpurun_out/${tag}_pmc_w -o p --output-format csv -- python3 bench.py --config $cfg --sessions 1 --steps 4 --warmup 1 --no-cpu-baseline --no-decode --no-iso > gpurun_out/${tag}_pmc_w.log 2>&1
+# 5 = the encodes that command runs: 1 warm-up + 4 timed (no single-sequence pass, no decode extra)
+python3 tools/pmc_summary.py $(find gpurun_out/${tag}_pmc_f -name "*counter_collection.csv") $(find gpurun_out/${tag}_pmc_w -name "*counter_collection.csv") gpurun_out/${tag}_pmc_hbm.json 5 > /dev/null
 echo "pmc done"
 python3 bench.py --config $cfg > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -c 400 gpurun_out/${tag}_bench.json; echo
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -o b --output-format csv -- python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -o b --output-format csv -- python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-iso > gpurun_out/${tag}_prof.log 2>&1
 cp $(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_kernel_stats.csv
 echo "multi-session stats done"
 python3 bench.py --config $cfg --sessions 1 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_s1_bench.json 2> gpurun_out/${tag}_s1_bench.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_s1_prof -o b --output-format csv -- python3 bench.py --config $cfg --sessions 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_s1_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_s1_prof -o b --output-format csv -- python3 bench.py --config $cfg --sessions 1 --steps 7 --warmup 1 --no-cpu-baseline --no-decode --no-iso > gpurun_out/${tag}_s1_prof.log 2>&1
 cp $(find gpurun_out/${tag}_s1_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_s1_kernel_stats.csv
 rm -rf gpurun_out/${tag}_prof gpurun_out/${tag}_s1_prof gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w
-python3 tools/kstats.py gpurun_out/${tag}_s1_kernel_stats.csv 8 | head -30
+python3 tools/kstats.py gpurun_out/${tag}_s1_kernel_stats.csv 8 | head -30   # 8 encodes: 1 warm-up + 7 timed
