@@ -274,6 +274,9 @@ struct J2kState {
   hipEvent_t cm_done[3] = {nullptr, nullptr, nullptr}, mq_done[3] = {nullptr, nullptr, nullptr};
   std::vector<PlaneDesc> planes;
   std::vector<CbDesc> cbs;
+  // what the device tables hold (a video encoder codes the same geometry step after step: identical tables are not uploaded again)
+  std::vector<uint8_t> up_planes, up_cbs, up_sbtab;
+  const void *up_planes_at = nullptr, *up_cbs_at = nullptr, *up_sbtab_at = nullptr;
   Pinned<CbOut> res;
   Pinned<int> plen;
   Pinned<long long> pdist;
@@ -281,6 +284,21 @@ struct J2kState {
   std::vector<HostCb> hcb;
   uint64_t st_cb = 0, st_pass = 0, st_sym = 0;
 };
+
+// H2D copy of a host-built table unless the device buffer already holds exactly these bytes (same buffer, same content).  The
+// shadow copy is what was last uploaded from; the source of the async copy is the shadow, which outlives the call.
+static int upload_if_changed(qsvc_ctx* c, void* dev, const void* src, size_t bytes, std::vector<uint8_t>& shadow, const void*& at) {
+  if (at == dev && shadow.size() == bytes && (bytes == 0 || memcmp(shadow.data(), src, bytes) == 0)) return QSVC_OK;
+  hipError_t e = hipStreamSynchronize(c->st);  // (a copy still reading the old shadow must have finished before it is overwritten)
+  if (e != hipSuccess) return c->hipfail(e, "hipStreamSynchronize");
+  shadow.assign((const uint8_t*)src, (const uint8_t*)src + bytes);
+  at = dev;
+  if (bytes) {
+    e = hipMemcpyAsync(dev, shadow.data(), bytes, hipMemcpyHostToDevice, c->st);
+    if (e != hipSuccess) { at = nullptr; return c->hipfail(e, "hipMemcpyAsync(table)"); }
+  }
+  return QSVC_OK;
+}
 
 void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
@@ -484,7 +502,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     if ((r = S.llA.ensure(c, llA_n * ll_elem + 64))) return r;
     if ((r = S.llB.ensure(c, llB_n * ll_elem + 64))) return r;
     if ((r = S.sbtab_d.ensure(c, S.sbtab.size() * sizeof(DwtSb)))) return r;
-    HIPCHK(c, hipMemcpyAsync(S.sbtab_d.p, S.sbtab.data(), S.sbtab.size() * sizeof(DwtSb), hipMemcpyHostToDevice, c->st));
+    if ((r = upload_if_changed(c, S.sbtab_d.p, S.sbtab.data(), S.sbtab.size() * sizeof(DwtSb), S.up_sbtab, S.up_sbtab_at))) return r;
   }
   if ((r = S.planes_d.ensure(c, np * sizeof(PlaneDesc)))) return r;
   if ((r = S.cbs_d.ensure(c, (size_t)ncb * sizeof(CbDesc)))) return r;
@@ -497,8 +515,8 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   if ((r = S.offs_d.ensure(c, (size_t)ncb * 8))) return r;
   if ((r = S.lens_d.ensure(c, (size_t)ncb * 4))) return r;
   if ((r = S.err_d.ensure(c, 16))) return r;
-  HIPCHK(c, hipMemcpyAsync(S.planes_d.p, S.planes.data(), np * sizeof(PlaneDesc), hipMemcpyHostToDevice, c->st));
-  HIPCHK(c, hipMemcpyAsync(S.cbs_d.p, S.cbs.data(), (size_t)ncb * sizeof(CbDesc), hipMemcpyHostToDevice, c->st));
+  if ((r = upload_if_changed(c, S.planes_d.p, S.planes.data(), np * sizeof(PlaneDesc), S.up_planes, S.up_planes_at))) return r;
+  if ((r = upload_if_changed(c, S.cbs_d.p, S.cbs.data(), (size_t)ncb * sizeof(CbDesc), S.up_cbs, S.up_cbs_at))) return r;
   HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
   Prof pf;
   if (maxL > 0) {
@@ -524,7 +542,11 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     perr = 0;
     HIPCHK(c, hipMemcpyAsync(S.h_nbps.data(), S.nbps_d.p, (size_t)ncb * 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(&perr, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    {
+      const auto w0 = std::chrono::steady_clock::now();
+      HIPCHK(c, hipStreamSynchronize(c->st));
+      c->host_time("host_wait_dwt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+    }
     // a block with more bit-planes than its subband allows (or than the 15-bit magnitude format holds) must never reach
     // the context-modelling / MQ kernels: their job and pass tables are sized for nbps <= 15
     if (perr) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
@@ -616,7 +638,11 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     HIPCHK(c, hipMemcpyAsync(S.plen.data(), S.plen_d.p, (size_t)ncb * T1_MAXPASS * 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(S.pdist.data(), S.pdist_d.p, (size_t)ncb * T1_MAXPASS * 8, hipMemcpyDeviceToHost, c->st));
   }
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  {
+    const auto w0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->host_time("host_wait_tier1", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+  }
   HIPCHK(c, hipGetLastError());
   if (err & 2) return c->fail(QSVC_ERR_HIP, "internal: the MQ coder's wave pair lost step (a wait gave up)");
   if (err) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
