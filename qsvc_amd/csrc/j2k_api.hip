@@ -524,7 +524,9 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     // packed straight into the Tier-1 magnitudes; the blocks' largest magnitudes are collected by atomicMax into nbps_d
     pf.begin(c, rev ? "j2k_dwt53" : "j2k_dwt97");
     HIPCHK(c, hipMemsetAsync(S.nbps_d.p, 0, (size_t)ncb * 4, c->st));
-    launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, (const DwtSb*)S.sbtab_d.p, maxL, rev, S.llA.p, S.llB.p,
+    int minW = maxW, minH = maxH;
+    for (const PlaneDesc& q : S.planes) { if (q.W < minW) minW = q.W; if (q.H < minH) minH = q.H; }
+    launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, minW, minH, (const DwtSb*)S.sbtab_d.p, maxL, rev, S.llA.p, S.llB.p,
                      (unsigned long long*)S.mags.p, (int*)S.nbps_d.p, nullptr, ilog2i(cbw), ilog2i(cbh), (int*)S.err_d.p);
     launch_t1_nbps(c->st, (const CbDesc*)S.cbs_d.p, ncb, (int*)S.nbps_d.p, (int*)S.err_d.p);
     pf.end(c);
@@ -899,7 +901,7 @@ int qsvc_j2k_dwt(qsvc_ctx* c, const uint8_t* plane, int H, int W, int reversible
   HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
   // the same tile kernel as the encoder's, with the subbands written to a Mallat-layout plane instead of the Tier-1 layout
   if (L == 0) launch_level_shift(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, S.coefA.p, reversible != 0);
-  else launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, nullptr, L, reversible != 0, S.llA.p, S.llB.p, nullptr, nullptr,
+  else launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, W, H, nullptr, L, reversible != 0, S.llA.p, S.llB.p, nullptr, nullptr,
                         S.coefA.p, 6, 6, (int*)S.err_d.p);
   HIPCHK(c, hipMemcpyAsync(out, S.coefA.p, N * 4, hipMemcpyDeviceToHost, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));

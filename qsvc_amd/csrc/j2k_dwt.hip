@@ -16,6 +16,7 @@
 // a plain parallel map over the tile with one barrier after it.  No MFMA: there is no contraction here.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <stdlib.h>
 #include "j2k_kernels.h"
 
 namespace qsvc {
@@ -333,11 +334,194 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Reversible 5/3, packed form (the Tier-1 path of lossless coding; k_dwt_tile above stays for 9/7, for the unit-test plane
+// output and for levels smaller than 4 samples).  Same tile, same outputs, but the samples live in LDS as PAIRS of 16-bit
+// values (two adjacent columns per word: half the LDS, and every lifting operation works on two samples -- v_pk_add_i16,
+// v_pk_ashrrev_i16), the tile is staged with the signal's ends already mirrored (whole-sample symmetric extension is exactly
+// the rule "a neighbour outside the signal is replaced by the one on the other side", so the lifting itself has no boundary
+// case), each of the two directions is ONE pass with the intermediate highs in registers instead of two read-modify-write
+// sweeps, and the four rows of a stripe column are produced by the same lane, so the Tier-1 words (4 x 16 bit per column)
+// leave without any exchange between lanes.
+//   vertical:   lane = (column pair, 8-row segment): 11 words in, highs and lows of 8 rows out (out of place)
+//   horizontal: lane = (2 subband columns, 4 rows of one parity = one stripe): even / odd columns de-interleaved with v_perm
+typedef short dp_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short dp_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dp_s2 dpS(uint32_t v) { return __builtin_bit_cast(dp_s2, v); }
+__device__ __forceinline__ uint32_t dpU(dp_s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t dp_add(uint32_t a, uint32_t b) { return dpU(dpS(a) + dpS(b)); }
+__device__ __forceinline__ uint32_t dp_sub(uint32_t a, uint32_t b) { return dpU(dpS(a) - dpS(b)); }
+__device__ __forceinline__ uint32_t dp_sar(uint32_t a, int k) { return dpU(dpS(a) >> (short)k); }
+// T.800 F.4.8.1 on both lanes: high = x - floor((l + r) / 2); low = x + floor((hl + hr + 2) / 4)
+__device__ __forceinline__ uint32_t dp_high(uint32_t x, uint32_t l, uint32_t r) { return dp_sub(x, dp_sar(dp_add(l, r), 1)); }
+__device__ __forceinline__ uint32_t dp_low(uint32_t x, uint32_t hl, uint32_t hr) { return dp_add(x, dp_sar(dp_add(dp_add(hl, hr), 0x00020002u), 2)); }
+// sign << 15 | magnitude of both lanes
+__device__ __forceinline__ uint32_t dp_signmag(uint32_t v) {
+  const uint32_t neg = dp_sar(v, 15);
+  return dp_sub(v ^ neg, neg) | (neg & 0x80008000u);
+}
+__device__ __forceinline__ int dwt_reflect(int i, int n) {  // whole-sample symmetric extension of index i into [0, n), n >= 2
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);  // (farther out than the lifting reads: any valid sample)
+}
+#define DP_NP (DT_NC / 2)           // column pairs per staged row
+#define DP_STR (DP_NP + 1)          // odd row stride (words)
+template <bool FROM_U8>
+__global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
+  constexpr int HALO = 2, NR = 2 * DT_TH + 2 * HALO;   // 36 rows: [2 ty0 - 2, 2 ty0 + 34)
+  static_assert(DT_TH == 16 && DT_TW == 64 && DT_CL == 4, "task maps of k_dwt53_pk");
+  __shared__ uint32_t sX[NR * DP_STR];   // staged input pairs
+  __shared__ uint32_t sV[NR * DP_STR];   // after the vertical lifting
+  const int tid = threadIdx.x;
+  const PlaneDesc pd = a.planes[blockIdx.z];
+  int w = pd.W, h = pd.H;
+  for (int l = 0; l < a.lev; l++) { w = (w + 1) >> 1; h = (h + 1) >> 1; }
+  const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, hw = w >> 1, hh = h >> 1;
+  const int tx0 = blockIdx.x * DT_TW, ty0 = blockIdx.y * DT_TH;
+  if (tx0 >= lw || ty0 >= lh) return;
+  const int gc0 = 2 * tx0 - DT_CL, gr0 = 2 * ty0 - HALO;
+  // ---- stage: 4 samples per thread-load; the signal's ends mirrored ----------------------------------------------------------
+  {
+    typedef const uint8_t __attribute__((address_space(1))) * gu8;
+    typedef const uint32_t __attribute__((address_space(1))) * gu32;
+    const gu8 u = (gu8)(uintptr_t)pd.src;
+    const int16_t* lin = (const int16_t*)a.llin + (((a.lev - 1) & 1) ? pd.ll[1] : pd.ll[0]);
+    const int sstr = FROM_U8 ? pd.u8stride : dwt_ll_stride(w);
+    const bool wide = FROM_U8 ? ((((uintptr_t)u) & 3) == 0 && (sstr & 3) == 0) : true;
+    constexpr int NQ = NR * (DT_NC / 4), NIT = (NQ + 255) / 256;
+    typedef typename std::conditional<FROM_U8, uint32_t, uint2>::type Raw;
+    Raw raw[NIT];
+    unsigned fast = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int idx = tid + it * 256, lr = idx / (DT_NC / 4), q = idx % (DT_NC / 4), gr = gr0 + lr, gc = gc0 + 4 * q;
+      if (idx < NQ && gr >= 0 && gr < h && gc >= 0 && gc + 3 < w && wide) {
+        fast |= 1u << it;
+        if constexpr (FROM_U8) raw[it] = *(gu32)(u + (size_t)gr * sstr + gc);
+        else raw[it] = *(const uint2*)(lin + (size_t)gr * sstr + gc);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int idx = tid + it * 256, lr = idx / (DT_NC / 4), q = idx % (DT_NC / 4), gr = gr0 + lr, gc = gc0 + 4 * q;
+      if (idx >= NQ) continue;
+      uint32_t p0, p1;
+      if (fast & (1u << it)) {
+        if constexpr (FROM_U8) {
+          const uint32_t d = raw[it];  // level shift: two samples per word, - 128 each
+          p0 = dp_sub(__builtin_amdgcn_perm(0u, d, 0x0c010c00u), 0x00800080u);
+          p1 = dp_sub(__builtin_amdgcn_perm(0u, d, 0x0c030c02u), 0x00800080u);
+        } else { p0 = raw[it].x; p1 = raw[it].y; }
+      } else {  // the signal's ends (or an unaligned source): sample by sample at the mirrored position
+        const int rr = dwt_reflect(gr, h);
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int cc = dwt_reflect(gc + k, w);
+          v[k] = FROM_U8 ? (int)u[(size_t)rr * sstr + cc] - 128 : (int)lin[(size_t)rr * sstr + cc];
+        }
+        p0 = ((uint32_t)v[0] & 0xFFFFu) | ((uint32_t)v[1] << 16);
+        p1 = ((uint32_t)v[2] & 0xFFFFu) | ((uint32_t)v[3] << 16);
+      }
+      uint32_t* p = sX + lr * DP_STR + 2 * q;
+      p[0] = p0; p[1] = p1;
+    }
+  }
+  __syncthreads();
+  // ---- vertical lifting: rows 1 .. 33 of the tile (row 0 is global row 2 ty0 - 2: even rows are lows, odd rows highs) --------
+  for (int k = tid; k < DP_NP * 4; k += 256) {
+    const int cp = k % DP_NP, q = k / DP_NP, r0 = 8 * q;
+    const uint32_t* x = sX + r0 * DP_STR + cp;
+    uint32_t xr[11];
+#pragma unroll
+    for (int r = 0; r < 11; r++) xr[r] = x[r * DP_STR];
+    uint32_t hv[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) hv[j] = dp_high(xr[2 * j + 1], xr[2 * j], xr[2 * j + 2]);   // rows r0 + 1, 3, 5, 7, 9
+    uint32_t* o = sV + r0 * DP_STR + cp;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      o[(2 * j + 1) * DP_STR] = hv[j];                                            // rows r0 + 1, 3, 5, 7
+      o[(2 * j + 2) * DP_STR] = dp_low(xr[2 * j + 2], hv[j], hv[j + 1]);          // rows r0 + 2, 4, 6, 8
+    }
+    if (q == 3) o[9 * DP_STR] = hv[4];                                            // row 33
+  }
+  __syncthreads();
+  // ---- horizontal lifting + output: lane = (parity ry, stripe s of the tile, 2 subband columns 2 cq, 2 cq + 1) -----------------
+  const bool last = a.lev == a.L - 1;
+  const int cq = tid & 31, sidx = (tid >> 5) & 3, ry = tid >> 7;
+  const int kx = 2 * cq;                       // the lane's first subband column within the tile
+  // columns: subband column kx <-> tile columns 4 + 2 kx (low) and 5 + 2 kx (high); even index e = 2 + kx counts tile columns 2 e
+  uint32_t Lw[4], Hw[4];                       // per row: {col kx, col kx + 1} of the low / high band
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int t = HALO + 2 * (4 * sidx + r) + ry;
+    const uint32_t* row = sV + t * DP_STR + (1 + kx);   // pairs holding tile columns 2 + 2 kx .. 9 + 2 kx
+    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];
+    const uint32_t E0 = __builtin_amdgcn_perm(d1, d0, 0x05040100u), E1 = __builtin_amdgcn_perm(d3, d2, 0x05040100u);  // evens e-1, e | e+1, e+2
+    const uint32_t O0 = __builtin_amdgcn_perm(d1, d0, 0x07060302u), O1 = __builtin_amdgcn_perm(d3, d2, 0x07060302u);  // odds between them
+    const uint32_t Es0 = __builtin_amdgcn_alignbit(E1, E0, 16);            // evens e, e + 1 (the lows' centres)
+    const uint32_t Es1 = __builtin_amdgcn_alignbit(0u, E1, 16);            // even e + 2, -
+    const uint32_t H0 = dp_high(O0, E0, Es0);                              // highs right of evens e - 1, e
+    const uint32_t H1 = dp_high(O1, E1, Es1);                              // high right of even e + 1 (second lane unused)
+    const uint32_t Hs = __builtin_amdgcn_alignbit(H1, H0, 16);             // highs right of evens e, e + 1 = subband columns kx, kx + 1
+    Lw[r] = dp_low(Es0, H0, Hs);
+    Hw[r] = Hs;
+  }
+  const int ky0 = 4 * sidx, y = ty0 + ky0, x = tx0 + kx;
+  // LL -> next level's input (int16 pairs)
+  if (!last && ry == 0) {
+    int16_t* lout = (int16_t*)a.llout + ((a.lev & 1) ? pd.ll[1] : pd.ll[0]);
+    const int ostr = dwt_ll_stride(lw);
+    if (x < ostr)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (y + r < lh) *(uint32_t*)(lout + (size_t)(y + r) * ostr + x) = Lw[r];   // columns in [lw, ostr) are padding, never read back
+  }
+  // HL / LH / HH (and LL of the last level): sign-magnitude, 4 rows of a stripe column per u64, into the block's Tier-1 words
+  const DwtSb* sbp = a.sbtab + (size_t)blockIdx.z * a.nsb;
+  const int lane = tid & 63;
+  const int span2 = a.cbwl >= 6 ? 32 : (1 << (a.cbwl - 1));   // lanes (of 2 columns) per code-block
+#pragma unroll
+  for (int band = 0; band < 2; band++) {       // 0: the low band of this row parity (LL / LH), 1: the high band (HL / HH)
+    const int sub = 2 * ry + band;
+    if (sub == 0 && !last) continue;
+    const int sbh = ry ? hh : lh, sbw = band ? hw : lw;
+    const DwtSb sb = sbp[sub == 0 ? 0 : 1 + 3 * (a.L - 1 - a.lev) + (sub == 1 ? 0 : (sub == 2 ? 1 : 2))];
+    int acc = 0;
+    if (y < sbh && x < sbw) {
+      uint32_t q[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        q[r] = y + r < sbh ? dp_signmag(band ? Hw[r] : Lw[r]) : 0u;
+        acc |= (int)(q[r] & 0x7FFF7FFFu);
+      }
+      if (x + 1 >= sbw) acc &= 0xFFFF;         // the second column lies beyond the subband
+      // column x: low halves of the four rows; column x + 1: high halves
+      const uint32_t c0lo = __builtin_amdgcn_perm(q[1], q[0], 0x05040100u), c0hi = __builtin_amdgcn_perm(q[3], q[2], 0x05040100u);
+      const uint32_t c1lo = __builtin_amdgcn_perm(q[1], q[0], 0x07060302u), c1hi = __builtin_amdgcn_perm(q[3], q[2], 0x07060302u);
+      const int bx = x >> a.cbwl, by = y >> a.cbhl;
+      const size_t b = (size_t)sb.first_cb + (size_t)by * sb.gx + bx;
+      unsigned long long* m = a.mags + b * 1024 + (size_t)(((y & ((1 << a.cbhl) - 1)) >> 2) * 64 + (x & ((1 << a.cbwl) - 1)));
+      if (x + 1 < sbw) *(uint4*)m = make_uint4(c0lo, c0hi, c1lo, c1hi);
+      else *(uint2*)m = make_uint2(c0lo, c0hi);
+    }
+    acc = (acc | (acc >> 16)) & 0x7FFF;
+    // OR over the lanes of each code-block (DPP row shifts), one atomic per (block, stripe): the group's last lane speaks
+    const int v = wave_or_segments(acc, span2);
+    if ((lane & (span2 - 1)) == span2 - 1 && v && y < sbh) {
+      const int xl = tx0 + 2 * (cq | (span2 - 1)) ;   // a column of this lane group's block (may lie beyond the subband: same block index)
+      atomicOr(&a.maxmag[sb.first_cb + (y >> a.cbhl) * sb.gx + ((xl < sbw ? xl : sbw - 1) >> a.cbwl)], v);
+    }
+  }
+}
+
 // Forward DWT of a batch of planes sharing L >= 1 levels.  mode 0: Tier-1 magnitudes; mode 1: Mallat plane (unit tests).
-void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, const DwtSb* d_sbtab, int L,
+void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, int minW0, int minH0, const DwtSb* d_sbtab, int L,
                       bool reversible, void* llA, void* llB, unsigned long long* mags, int* maxmag, void* plane_out,
                       int cbw_log2, int cbh_log2, int* err) {
-  int w = maxW, h = maxH;
+  int w = maxW, h = maxH, minW = minW0, minH = minH0;   // the largest and the smallest plane of the batch at this level
   for (int l = 0; l < L; l++) {
     const int lw = (w + 1) >> 1, lh = (h + 1) >> 1;
     DwtArgs a;
@@ -351,11 +535,15 @@ void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, in
       if (reversible) { if (l == 0) DWT_LAUNCH(true, true, true); else DWT_LAUNCH(true, false, true); }
       else { if (l == 0) DWT_LAUNCH(false, true, true); else DWT_LAUNCH(false, false, true); }
     } else {
-      if (reversible) { if (l == 0) DWT_LAUNCH(true, true, false); else DWT_LAUNCH(true, false, false); }
+      // the packed 5/3 kernel: levels of at least 4 x 4 samples, code-blocks at least 8 wide (QSVC_DWT_PK=0: the general kernel)
+      static const bool pk_env = [] { const char* e = getenv("QSVC_DWT_PK"); return !(e && e[0] == '0'); }();
+      const bool pk = reversible && pk_env && minW >= 4 && minH >= 4 && cbw_log2 >= 3 && cbh_log2 >= 2;
+      if (pk) { if (l == 0) hipLaunchKernelGGL(k_dwt53_pk<true>, grid, block, 0, st, a); else hipLaunchKernelGGL(k_dwt53_pk<false>, grid, block, 0, st, a); }
+      else if (reversible) { if (l == 0) DWT_LAUNCH(true, true, false); else DWT_LAUNCH(true, false, false); }
       else { if (l == 0) DWT_LAUNCH(false, true, false); else DWT_LAUNCH(false, false, false); }
     }
 #undef DWT_LAUNCH
-    w = lw; h = lh;
+    w = lw; h = lh; minW = (minW + 1) >> 1; minH = (minH + 1) >> 1;
   }
 }
 

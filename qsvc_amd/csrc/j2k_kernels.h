@@ -39,7 +39,7 @@ struct DwtSb {       // one subband of one plane as the DWT kernel addresses its
 #define T1_MAGS_BYTES (1024 * 8)
 
 // forward DWT, L >= 1 levels (j2k_dwt.hip); plane_out != nullptr selects the Mallat-plane form of the unit-test entry point
-void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, const DwtSb* d_sbtab, int L,
+void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, int minW, int minH, const DwtSb* d_sbtab, int L,
                       bool reversible, void* llA, void* llB, unsigned long long* mags, int* maxmag, void* plane_out,
                       int cbw_log2, int cbh_log2, int* err);
 // planes without a decomposition level: level shift into a 32-bit plane, then launch_t1_pack_blk

@@ -113,8 +113,7 @@ __device__ __forceinline__ void me_piece_sums(const MePiece<T>& pc, const T* ref
 }
 
 // SUB = bs / 8 pieces per block side; LPB = SUB * SUB lanes per block, 64 / LPB blocks per wave, 4 waves per workgroup
-// Workgroups [0, npx * nby * nB): the piece role; the rest: the ring role, a wave per group of ring blocks (8 blocks of 8x8 per
-// wave, or one larger block per wave), which skips the blocks the piece role takes (MeArgs::ring).
+// Workgroups [0, npx * nby * nB): the piece role; the rest: the ring role, a wave per ring block, which skips the blocks the piece role takes (MeArgs::ring).
 template <class T, int SUB>
 __global__ void __launch_bounds__(256) k_me_piece(MeArgs a, int npx, int ring_groups) {
   constexpr int LPB = SUB * SUB, BPW = 64 / LPB;
@@ -125,8 +124,7 @@ __global__ void __launch_bounds__(256) k_me_piece(MeArgs a, int npx, int ring_gr
   if ((int)blockIdx.x >= npiece) {
     const int r = (int)blockIdx.x - npiece, per_pic = (ring_groups + 3) / 4, gi = (r % per_pic) * 4 + wv;
     if (gi >= ring_groups) return;
-    if (SUB == 1) me_search8_body<T>(a, gi, 0, r / per_pic, lane);
-    else me_search_body<T, 64>(a, gi, 0, r / per_pic, lane);
+    me_search_body<T, 64>(a, gi, 0, r / per_pic, lane);  // one ring block per wave, a lane per sample (or a few): the shortest chain
     return;
   }
   const int grp = lane / LPB, li = lane % LPB;
@@ -184,7 +182,7 @@ template <class T>
 static void launch_piece(hipStream_t st, const MeArgs& a, int ring_blocks) {
   const int sub = a.g.bs / 8, bpw = 64 / (sub * sub);
   const int npx = (a.nbx + 4 * bpw - 1) / (4 * bpw);
-  const int ring_groups = sub == 1 ? (ring_blocks + 7) / 8 : ring_blocks;      // waves the ring needs per picture
+  const int ring_groups = ring_blocks;      // waves the ring needs per picture (one block each)
   const unsigned nwg = (unsigned)(npx * a.nby * a.g.nB + ((ring_groups + 3) / 4) * a.g.nB);
   dim3 grid(nwg), block(256);
   switch (sub) {
