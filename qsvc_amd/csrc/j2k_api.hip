@@ -264,6 +264,9 @@ struct J2kState {
   T2Pool* pool = nullptr;
   DevBuf coefA, llA, llB, sbtab_d, planes_d, cbs_d, nbps_d, mags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
   DevBuf joboff_d, order_d, segs_d, cnt_d, dist_d;  // Tier-1: first job of each block, MQ slot table, decision segments
+  DevBuf nbeff_d, njobs_d;                          // device job list: bit-planes as the Tier-1 kernels see them, total jobs
+  size_t jobs_cap = 0;                              // jobs the segment / count (/ distortion) buffers were last sized for
+  bool jobs_cap_dist = false;
   Pinned<int> h_nbps, h_joboff;
   std::vector<int> h_order;
   std::vector<DwtSb> sbtab;
@@ -304,7 +307,7 @@ void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->llA, &s->llB, &s->sbtab_d, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d};
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d, &s->nbeff_d, &s->njobs_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   for (auto& e : s->copied) if (e) (void)hipEventDestroy(e);
@@ -537,9 +540,32 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
                        (int*)S.nbps_d.p, (int*)S.err_d.p, rev);
     pf.end(c);
   }
-  {
+  // Tier-1.  The job list (bit-planes per block -> first job of each block, MQ slot table) is built ON THE DEVICE when the segment
+  // buffers of an earlier call can be reused: no host round trip between the DWT and Tier-1 (k_t1_joblist; QSVC_T1_DEVLIST=0 or
+  // QSVC_MQ_SORT=0: always the host's list).  If the batch needs more jobs than the buffers hold, the device list disarms the
+  // Tier-1 kernels and flags it, and the stage is run again with the host's list and larger buffers.
+  const int MQW = 64;
+  const int nslots = ((ncb + MQW - 1) / MQW) * MQW;
+  const bool mq_sort = [] { const char* e = getenv("QSVC_MQ_SORT"); return !e || atoi(e) != 0; }();
+  static const bool devlist_env = [] { const char* e = getenv("QSVC_T1_DEVLIST"); return !(e && e[0] == '0'); }();
+  bool devlist = devlist_env && mq_sort && S.jobs_cap > 0 && (!want_dist || S.jobs_cap_dist);
+  if (!S.res.resize(ncb) || !S.h_err.resize(2) || (want_dist && (!S.plen.resize((size_t)ncb * T1_MAXPASS) || !S.pdist.resize((size_t)ncb * T1_MAXPASS))))
+    return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
+  int& err = S.h_err[1];
+  for (;;) {
+    const int* nbp = (const int*)S.nbps_d.p;   // the bit-plane counts the Tier-1 kernels read
+    size_t njobs = 1;
+    if ((r = S.order_d.ensure(c, (size_t)nslots * 4))) return r;
+    if ((r = S.joboff_d.ensure(c, (size_t)ncb * 4))) return r;
+    if (devlist) {
+      if ((r = S.nbeff_d.ensure(c, (size_t)ncb * 4))) return r;
+      if ((r = S.njobs_d.ensure(c, 16))) return r;
+      launch_t1_joblist(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (int)std::min<size_t>(S.jobs_cap, 0x7fffffff), (int*)S.nbeff_d.p,
+                        (int*)S.joboff_d.p, (int*)S.order_d.p, nslots, (int*)S.njobs_d.p, (int*)S.err_d.p);
+      nbp = (const int*)S.nbeff_d.p;
+    } else {
     // the per-block bit-plane counts decide the job list: one context-modelling wave per (block, bit-plane)
-    if (!S.h_nbps.resize(ncb) || !S.h_err.resize(2)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
+    if (!S.h_nbps.resize(ncb)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
     int& perr = S.h_err[0];
     perr = 0;
     HIPCHK(c, hipMemcpyAsync(S.h_nbps.data(), S.nbps_d.p, (size_t)ncb * 4, hipMemcpyDeviceToHost, c->st));
@@ -551,16 +577,13 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     }
     // a block with more bit-planes than its subband allows (or than the 15-bit magnitude format holds) must never reach
     // the context-modelling / MQ kernels: their job and pass tables are sized for nbps <= 15
-    if (perr) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
+    if (perr & 1) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
     if (!S.h_joboff.resize(ncb)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
-    size_t njobs = 0;
+    njobs = 0;
     for (int b = 0; b < ncb; b++) { S.h_joboff[b] = (int)njobs; njobs += S.h_nbps[b] > 15 ? 15 : S.h_nbps[b]; }
     // MQ slot table: slot k of the MQ launch codes block order[k] (ncb = idle lane).  A wave runs until its longest block is
     // coded, so blocks of similar expected length (bit-planes x area) share a wave, the longest first (counting sort);
     // QSVC_MQ_SORT=0 keeps the natural order.
-    const int MQW = 64;
-    const bool mq_sort = [] { const char* e = getenv("QSVC_MQ_SORT"); return !e || atoi(e) != 0; }();
-    int nslots = 0;
     {
       std::vector<int>& ord = S.h_order;
       ord.resize(ncb);
@@ -573,17 +596,22 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
       } else {
         for (int b = 0; b < ncb; b++) ord[b] = b;
       }
-      while (ord.size() % MQW) ord.push_back(ncb);
-      nslots = (int)ord.size();
+      while ((int)ord.size() < nslots) ord.push_back(ncb);
     }
-    if ((r = S.order_d.ensure(c, (size_t)nslots * 4))) return r;
     HIPCHK(c, hipMemcpyAsync(S.order_d.p, S.h_order.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, c->st));
     // the MQ stage reads joboff[b] of every block, also when no block of the batch has a bit-plane (all-zero planes)
-    if ((r = S.joboff_d.ensure(c, (size_t)ncb * 4))) return r;
     HIPCHK(c, hipMemcpyAsync(S.joboff_d.p, S.h_joboff.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
-    if ((r = S.segs_d.ensure(c, (njobs ? njobs : 1) * (size_t)T1_SEG_BYTES))) return r;
-    if ((r = S.cnt_d.ensure(c, (njobs ? njobs : 1) * 3 * 4))) return r;
-    if (want_dist) if ((r = S.dist_d.ensure(c, (njobs ? njobs : 1) * 3 * 8))) return r;
+    // buffers with some headroom, so that the next calls (a video: much the same counts) can take the device list
+    const size_t want_jobs = njobs + njobs / 8 + 64;
+    if (want_jobs > S.jobs_cap || (want_dist && !S.jobs_cap_dist)) {
+      if ((r = S.segs_d.ensure(c, want_jobs * (size_t)T1_SEG_BYTES))) return r;
+      if ((r = S.cnt_d.ensure(c, want_jobs * 3 * 4))) return r;
+      if (want_dist) if ((r = S.dist_d.ensure(c, want_jobs * 3 * 8))) return r;
+      S.jobs_cap = std::min(S.segs_d.cap / (size_t)T1_SEG_BYTES, S.cnt_d.cap / 12);
+      if (want_dist) { S.jobs_cap = std::min(S.jobs_cap, S.dist_d.cap / 24); S.jobs_cap_dist = true; }
+      else S.jobs_cap_dist = S.dist_d.cap / 24 >= S.jobs_cap;
+    }
+    }
     // Tier-1 in parts (an experiment kept behind QSVC_T1_PARTS = 2 .. 4; default 1 = one launch each, back to back).  The MQ
     // coder is a serial chain per code-block: its kernel lasts as long as its longest block, whatever else the chip does, while
     // context modelling fills the chip.  The idea: cut the slot table (longest blocks first) into parts of growing size, model
@@ -607,14 +635,14 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     }
     auto mq_part = [&](hipStream_t st, int k) {
       if (cut[k + 1] > cut[k])
-        launch_t1_mq(st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p, (const int*)S.order_d.p + cut[k], cut[k + 1] - cut[k],
+        launch_t1_mq(st, (const CbDesc*)S.cbs_d.p, ncb, nbp, (const int*)S.joboff_d.p, (const int*)S.order_d.p + cut[k], cut[k + 1] - cut[k],
                      (const uint8_t*)S.segs_d.p, (const int*)S.cnt_d.p, (const long long*)S.dist_d.p, (uint8_t*)S.outbuf.p, J2K_OUTCAP,
                      (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, (int*)S.err_d.p);
     };
     pf.begin(c, "j2k_t1_cm");
     for (int k = 0; k < nparts; k++) {
       if (njobs && cut[k + 1] > cut[k])  // one context-modelling wave per block, its bit-planes one after the other (plane p = job joboff[block] + p)
-        launch_t1_cm2(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const int*)S.nbps_d.p, (const int*)S.joboff_d.p, (const int*)S.order_d.p + cut[k],
+        launch_t1_cm2(c->st, (const CbDesc*)S.cbs_d.p, ncb, nbp, (const int*)S.joboff_d.p, (const int*)S.order_d.p + cut[k],
                       cut[k + 1] - cut[k], (const unsigned long long*)S.mags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p, want_dist ? 1 : 0);
       if (k + 1 < nparts) {
         HIPCHK(c, hipEventRecord(S.cm_done[k], c->st));
@@ -628,26 +656,29 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     mq_part(c->st, nparts - 1);
     for (int k = 0; k + 1 < nparts; k++) HIPCHK(c, hipStreamWaitEvent(c->st, S.mq_done[k], 0));
     pf.end(c);
+    // (the per-pass lengths and distortions only matter when some layer leaves passes out: lossless single-layer streams take every pass)
+    err = 0;
+    HIPCHK(c, hipMemcpyAsync(S.res.data(), S.res_d.p, (size_t)ncb * sizeof(CbOut), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(&err, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
+    if (want_dist) {
+      HIPCHK(c, hipMemcpyAsync(S.plen.data(), S.plen_d.p, (size_t)ncb * T1_MAXPASS * 4, hipMemcpyDeviceToHost, c->st));
+      HIPCHK(c, hipMemcpyAsync(S.pdist.data(), S.pdist_d.p, (size_t)ncb * T1_MAXPASS * 8, hipMemcpyDeviceToHost, c->st));
+    }
+    {
+      const auto w0 = std::chrono::steady_clock::now();
+      HIPCHK(c, hipStreamSynchronize(c->st));
+      c->host_time("host_wait_tier1", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+    }
+    HIPCHK(c, hipGetLastError());
+    if (err & 2) return c->fail(QSVC_ERR_HIP, "internal: the MQ coder's wave pair lost step (a wait gave up)");
+    if (err & 1) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
+    if (devlist && (err & 4)) {  // the batch outgrew the segment buffers: once more with the host's list (which resizes them)
+      devlist = false;
+      HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
+      continue;
+    }
+    break;
   }
-  // (the per-pass lengths and distortions only matter when some layer leaves passes out: lossless single-layer streams take every pass)
-  if (!S.res.resize(ncb) || !S.h_err.resize(2) || (want_dist && (!S.plen.resize((size_t)ncb * T1_MAXPASS) || !S.pdist.resize((size_t)ncb * T1_MAXPASS))))
-    return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
-  int& err = S.h_err[1];
-  err = 0;
-  HIPCHK(c, hipMemcpyAsync(S.res.data(), S.res_d.p, (size_t)ncb * sizeof(CbOut), hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipMemcpyAsync(&err, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
-  if (want_dist) {
-    HIPCHK(c, hipMemcpyAsync(S.plen.data(), S.plen_d.p, (size_t)ncb * T1_MAXPASS * 4, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(S.pdist.data(), S.pdist_d.p, (size_t)ncb * T1_MAXPASS * 8, hipMemcpyDeviceToHost, c->st));
-  }
-  {
-    const auto w0 = std::chrono::steady_clock::now();
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    c->host_time("host_wait_tier1", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
-  }
-  HIPCHK(c, hipGetLastError());
-  if (err & 2) return c->fail(QSVC_ERR_HIP, "internal: the MQ coder's wave pair lost step (a wait gave up)");
-  if (err) return c->fail(QSVC_ERR_UNSUPPORTED, "a coefficient exceeds its subband's magnitude bit-planes (M_b) or 15 bits");
   // The code bytes of every block (all of them: what a layer leaves out is decided on the host meanwhile) are gathered in block
   // order and start their way to the host; rate allocation and the code-streams' lengths are worked out under that copy.
   std::vector<unsigned long long> goffs(ncb);

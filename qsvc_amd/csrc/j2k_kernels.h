@@ -50,6 +50,8 @@ void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, c
                   long long* pass_dist, int want_dist, int* err);
 void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneDesc* planes, const void* coef,
                         unsigned long long* mags, int* nbps, int* err, bool reversible);
+void launch_t1_joblist(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, int cap_jobs, int* nb_eff, int* joboff, int* order, int nslots,
+                       int* njobs_out, int* err);
 void launch_t1_cm2(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int count,
                    const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist);
 void launch_gather(hipStream_t st, const uint8_t* outbuf, int outcap, const unsigned long long* offs, const int* lens, int ncb,

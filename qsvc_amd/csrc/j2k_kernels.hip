@@ -48,6 +48,52 @@ void launch_t1_nbps(hipStream_t st, const CbDesc* cbs, int ncb, int* nbps, int* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The Tier-1 job list on the device (one workgroup): nb[b] = the block's bit-planes, joboff[b] = the exclusive prefix sum over the
+// blocks (plane p of block b is job joboff[b] + p: its decision segments' slot), order[] = the MQ stage's slot table -- blocks
+// sorted by expected length nb x area, longest first (counting sort on 961 keys; ties in any order: the slot table only decides
+// which blocks share a wave, never what is coded), padded with ncb (= idle lane) to nslots.  cap_jobs = the jobs the segment
+// buffers hold: if the batch needs more, nb is written as 0 for every block (the Tier-1 kernels then touch nothing) and err
+// gets bit 4; the host re-runs the stage with its own job list and larger buffers.
+__global__ void __launch_bounds__(1024) k_t1_joblist(const CbDesc* cbs, int ncb, const int* nbps, int cap_jobs, int* nb_eff, int* joboff,
+                                                      int* order, int nslots, int* njobs_out, int* err) {
+  __shared__ int s_scan[1024];
+  __shared__ int s_hist[15 * 64 + 2];
+  const int tid = threadIdx.x, per = (ncb + 1023) / 1024, b0 = tid * per, b1 = b0 + per < ncb ? b0 + per : ncb;
+  int sum = 0;
+  for (int b = b0; b < b1; b++) sum += nbps[b] > 15 ? 15 : nbps[b];
+  s_scan[tid] = sum;
+  for (int k = tid; k < 15 * 64 + 2; k += 1024) s_hist[k] = 0;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan
+    const int v = tid >= o ? s_scan[tid - o] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  const int total = s_scan[1023];
+  const bool over = total > cap_jobs;
+  if (tid == 0) { *njobs_out = total; if (over) atomicOr(err, 4); }
+  int run = s_scan[tid] - sum;
+  auto key_of = [&](int b, int nb) { return 15 * 64 - nb * (((int)cbs[b].w * cbs[b].h + 63) >> 6); };
+  for (int b = b0; b < b1; b++) {
+    const int nb = nbps[b] > 15 ? 15 : nbps[b], ne = over ? 0 : nb;
+    nb_eff[b] = ne;
+    joboff[b] = over ? 0 : run;
+    run += nb;
+    atomicAdd(&s_hist[key_of(b, ne) + 1], 1);
+  }
+  __syncthreads();
+  if (tid == 0) for (int k = 1; k <= 15 * 64 + 1; k++) s_hist[k] += s_hist[k - 1];  // s_hist[k] = first slot of key k
+  __syncthreads();
+  for (int b = b0; b < b1; b++) order[atomicAdd(&s_hist[key_of(b, nb_eff[b])], 1)] = b;
+  for (int k = ncb + tid; k < nslots; k += 1024) order[k] = ncb;
+}
+void launch_t1_joblist(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, int cap_jobs, int* nb_eff, int* joboff, int* order, int nslots,
+                       int* njobs_out, int* err) {
+  hipLaunchKernelGGL(k_t1_joblist, dim3(1), dim3(1024), 0, st, cbs, ncb, nbps, cap_jobs, nb_eff, joboff, order, nslots, njobs_out, err);
+}
+
+// ---------------------------------------------------------------------------------------------
 // EBCOT Tier-1 (T.800 Annex C + D) in two kernels: sample-parallel context modelling (k_t1_cm2, t1_cm2.h: one wave per
 // (code-block, bit-plane), decisions as one byte each into per-(block, plane, pass) segments) and the MQ coder over those
 // segments (k_t1_mq, t1_core.h: one code-block per lane).
