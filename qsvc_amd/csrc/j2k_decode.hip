@@ -382,6 +382,110 @@ __global__ void __launch_bounds__(64) k_t1_decode(const DecCb* cbs, int ncb, con
     }
 }
 
+// Round 3 form of the block decoder: still one code-block per lane (the decoding direction is serial per block), but the
+// per-sample flag plane -- what every context needs eight reads of -- lives in LDS (66 x 66 bytes per lane, 32 lanes per
+// workgroup), and the magnitude bits go to the coefficient plane as OR-atomics that return nothing (bit 31 = the sign): the
+// kernel never waits for global memory except for its code bytes.  k_dec_dequant then turns the words into coefficients.
+#define DEC_LANES 32
+#define DEC_FL_BYTES (66 * 66)
+__global__ void __launch_bounds__(DEC_LANES) k_t1_decode_lds(const DecCb* cbs, int ncb, const uint8_t* segs, uint8_t* lastp_all, void* coefv) {
+  __shared__ uint8_t s_ctx[19 * 64];
+  __shared__ __attribute__((aligned(4))) uint8_t s_fl[DEC_LANES * DEC_FL_BYTES];
+  const int b = blockIdx.x * DEC_LANES + threadIdx.x;
+  if (b >= ncb) return;
+  const DecCb cb = cbs[b];
+  uint8_t* fl = s_fl + threadIdx.x * DEC_FL_BYTES;   // this lane's flag plane (a word stride of 1089: lanes start one bank apart)
+  for (int k = 0; k < DEC_FL_BYTES / 4; k++) ((uint32_t*)fl)[k] = 0;
+  uint8_t* lastp = lastp_all + (size_t)b * 64 * 64;
+  int32_t* mag = (int32_t*)coefv + cb.plane_off + (size_t)cb.y0 * cb.W + cb.x0;  // row stride cb.W
+  const int w = cb.w, h = cb.h, orient = cb.orient, W = cb.W;
+  MqDec m;
+  m.init(segs + cb.seg, cb.len, s_ctx + threadIdx.x);
+  int np = 0;
+#define MAG_OR(y, x, bits) atomicOr((unsigned*)&mag[(size_t)(y) * W + (x)], (unsigned)(bits))   /* no value comes back: never waited for */
+#define DEC_SIGN(y, x) do { int xb_, cx_ = d_sc(fl, (y), (x), &xb_); int s_ = m.decode(cx_) ^ xb_; DFL((y), (x)) |= (uint8_t)(DF_SIG | (s_ ? DF_NEG : 0)); \
+                            if (s_) MAG_OR((y), (x), 0x80000000u); } while (0)
+  for (int p = cb.nbps - 1; p >= 0 && np < cb.npasses; p--) {
+    if (p != cb.nbps - 1) {
+      for (int y0 = 0; y0 < h; y0 += 4)
+        for (int x = 0; x < w; x++)
+          for (int y = y0; y < y0 + 4 && y < h; y++) {
+            const uint8_t f = DFL(y, x);
+            if ((f & DF_SIG) || !d_anysig(fl, y, x)) continue;
+            if (m.decode(d_zc(fl, y, x, orient))) { MAG_OR(y, x, 1u << p); DEC_SIGN(y, x); }
+            lastp[y * 64 + x] = (uint8_t)p;
+            DFL(y, x) |= DF_VISIT;
+          }
+      if (++np >= cb.npasses) break;
+      for (int y0 = 0; y0 < h; y0 += 4)
+        for (int x = 0; x < w; x++)
+          for (int y = y0; y < y0 + 4 && y < h; y++) {
+            const uint8_t f = DFL(y, x);
+            if (!(f & DF_SIG) || (f & DF_VISIT)) continue;
+            const int cx = (f & DF_REFINED) ? 16 : (d_anysig(fl, y, x) ? 15 : 14);
+            if (m.decode(cx)) MAG_OR(y, x, 1u << p);
+            lastp[y * 64 + x] = (uint8_t)p;
+            DFL(y, x) |= DF_REFINED;
+          }
+      if (++np >= cb.npasses) break;
+    }
+    for (int y0 = 0; y0 < h; y0 += 4)
+      for (int x = 0; x < w; x++) {
+        int y = y0;
+        if (y0 + 3 < h) {
+          bool run = true;
+          for (int k = 0; k < 4; k++)
+            if ((DFL(y0 + k, x) & (DF_SIG | DF_VISIT)) || d_anysig(fl, y0 + k, x)) { run = false; break; }
+          if (run) {
+            if (!m.decode(17)) { for (int k = 0; k < 4; k++) lastp[(y0 + k) * 64 + x] = (uint8_t)p; continue; }
+            int first = m.decode(18) << 1;
+            first |= m.decode(18);
+            for (int k = 0; k < first; k++) lastp[(y0 + k) * 64 + x] = (uint8_t)p;
+            y = y0 + first;
+            MAG_OR(y, x, 1u << p); lastp[y * 64 + x] = (uint8_t)p;
+            DEC_SIGN(y, x);
+            y++;
+          }
+        }
+        for (; y < y0 + 4 && y < h; y++) {
+          const uint8_t f = DFL(y, x);
+          if (f & (DF_SIG | DF_VISIT)) continue;
+          if (m.decode(d_zc(fl, y, x, orient))) { MAG_OR(y, x, 1u << p); DEC_SIGN(y, x); }
+          lastp[y * 64 + x] = (uint8_t)p;
+        }
+      }
+    np++;
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) DFL(y, x) &= (uint8_t)~DF_VISIT;
+  }
+#undef DEC_SIGN
+}
+#undef MAG_OR
+
+// magnitude word (bit 31 sign, bits 30..0 magnitude bits decoded) -> coefficient, in place (E.1.1.2: r = 1/2 for the bit-planes
+// that were not decoded; exact for a fully decoded reversible sample).  One workgroup per code-block.
+__global__ void __launch_bounds__(256) k_dec_dequant(const DecCb* cbs, int ncb, const uint8_t* lastp_all, void* coefv) {
+  const int b = blockIdx.x;
+  if (b >= ncb) return;
+  const DecCb cb = cbs[b];
+  const uint8_t* lastp = lastp_all + (size_t)b * 64 * 64;
+  int32_t* mag = (int32_t*)coefv + cb.plane_off + (size_t)cb.y0 * cb.W + cb.x0;
+  for (int k = threadIdx.x; k < cb.w * cb.h; k += 256) {
+    const int y = k / cb.w, x = k % cb.w;
+    const uint32_t wd = (uint32_t)mag[(size_t)y * cb.W + x];
+    const int mg = (int)(wd & 0x7FFFFFFFu), neg = (int)(wd >> 31);
+    if (!mg) { mag[(size_t)y * cb.W + x] = 0; continue; }
+    const int pl = lastp[y * 64 + x];
+    if (cb.rev) {
+      const int v = mg + (pl > 0 ? (1 << (pl - 1)) : 0);
+      mag[(size_t)y * cb.W + x] = neg ? -v : v;
+    } else {
+      const float v = __fmul_rn(__fadd_rn((float)mg, pl > 0 ? (float)(1 << (pl - 1)) : 0.5f), cb.delta);
+      ((float*)mag)[(size_t)y * cb.W + x] = neg ? -v : v;
+    }
+  }
+}
+
 // ---- device: inverse DWT, one 1-D pass per launch, thread per output sample --------------------------------------------------
 template <class Ld> __device__ __forceinline__ int idwt53_sample(const Ld& X /* Mallat: low half first */, int k, int n) {
   const int nl = (n + 1) >> 1, nh = n >> 1;
@@ -500,11 +604,18 @@ extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* 
     if ((r = S.lastp_d.ensure(c, (size_t)ncb * 64 * 64))) return r;
     HIPCHK(c, hipMemcpyAsync(S.cbs_d.p, cbs.data(), (size_t)ncb * sizeof(DecCb), hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(S.segs_d.p, segs.data(), segs.size(), hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemsetAsync(S.flags_d.p, 0, (size_t)ncb * 66 * 66, c->st));
     HIPCHK(c, hipMemsetAsync(S.lastp_d.p, 0, (size_t)ncb * 64 * 64, c->st));
     pf.begin(c, "j2k_t1_decode");
-    hipLaunchKernelGGL(k_t1_decode, dim3((ncb + 63) / 64), dim3(64), 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.segs_d.p,
-                       (uint8_t*)S.flags_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p);
+    static const bool lds_env = [] { const char* e = getenv("QSVC_DEC_LDS"); return !(e && e[0] == '0'); }();
+    if (lds_env) {
+      hipLaunchKernelGGL(k_t1_decode_lds, dim3((ncb + DEC_LANES - 1) / DEC_LANES), dim3(DEC_LANES), 0, c->st, (const DecCb*)S.cbs_d.p, ncb,
+                         (const uint8_t*)S.segs_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p);
+      hipLaunchKernelGGL(k_dec_dequant, dim3(ncb), dim3(256), 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.lastp_d.p, S.coefA.p);
+    } else {
+      HIPCHK(c, hipMemsetAsync(S.flags_d.p, 0, (size_t)ncb * 66 * 66, c->st));
+      hipLaunchKernelGGL(k_t1_decode, dim3((ncb + 63) / 64), dim3(64), 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.segs_d.p,
+                         (uint8_t*)S.flags_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p);
+    }
     pf.end(c);
   }
   // inverse DWT, levels L .. 1: horizontal (A -> B) then vertical (B -> A); samples outside the level's region are not touched,

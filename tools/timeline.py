@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Kernel timeline of ONE single-sequence encode from a rocprofv3 --kernel-trace csv:  timeline.py <kernel_trace.csv> [step]
-(steps are found by the first k_pyr_level<unsigned char> launch of each level-1 analysis)"""
+(steps are found by the k_pyr_ll_tile launches: the first kernel of each temporal level's motion search, [levels] per encode)"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-first = [i for i, r in enumerate(rows) if "k_pyr_level<unsigned char>" in r["Kernel_Name"]]
-steps = first[::3]
+first = [i for i, r in enumerate(rows) if "k_pyr_ll_tile" in r["Kernel_Name"]]
+levels = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+steps = first[::levels]
 st = int(sys.argv[2]) if len(sys.argv) > 2 else len(steps) - 2
 i0, i1 = steps[st], steps[st + 1]
 t0 = int(rows[i0]["Start_Timestamp"])
