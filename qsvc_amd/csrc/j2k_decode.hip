@@ -382,11 +382,15 @@ __global__ void __launch_bounds__(64) k_t1_decode(const DecCb* cbs, int ncb, con
     }
 }
 
-// Round 3 form of the block decoder: still one code-block per lane (the decoding direction is serial per block), but the
-// per-sample flag plane -- what every context needs eight reads of -- lives in LDS (66 x 66 bytes per lane, 32 lanes per
-// workgroup), and the magnitude bits go to the coefficient plane as OR-atomics that return nothing (bit 31 = the sign): the
-// kernel never waits for global memory except for its code bytes.  k_dec_dequant then turns the words into coefficients.
-#define DEC_LANES 32
+// Round 3 form of the block decoder.  The decoding direction is serial per block and its control flow is data dependent at every
+// sample (which pass a sample belongs to, run mode, renormalisation shifts), so lanes that decode different blocks in one wave
+// each pay for every other lane's path: with 64 blocks per wave the wave executed the union of 64 control flows (measured:
+// 159 ms for the 15 657 blocks of config 3, and no faster with the flags in LDS -- it was instruction stream, not memory).  A
+// GPU has more wave slots than a sequence has code-blocks per round: so ONE CODE-BLOCK PER WAVE (a single active lane; the
+// other 63 idle), a wave runs only its own block's path.  The per-sample flag plane lives in LDS (66 x 66 bytes per wave, up to
+// 29 waves per CU), and the magnitude bits go to the coefficient plane as OR-atomics that return nothing (bit 31 = the sign):
+// the kernel never waits for global memory except for its code bytes.  k_dec_dequant then turns the words into coefficients.
+#define DEC_LANES 1
 #define DEC_FL_BYTES (66 * 66)
 __global__ void __launch_bounds__(DEC_LANES) k_t1_decode_lds(const DecCb* cbs, int ncb, const uint8_t* segs, uint8_t* lastp_all, void* coefv) {
   __shared__ uint8_t s_ctx[19 * 64];
