@@ -521,6 +521,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   if ((r = upload_if_changed(c, S.planes_d.p, S.planes.data(), np * sizeof(PlaneDesc), S.up_planes, S.up_planes_at))) return r;
   if ((r = upload_if_changed(c, S.cbs_d.p, S.cbs.data(), (size_t)ncb * sizeof(CbDesc), S.up_cbs, S.up_cbs_at))) return r;
   HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }  // pending I/B decisions (qsvc_api.hip): the pictures must be final from here on
   Prof pf;
   if (maxL > 0) {
     // one kernel per level: tile in LDS, vertical + horizontal lifting, LL to the next level, the other subbands quantised and
@@ -841,7 +842,8 @@ extern "C" {
 
 static int add_sequence(qsvc_ctx* c, int kind, int t, int first, int count, const qsvc_j2k_params* prm, std::vector<PlaneSrc>& src) {
   if (t < 0 || t > QSVC_MAX_T) return c->fail(QSVC_ERR_INVALID, "temporal subband %d out of range", t);
-  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }  // pending I/B decisions of the temporal levels (qsvc_api.hip)
+  // (pending I/B decisions of the temporal levels are taken by j2k_encode_planes, right before its first kernel: counts and
+  //  buffer addresses do not depend on them, and the host builds its tables while the MCTF kernels are still running)
   Level& lv = c->lv[t];
   DevBuf* b; int n;
   switch (kind) {

@@ -392,9 +392,10 @@ __global__ void __launch_bounds__(64) k_t1_decode(const DecCb* cbs, int ncb, con
 // the kernel never waits for global memory except for its code bytes.  k_dec_dequant then turns the words into coefficients.
 #define DEC_LANES 1
 #define DEC_FL_BYTES (66 * 66)
-__global__ void __launch_bounds__(DEC_LANES) k_t1_decode_lds(const DecCb* cbs, int ncb, const uint8_t* segs, uint8_t* lastp_all, void* coefv) {
+__global__ void __launch_bounds__(64) k_t1_decode_lds(const DecCb* cbs, int ncb, const uint8_t* segs, uint8_t* lastp_all, void* coefv) {
   __shared__ uint8_t s_ctx[19 * 64];
   __shared__ __attribute__((aligned(4))) uint8_t s_fl[DEC_LANES * DEC_FL_BYTES];
+  if (threadIdx.x >= DEC_LANES) return;   // a whole wave is launched, DEC_LANES of its lanes decode
   const int b = blockIdx.x * DEC_LANES + threadIdx.x;
   if (b >= ncb) return;
   const DecCb cb = cbs[b];
@@ -612,7 +613,7 @@ extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* 
     pf.begin(c, "j2k_t1_decode");
     static const bool lds_env = [] { const char* e = getenv("QSVC_DEC_LDS"); return !(e && e[0] == '0'); }();
     if (lds_env) {
-      hipLaunchKernelGGL(k_t1_decode_lds, dim3((ncb + DEC_LANES - 1) / DEC_LANES), dim3(DEC_LANES), 0, c->st, (const DecCb*)S.cbs_d.p, ncb,
+      hipLaunchKernelGGL(k_t1_decode_lds, dim3((ncb + DEC_LANES - 1) / DEC_LANES), dim3(64), 0, c->st, (const DecCb*)S.cbs_d.p, ncb,
                          (const uint8_t*)S.segs_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p);
       hipLaunchKernelGGL(k_dec_dequant, dim3(ncb), dim3(256), 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.lastp_d.p, S.coefA.p);
     } else {

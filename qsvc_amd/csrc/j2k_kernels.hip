@@ -56,13 +56,24 @@ void launch_t1_nbps(hipStream_t st, const CbDesc* cbs, int ncb, int* nbps, int* 
 // gets bit 4; the host re-runs the stage with its own job list and larger buffers.
 __global__ void __launch_bounds__(1024) k_t1_joblist(const CbDesc* cbs, int ncb, const int* nbps, int cap_jobs, int* nb_eff, int* joboff,
                                                       int* order, int nslots, int* njobs_out, int* err) {
+  constexpr int STAGE = 16384;      // blocks whose (bit-planes, area) pairs are staged in LDS with coalesced loads (a 1080p GOP: 15 657)
   __shared__ int s_scan[1024];
-  __shared__ int s_hist[15 * 64 + 2];
+  __shared__ int s_hist[1024];      // 15 * 64 + 2 = 962 in use
+  __shared__ uint16_t s_blk[STAGE]; // nb | area64 << 4
   const int tid = threadIdx.x, per = (ncb + 1023) / 1024, b0 = tid * per, b1 = b0 + per < ncb ? b0 + per : ncb;
+  const bool staged = ncb <= STAGE;
+  if (staged)
+    for (int b = tid; b < ncb; b += 1024) {
+      const int nb = nbps[b] > 15 ? 15 : nbps[b];
+      s_blk[b] = (uint16_t)(nb | ((((int)cbs[b].w * cbs[b].h + 63) >> 6) << 4));
+    }
+  s_hist[tid] = 0;
+  __syncthreads();
+  auto nb_of = [&](int b) { return staged ? (int)(s_blk[b] & 15) : (nbps[b] > 15 ? 15 : nbps[b]); };
+  auto area_of = [&](int b) { return staged ? (int)(s_blk[b] >> 4) : (((int)cbs[b].w * cbs[b].h + 63) >> 6); };
   int sum = 0;
-  for (int b = b0; b < b1; b++) sum += nbps[b] > 15 ? 15 : nbps[b];
+  for (int b = b0; b < b1; b++) sum += nb_of(b);
   s_scan[tid] = sum;
-  for (int k = tid; k < 15 * 64 + 2; k += 1024) s_hist[k] = 0;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan
     const int v = tid >= o ? s_scan[tid - o] : 0;
@@ -74,18 +85,21 @@ __global__ void __launch_bounds__(1024) k_t1_joblist(const CbDesc* cbs, int ncb,
   const bool over = total > cap_jobs;
   if (tid == 0) { *njobs_out = total; if (over) atomicOr(err, 4); }
   int run = s_scan[tid] - sum;
-  auto key_of = [&](int b, int nb) { return 15 * 64 - nb * (((int)cbs[b].w * cbs[b].h + 63) >> 6); };
   for (int b = b0; b < b1; b++) {
-    const int nb = nbps[b] > 15 ? 15 : nbps[b], ne = over ? 0 : nb;
+    const int nb = nb_of(b), ne = over ? 0 : nb;
     nb_eff[b] = ne;
     joboff[b] = over ? 0 : run;
     run += nb;
-    atomicAdd(&s_hist[key_of(b, ne) + 1], 1);
+    atomicAdd(&s_hist[15 * 64 - ne * area_of(b) + 1], 1);
   }
   __syncthreads();
-  if (tid == 0) for (int k = 1; k <= 15 * 64 + 1; k++) s_hist[k] += s_hist[k - 1];  // s_hist[k] = first slot of key k
-  __syncthreads();
-  for (int b = b0; b < b1; b++) order[atomicAdd(&s_hist[key_of(b, nb_eff[b])], 1)] = b;
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan over the counts at [key + 1]: s_hist[k] = first slot of key k
+    const int v = tid >= o ? s_hist[tid - o] : 0;
+    __syncthreads();
+    s_hist[tid] += v;
+    __syncthreads();
+  }
+  for (int b = b0; b < b1; b++) order[atomicAdd(&s_hist[15 * 64 - (over ? 0 : nb_of(b)) * area_of(b)], 1)] = b;
   for (int k = ncb + tid; k < nslots; k += 1024) order[k] = ncb;
 }
 void launch_t1_joblist(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, int cap_jobs, int* nb_eff, int* joboff, int* order, int nslots,
