@@ -392,20 +392,23 @@ __global__ void __launch_bounds__(64) k_t1_decode(const DecCb* cbs, int ncb, con
 // the kernel never waits for global memory except for its code bytes.  k_dec_dequant then turns the words into coefficients.
 #define DEC_LANES 1
 #define DEC_FL_BYTES (66 * 66)
-__global__ void __launch_bounds__(64) k_t1_decode_lds(const DecCb* cbs, int ncb, const uint8_t* segs, uint8_t* lastp_all, void* coefv) {
+__global__ void __launch_bounds__(64) k_t1_decode_lds(const DecCb* cbs, int ncb, const uint8_t* segs, uint8_t* lastp_all, void* coefv, int lane0, int nlanes) {
   __shared__ uint8_t s_ctx[19 * 64];
   __shared__ __attribute__((aligned(4))) uint8_t s_fl[DEC_LANES * DEC_FL_BYTES];
-  if (threadIdx.x >= DEC_LANES) return;   // a whole wave is launched, DEC_LANES of its lanes decode
-  const int b = blockIdx.x * DEC_LANES + threadIdx.x;
+  // a whole wave is launched, lanes lane0 .. lane0 + nlanes - 1 decode (0 and DEC_LANES, passed as arguments: with the lane index a
+  // compile-time constant the build of ROCm 7.2 produced a kernel that decoded garbage -- 16 VGPRs, everything scalarised)
+  const int dl = (int)threadIdx.x - lane0;
+  if (dl < 0 || dl >= nlanes) return;
+  const int b = blockIdx.x * DEC_LANES + dl;
   if (b >= ncb) return;
   const DecCb cb = cbs[b];
-  uint8_t* fl = s_fl + threadIdx.x * DEC_FL_BYTES;   // this lane's flag plane (a word stride of 1089: lanes start one bank apart)
+  uint8_t* fl = s_fl + dl * DEC_FL_BYTES;   // this lane's flag plane (a word stride of 1089: lanes start one bank apart)
   for (int k = 0; k < DEC_FL_BYTES / 4; k++) ((uint32_t*)fl)[k] = 0;
   uint8_t* lastp = lastp_all + (size_t)b * 64 * 64;
   int32_t* mag = (int32_t*)coefv + cb.plane_off + (size_t)cb.y0 * cb.W + cb.x0;  // row stride cb.W
   const int w = cb.w, h = cb.h, orient = cb.orient, W = cb.W;
   MqDec m;
-  m.init(segs + cb.seg, cb.len, s_ctx + threadIdx.x);
+  m.init(segs + cb.seg, cb.len, s_ctx + dl);
   int np = 0;
 #define MAG_OR(y, x, bits) atomicOr((unsigned*)&mag[(size_t)(y) * W + (x)], (unsigned)(bits))   /* no value comes back: never waited for */
 #define DEC_SIGN(y, x) do { int xb_, cx_ = d_sc(fl, (y), (x), &xb_); int s_ = m.decode(cx_) ^ xb_; DFL((y), (x)) |= (uint8_t)(DF_SIG | (s_ ? DF_NEG : 0)); \
@@ -614,7 +617,7 @@ extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* 
     static const bool lds_env = [] { const char* e = getenv("QSVC_DEC_LDS"); return !(e && e[0] == '0'); }();
     if (lds_env) {
       hipLaunchKernelGGL(k_t1_decode_lds, dim3((ncb + DEC_LANES - 1) / DEC_LANES), dim3(64), 0, c->st, (const DecCb*)S.cbs_d.p, ncb,
-                         (const uint8_t*)S.segs_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p);
+                         (const uint8_t*)S.segs_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p, 0, DEC_LANES);
       hipLaunchKernelGGL(k_dec_dequant, dim3(ncb), dim3(256), 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.lastp_d.p, S.coefA.p);
     } else {
       HIPCHK(c, hipMemsetAsync(S.flags_d.p, 0, (size_t)ncb * 66 * 66, c->st));
