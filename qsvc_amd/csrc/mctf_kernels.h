@@ -7,6 +7,8 @@ namespace qsvc {
 void launch_pyr_level_u8(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int P, int R, int C);
 bool pyr_tile_applies(int W, int H);             // mctf_pyr.hip
 void launch_pyr_ll_tile(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int P, int R, int C);
+bool pyr_tile16_applies(int W, int ny, int nx);
+void launch_pyr_ll_tile16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int ny, int nx, int R, int C);  // LL (rows < R, columns < C) of the level below's ny x nx quadrant
 void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int l, int R, int C);
 void launch_me_search(hipStream_t st, const MeArgs& a, int mv_bound);
 bool me_piece_applies(const MeArgs& a);          // mctf_me.hip

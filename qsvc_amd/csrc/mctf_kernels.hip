@@ -37,7 +37,17 @@ void launch_pyr_level_u8(hipStream_t st, const uint8_t* frames, size_t F, int W,
   hipLaunchKernelGGL(k_pyr_level<uint8_t>, grid, block, 0, st, frames, F, W, dst, (size_t)H * W, H, W, 1, R, C, 0, 0);
 }
 void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int l, int R, int C) {
-  dim3 grid((C + 63) / 64, (R + 3) / 4, P), block(64, 4);
+  dim3 block(64, 4);
+  const int ny = H >> (l - 1), nx = W >> (l - 1);
+  if (pyr_tile16_applies(W, ny, nx) && getenv("QSVC_PYR_TILE") == nullptr) {
+    // the LL quadrant out of LDS tiles (mctf_pyr.hip); what a block window reads beyond it (bands of this and of earlier levels), per coefficient
+    const int Rl = imin(R, ny / 2), Cl = imin(C, nx / 2);
+    launch_pyr_ll_tile16(st, src, dst, W, H, P, ny, nx, Rl, Cl);
+    if (R > Rl) hipLaunchKernelGGL(k_pyr_level<int16_t>, dim3((C + 63) / 64, (R - Rl + 3) / 4, P), block, 0, st, src, (size_t)H * W, W, dst, (size_t)H * W, H, W, l, R, C, 0, Rl);
+    if (C > Cl) hipLaunchKernelGGL(k_pyr_level<int16_t>, dim3((C - Cl + 63) / 64, (Rl + 3) / 4, P), block, 0, st, src, (size_t)H * W, W, dst, (size_t)H * W, H, W, l, Rl, C, Cl, 0);
+    return;
+  }
+  dim3 grid((C + 63) / 64, (R + 3) / 4, P);
   hipLaunchKernelGGL(k_pyr_level<int16_t>, grid, block, 0, st, src, (size_t)H * W, W, dst, (size_t)H * W, H, W, l, R, C, 0, 0);
 }
 
