@@ -502,8 +502,11 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const uint64_t bb = __ballot((bit4 >> k) & 1);
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(blo) : "s"((uint32_t)bb), "n"(4 * s + k));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(bhi) : "s"((uint32_t)(bb >> 32)), "n"(4 * s + k));
+        // s_nop 1: gfx950 wants two wait states between the v_cmp that writes the ballot's SGPRs and a VALU instruction that reads
+        // them, and the compiler's hazard recogniser does not look inside an asm statement (without it the result depends on
+        // what the scheduler happens to put in between: seen as wrong, run-to-run different streams in an experiment of round 3)
+        asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+            : "+v"(blo), "+v"(bhi) : "s"((uint32_t)bb), "s"((uint32_t)(bb >> 32)), "n"(4 * s + k));
       }
     }
     cwreg[s] = c;

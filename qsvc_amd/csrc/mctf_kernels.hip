@@ -23,14 +23,31 @@ __global__ void __launch_bounds__(256) k_pyr_level(const T* src, size_t src_pic_
   int y = oy + blockIdx.y * 4 + threadIdx.y;
   pyr_thread<T>(src, src_pic_stride, src_row_stride, dst, dst_pic_stride, H, W, l, R, C, x, y, blockIdx.z);
 }
+// What a block window reads beyond the LL quadrant the tile kernels (mctf_pyr.hip) write: rows [R, Rf) of all Cf columns, then columns
+// [C, Cf) of the first R rows, one launch.  (Kept apart from the tile kernels: the general coefficient code is ~50 KB of instructions and
+// evicts the tile loop from the instruction cache when both run on one CU.)
+template <class T>
+__global__ void __launch_bounds__(256) k_pyr_margin(const T* src, size_t src_pic_stride, int src_row_stride, int16_t* dst, size_t dst_pic_stride, int H, int W,
+                                                     int l, int R, int C, int Rf, int Cf, int gyR) {
+  const bool rows = (int)blockIdx.y < gyR;
+  const int x = (rows ? 0 : C) + blockIdx.x * 64 + threadIdx.x;
+  const int y = rows ? R + blockIdx.y * 4 + threadIdx.y : (blockIdx.y - gyR) * 4 + threadIdx.y;
+  pyr_thread<T>(src, src_pic_stride, src_row_stride, dst, dst_pic_stride, H, W, l, rows ? Rf : R, Cf, x, y, blockIdx.z);
+}
+template <class T>
+static void launch_pyr_margin(hipStream_t st, const T* src, size_t src_pic_stride, int16_t* dst, int W, int H, int P, int l, int R, int C, int Rf, int Cf) {
+  const int gyR = Rf > R ? (Rf - R + 3) / 4 : 0, gyC = Cf > C ? (R + 3) / 4 : 0;
+  if (gyR + gyC == 0) return;
+  const int gx = gyR ? (Cf + 63) / 64 : (Cf - C + 63) / 64;
+  hipLaunchKernelGGL(k_pyr_margin<T>, dim3(gx, gyR + gyC, P), dim3(64, 4), 0, st, src, src_pic_stride, W, dst, (size_t)H * W, H, W, l, R, C, Rf, Cf, gyR);
+}
 void launch_pyr_level_u8(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int P, int R, int C) {
   dim3 block(64, 4);
   if (pyr_tile_applies(W, H) && getenv("QSVC_PYR_TILE") == nullptr) {
     // the LL quadrant out of LDS tiles (mctf_pyr.hip); what a block window reads beyond it, coefficient by coefficient
     const int Rl = imin(R, H / 2), Cl = imin(C, W / 2);
     launch_pyr_ll_tile(st, frames, F, W, H, dst, P, Rl, Cl);
-    if (R > Rl) hipLaunchKernelGGL(k_pyr_level<uint8_t>, dim3((C + 63) / 64, (R - Rl + 3) / 4, P), block, 0, st, frames, F, W, dst, (size_t)H * W, H, W, 1, R, C, 0, Rl);
-    if (C > Cl) hipLaunchKernelGGL(k_pyr_level<uint8_t>, dim3((C - Cl + 63) / 64, (Rl + 3) / 4, P), block, 0, st, frames, F, W, dst, (size_t)H * W, H, W, 1, Rl, C, Cl, 0);
+    launch_pyr_margin<uint8_t>(st, frames, F, dst, W, H, P, 1, Rl, Cl, R, C);
     return;
   }
   dim3 grid((C + 63) / 64, (R + 3) / 4, P);
@@ -43,8 +60,7 @@ void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int 
     // the LL quadrant out of LDS tiles (mctf_pyr.hip); what a block window reads beyond it (bands of this and of earlier levels), per coefficient
     const int Rl = imin(R, ny / 2), Cl = imin(C, nx / 2);
     launch_pyr_ll_tile16(st, src, dst, W, H, P, ny, nx, Rl, Cl);
-    if (R > Rl) hipLaunchKernelGGL(k_pyr_level<int16_t>, dim3((C + 63) / 64, (R - Rl + 3) / 4, P), block, 0, st, src, (size_t)H * W, W, dst, (size_t)H * W, H, W, l, R, C, 0, Rl);
-    if (C > Cl) hipLaunchKernelGGL(k_pyr_level<int16_t>, dim3((C - Cl + 63) / 64, (Rl + 3) / 4, P), block, 0, st, src, (size_t)H * W, W, dst, (size_t)H * W, H, W, l, Rl, C, Cl, 0);
+    launch_pyr_margin<int16_t>(st, src, (size_t)H * W, dst, W, H, P, l, Rl, Cl, R, C);
     return;
   }
   dim3 grid((C + 63) / 64, (R + 3) / 4, P);
