@@ -440,6 +440,41 @@ void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneD
   else hipLaunchKernelGGL(k_t1_pack_blk<false>, dim3(ncb), dim3(256), 0, st, cbs, ncb, planes, coef, mags, nbps, err);
 }
 
+// lane i <- lane i - 1 (lane 0 <- 0) / lane i <- lane i + 1 (lane 63 <- 0): DPP wave shifts, no trip through the LDS crossbar
+__device__ __forceinline__ uint64_t cm2_wave_up(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138 /*wave_shr:1*/, 0xF, 0xF, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, true);
+  return (uint64_t)lo | (uint64_t)hi << 32;
+}
+__device__ __forceinline__ uint64_t cm2_wave_dn(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130 /*wave_shl:1*/, 0xF, 0xF, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xF, 0xF, true);
+  return (uint64_t)lo | (uint64_t)hi << 32;
+}
+// 64 x 64 bit-matrix transpose across the wave: lane r holds row r (bit c = column c) and receives column r (bit c = row c).  Six
+// butterfly stages, one per index bit: the lanes r and r ^ d exchange the off-diagonal d x d blocks; for d < 32 what a lane sends
+// -- the half of each 32-bit word its partner wants -- fits one word.
+__device__ __forceinline__ uint64_t cm2_transpose64(uint64_t v, int lane) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  {
+    const bool rj = (lane & 32) != 0;
+    const uint32_t got = (uint32_t)__shfl_xor((int)(rj ? lo : hi), 32, 64);
+    lo = rj ? got : lo; hi = rj ? hi : got;
+  }
+#pragma unroll
+  for (int j = 4; j >= 0; j--) {
+    const int d = 1 << j;
+    const uint32_t m0 = d == 16 ? 0x0000FFFFu : (d == 8 ? 0x00FF00FFu : (d == 4 ? 0x0F0F0F0Fu : (d == 2 ? 0x33333333u : 0x55555555u))), m1 = ~m0;
+    const bool rj = (lane & d) != 0;
+    const uint32_t P = rj ? ((lo & m0) | ((hi & m0) << d)) : (((lo & m1) >> d) | (hi & m1));
+    const uint32_t G = (uint32_t)__shfl_xor((int)P, d, 64);
+    const uint32_t lo1 = (lo & m1) | (G & m0), hi1 = (hi & m1) | ((G & m1) >> d);
+    const uint32_t lo0 = (lo & m0) | ((G & m0) << d), hi0 = (hi & m0) | (G & m1);
+    lo = rj ? lo1 : lo0; hi = rj ? hi1 : hi0;
+  }
+  return (uint64_t)lo | (uint64_t)hi << 32;
+}
+
 #define CM2_OUT_BYTES 10240  // the largest pass segment (clean-up: 10 decisions per stripe column at most)
 __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff, const int* order,
                                                 const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist) {
@@ -448,7 +483,7 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
   __shared__ uint8_t s_zc[1024];  // [0..511] zero coding, [512..1023] refinement (t1_cm2.h, cm2_emit3w)
   __shared__ __attribute__((aligned(16))) uint8_t s_out[CM2_OUT_BYTES + 16];  // zeroed per plane; the streams OR whole words into it
   __shared__ uint8_t s_sign[256];
-  __shared__ uint64_t s_rowM[64];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pk[64][8];   // per column: its 16 stripes' decisions per pass + "listed" flag (cm2_pack_pk)
   // order != nullptr: workgroup k models block order[k] (the MQ stage's slot table: longest blocks first; ncb = an idle slot)
   const int lane = threadIdx.x, b = order ? order[blockIdx.x] : (int)blockIdx.x;
   if (b >= ncb) return;
@@ -466,87 +501,76 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
     for (int i = lane; i < 512; i += 64) { s_zc[i] = (uint8_t)t1_zc_from_nb(i, oc); s_zc[512 + i] = (uint8_t)(((i >> 4) & 1) ? 16 : ((i & 0x1EF) ? 15 : 14)); }
   }
   for (int i = lane; i < 18 * 66; i += 64) (&s_cw[0][0])[i] = 0;
-  // The block's magnitudes stay in registers for all of its bit-planes (lane = column x: 16 stripes x 4 rows), and the column
-  // words are carried from plane to plane: sig0(p) = sig0(p+1) | bit(p+1), mu(p) = sig0(p+1); only bit(p) is new.  The same for
-  // the row masks: Zr(p) = Zr(p+1) | Br(p+1), so only the bit rows go through ballots.
-  uint32_t mlo[16], mhi[16], fixed[16], st[16];   // fixed: neg | val fields; st: sig0 nibble | previous plane's bit nibble << 4
+  // The block's magnitudes stay in registers for all of its bit-planes (lane = column x: 16 stripes x 4 rows).  The state of a
+  // plane is a handful of 64-bit masks in two layouts: by COLUMN (lane = x, bit y) where the column words are put together, by ROW
+  // (lane = y, bit x) where the membership recurrence runs; a bit-matrix transpose across the wave (cm2_transpose64) takes the
+  // plane's bits to the row layout and the membership back.  Both are carried from plane to plane:
+  // sig0(p) = sig0(p+1) | bit(p+1), mu(p) = sig0(p+1).
+  uint32_t mlo[16], mhi[16];
+  uint64_t NEGc = 0;   // sign bits (lane = column)
 #pragma unroll
   for (int s = 0; s < 16; s++) {
     unsigned long long m = 0;
     if (s < nstr && lane < w) m = mg[s * 64 + lane];
     mlo[s] = (uint32_t)m; mhi[s] = (uint32_t)(m >> 32);
-    const int rows = h - 4 * s > 4 ? 4 : (h - 4 * s < 0 ? 0 : h - 4 * s);
     const uint32_t tl = (mlo[s] >> 15) & 0x00010001u, th = (mhi[s] >> 15) & 0x00010001u;
     const uint32_t neg4 = ((tl | tl >> 15) & 3) | (((th | th >> 15) & 3) << 2);
-    const uint32_t val4 = (s < nstr && lane < w) ? ((1u << rows) - 1) : 0u;
-    fixed[s] = neg4 << CW_NEG | val4 << CW_VAL;
-    st[s] = 0;
+    NEGc |= (uint64_t)neg4 << (4 * s);
   }
-  uint64_t Zr = 0, Br = 0;   // row masks of the plane above (lane = row)
+  const uint64_t VALc = lane < w ? (h == 64 ? ~0ull : ((1ull << h) - 1)) : 0ull;   // samples of the block in this column
+  uint64_t Zc = 0, Bc = 0;   // by column: significant before the plane; the plane's bits (of the plane above on entry)
+  uint64_t Zr = 0, Br = 0;   // the same by row
   __syncthreads();
   for (int p = nb - 1; p >= 0; p--) {
   const size_t job = job0 + p;
   for (int i = lane; i < (CM2_OUT_BYTES + 16) / 16; i += 64) ((uint4*)s_out)[i] = make_uint4(0, 0, 0, 0);
+  const uint64_t MUc = Zc;   // significant before the plane above: "refined before" of the refinement pass
+  Zc |= Bc;
   Zr |= Br;
-  uint32_t blo = 0, bhi = 0;  // Br halves: a ballot lands in its row's lane by v_writelane
-  uint32_t cwreg[16];
+  {
+    uint32_t blo = 0, bhi = 0;
 #pragma unroll
-  for (int s = 0; s < 16; s++) {
-    uint32_t c = 0;
-    if (s < nstr) {  // uniform
-      const uint32_t sig_prev = st[s] & 0xF, sig0 = sig_prev | (st[s] >> 4);
+    for (int s = 0; s < 16; s++) {
       const uint32_t tl = (mlo[s] >> p) & 0x00010001u, th = (mhi[s] >> p) & 0x00010001u;
       const uint32_t bit4 = ((tl | tl >> 15) & 3) | (((th | th >> 15) & 3) << 2);
-      st[s] = sig0 | bit4 << 4;
-      c = sig0 << CW_SIG0 | bit4 << CW_BIT | sig_prev << CW_MU | fixed[s];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint64_t bb = __ballot((bit4 >> k) & 1);
-        // s_nop 1: gfx950 wants two wait states between the v_cmp that writes the ballot's SGPRs and a VALU instruction that reads
-        // them, and the compiler's hazard recogniser does not look inside an asm statement (without it the result depends on
-        // what the scheduler happens to put in between: seen as wrong, run-to-run different streams in an experiment of round 3)
-        asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-            : "+v"(blo), "+v"(bhi) : "s"((uint32_t)bb), "s"((uint32_t)(bb >> 32)), "n"(4 * s + k));
-      }
+      if (s < 8) blo |= bit4 << (4 * s); else bhi |= bit4 << (4 * s - 32);
     }
-    cwreg[s] = c;
+    Bc = (uint64_t)blo | (uint64_t)bhi << 32;
   }
-  Br = (uint64_t)blo | (uint64_t)bhi << 32;
+  Br = cm2_transpose64(Bc, lane);
   // membership: fixpoint of cm2_row_update over the 64 rows (t1_cm2.h)
+  uint64_t Mc;
   {
     const uint64_t wmask = w == 64 ? ~0ull : ((1ull << w) - 1);
     const uint64_t cand = (lane < h ? wmask : 0ull) & ~Zr;
-    auto up = [&](uint64_t v) {  // the value of lane - 1 (0 for lane 0)
-      uint32_t lo = __shfl_up((uint32_t)v, 1, 64), hi = __shfl_up((uint32_t)(v >> 32), 1, 64);
-      return lane ? ((uint64_t)lo | ((uint64_t)hi << 32)) : 0ull;
-    };
-    auto dn = [&](uint64_t v) {  // the value of lane + 1 (0 for lane 63)
-      uint32_t lo = __shfl_down((uint32_t)v, 1, 64), hi = __shfl_down((uint32_t)(v >> 32), 1, 64);
-      return lane < 63 ? ((uint64_t)lo | ((uint64_t)hi << 32)) : 0ull;
-    };
-    const uint64_t seed = cm2_row_seed(Zr, up(Zr), dn(Zr));
+    const uint64_t seed = cm2_row_seed(Zr, cm2_wave_up(Zr), cm2_wave_dn(Zr));
     uint64_t M = 0;
     for (;;) {
       const uint64_t S1 = M & Br;
-      const uint64_t Mn = cm2_row_update(cand, Br, seed, up(S1), dn(S1), lane & 3);
+      const uint64_t Mn = cm2_row_update(cand, Br, seed, cm2_wave_up(S1), cm2_wave_dn(S1), lane & 3);
       const bool changed = Mn != M;
       M = Mn;
       if (!__any(changed)) break;
     }
-    s_rowM[lane] = M;
+    Mc = cm2_transpose64(M, lane);
   }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < 16; s++) {
-    if (s < nstr && lane < w) {
-      const uint32_t c = cwreg[s];
-      uint32_t M4 = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) M4 |= (uint32_t)((s_rowM[4 * s + k] >> lane) & 1) << k;
-      const uint32_t S1 = M4 & (c >> CW_BIT) & 0xF;
-      const uint32_t S2 = (c >> CW_VAL) & ~(c >> CW_SIG0) & ~M4 & (c >> CW_BIT) & 0xF;
-      s_cw[s + 1][lane + 1] = c | (M4 << CW_M) | (S1 << CW_S1) | (S2 << CW_S2);
+  {
+    const uint64_t S1c = Mc & Bc, S2c = VALc & ~Zc & ~Mc & Bc;
+    {  // decisions per pass of the column's 16 stripes, bit-parallel on the masks (cm2_counts_swar); the neighbours' by DPP
+      const uint64_t T = Zc | S1c, T2 = T | S2c;
+      Cm2Counts cc;
+      cm2_counts_swar(cc, VALc, Zc, Bc, Mc, cm2_wave_up(T), cm2_wave_up(T2), cm2_wave_dn(T), cm2_wave_dn(T2));
+      uint32_t pk[8];
+      cm2_pack_pk(cc, pk);
+      *(uint4*)&s_pk[lane][0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      *(uint4*)&s_pk[lane][4] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     }
+    auto nib = [](uint64_t v, int s) { return (uint32_t)(v >> (4 * s)) & 0xFu; };
+#pragma unroll
+    for (int s = 0; s < 16; s++)
+      if (s < nstr)   // (uniform; lanes beyond the width hold 0 in every mask)
+        s_cw[s + 1][lane + 1] = nib(Zc, s) << CW_SIG0 | nib(Bc, s) << CW_BIT | nib(NEGc, s) << CW_NEG | nib(MUc, s) << CW_MU | nib(VALc, s) << CW_VAL |
+                                nib(Mc, s) << CW_M | nib(S1c, s) << CW_S1 | nib(S2c, s) << CW_S2;
   }
   __syncthreads();
   Cm2Ctx cx;
@@ -558,23 +582,14 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
   const int ls = lane >> 2, lx0 = (lane & 3) * 16;
   const bool lane_live = ls < nstr && lx0 < w;
   int n3[3] = {0, 0, 0};
-  uint16_t pk[16];     // per column: decisions of pass 0 | pass 1 << 4 | pass 2 << 8
   uint32_t act = 0;    // columns that are not "plain" (more to do than one RUN = 0)
-#pragma unroll
-  for (int j = 0; j < 16; j++) pk[j] = 0;
-  if (lane_live) {  // decisions per pass from the raw column words (the 3 x 3 neighbourhood slides along the stripe)
-    uint32_t u[3] = {0, s_cw[ls][lx0], s_cw[ls][lx0 + 1]}, m[3] = {0, s_cw[ls + 1][lx0], s_cw[ls + 1][lx0 + 1]},
-             d[3] = {0, s_cw[ls + 2][lx0], s_cw[ls + 2][lx0 + 1]};
+  const uint16_t* mypk = (const uint16_t*)&s_pk[lx0][0] + CM2_PK_AT(ls);   // column lx0 + j: + 16 j halfwords
+  if (lane_live) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      u[0] = u[1]; u[1] = u[2]; u[2] = s_cw[ls][lx0 + j + 2];
-      m[0] = m[1]; m[1] = m[2]; m[2] = s_cw[ls + 1][lx0 + j + 2];
-      d[0] = d[1]; d[1] = d[2]; d[2] = s_cw[ls + 2][lx0 + j + 2];
-      int n[3]; bool plain;
-      cm2_counts_w(u, m, d, n, &plain);  // zero for a column beyond the block's width (its word is 0)
-      n3[0] += n[0]; n3[1] += n[1]; n3[2] += n[2];
-      pk[j] = (uint16_t)(n[0] | n[1] << 4 | n[2] << 8);
-      if (!plain && (n[0] | n[1] | n[2])) act |= 1u << j;
+      const uint32_t pkj = mypk[16 * j];   // zero for a column beyond the block's width
+      n3[0] += pkj & 15; n3[1] += (pkj >> 4) & 15; n3[2] += (pkj >> 8) & 15;
+      act |= (pkj >> 12) << j;
     }
   }
   int off3[3], tot3[3];
@@ -604,7 +619,8 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
       int o0 = off3[0], o1 = off3[1], o2 = off3[2], lp = apos;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
-        const int n0 = pk[j] & 15, n1 = (pk[j] >> 4) & 15, n2 = pk[j] >> 8;
+        const uint32_t pkj = mypk[16 * j];
+        const int n0 = pkj & 15, n1 = (pkj >> 4) & 15, n2 = (pkj >> 8) & 15;
         if ((act >> j) & 1) {
           Cm2Entry e;
           e.col = (uint16_t)(ls * 64 + lx0 + j); e.o0 = (uint16_t)o0; e.o1 = (uint16_t)o1; e.o2 = (uint16_t)o2;

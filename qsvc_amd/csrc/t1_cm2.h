@@ -466,6 +466,60 @@ T1HD void cm2_counts_w(const uint32_t u[3], const uint32_t m[3], const uint32_t 
   if (plain) *plain = rl && !bit4;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same counts for ALL 16 stripe columns of one column x at once, on 64-bit masks over the rows (bit y; nibble s = the four
+// rows of stripe s): V valid rows, Z significant before the plane, B the plane's bits, M significance-pass membership.  The
+// neighbourhood test of the run-length mode needs T = Z | S1 and T2 = T | S2 of the columns x - 1 and x + 1 (zero outside the
+// block), S1 = M & B, S2 = V & ~Z & ~M & B -- in the kernel a DPP shift of the wave away.  Results as nibble arrays: decisions
+// of pass 0 (<= 8), 1 (<= 4), 2 (<= 11) and bit 0 of `act` = the column is listed by the sparse form (it has decisions and
+// is not "plain").  Bit-parallel within the word (SWAR): about 2 operations per stripe column against cm2_counts_w's 80.
+#define CM2_N1 0x1111111111111111ull
+T1HD uint64_t cm2_nib_any(uint64_t v) { return (v | v >> 1 | v >> 2 | v >> 3) & CM2_N1; }
+T1HD uint64_t cm2_nib_all(uint64_t v) { return (v & v >> 1 & v >> 2 & v >> 3) & CM2_N1; }
+T1HD uint64_t cm2_nib_pop(uint64_t v) {
+  v = (v & 0x5555555555555555ull) + ((v >> 1) & 0x5555555555555555ull);
+  return (v & 0x3333333333333333ull) + ((v >> 2) & 0x3333333333333333ull);
+}
+struct Cm2Counts { uint64_t n0, n1, n2, act; };
+T1HD void cm2_counts_swar(Cm2Counts& o, uint64_t V, uint64_t Z, uint64_t B, uint64_t M, uint64_t TL, uint64_t T2L, uint64_t TR, uint64_t T2R) {
+  const uint64_t Zv = Z & V, Mv = M & V, C = V & ~Zv & ~Mv, S1 = Mv & B, S2 = C & B;
+  const uint64_t T = Z | (M & B), T2 = T | (V & ~Z & ~M & B);   // the S1 / S2 fields as the column words hold them
+  // a significant neighbour as the clean-up pass sees the column's first row: rows 0..3 of x - 1 (incl. S2), x, x + 1; the row above
+  // in all three columns (incl. S2); the row below (before the clean-up pass)
+  const uint64_t any = cm2_nib_any(T2L | T | TR) | (((T2L | T2 | T2R) >> 3) & CM2_N1) << 4 | ((TL | T | TR) & CM2_N1) >> 4;
+  const uint64_t rl = cm2_nib_all(V) & ~any & ~cm2_nib_any(Mv);   // run-length mode (bit 0 of the nibble)
+  const uint64_t RLm = (rl << 4) - rl;                               // ... as a full nibble
+  const uint64_t LO = ((B << 1) & 0xEEEEEEEEEEEEEEEEull) | ((B << 2) & 0xCCCCCCCCCCCCCCCCull) | ((B << 3) & 0x8888888888888888ull);  // rows above the first 1
+  const uint64_t skipA = ~LO & RLm, skipB = skipA & ~B;              // rows the run covers: no zero-coding decision / no sign
+  const uint64_t hasbit = cm2_nib_any(B);
+  o.n0 = cm2_nib_pop(Mv) + cm2_nib_pop(S1);
+  o.n1 = cm2_nib_pop(Zv);
+  o.n2 = cm2_nib_pop(C & ~skipA) + cm2_nib_pop(S2 & ~skipB) + rl + 2 * (rl & hasbit);
+  o.act = cm2_nib_any(o.n0 | o.n1 | o.n2) & ~(rl & ~hasbit);
+}
+// v_perm_b32: byte k of the result = byte sel[k] of {b (0..3), a (4..7)}
+T1HD uint32_t cm2_perm(uint32_t a, uint32_t b, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(a, b, sel);
+#else
+  const uint64_t ab = (uint64_t)b | (uint64_t)a << 32;
+  uint32_t r = 0;
+  for (int k = 0; k < 4; k++) r |= (uint32_t)((ab >> (8 * ((sel >> (8 * k)) & 7))) & 0xFF) << (8 * k);
+  return r;
+#endif
+}
+// the four nibble arrays as one 16-bit word per stripe -- n0 | n1 << 4 | n2 << 8 | act << 12 -- in the order CM2_PK_AT gives
+#define CM2_PK_AT(s) (8 * ((s) >> 3) + 4 * ((s) & 1) + (((s) & 7) >> 1))   // halfword index of stripe s within the column's 32 bytes
+T1HD void cm2_pack_pk(const Cm2Counts& c, uint32_t out[8]) {
+  for (int h = 0; h < 2; h++) {
+    const uint32_t A = (uint32_t)(c.n0 >> (32 * h)), B = (uint32_t)(c.n1 >> (32 * h)), C = (uint32_t)(c.n2 >> (32 * h)), D = (uint32_t)(c.act >> (32 * h));
+    const uint32_t X = (A & 0x0F0F0F0Fu) | (B & 0x0F0F0F0Fu) << 4, Y = ((A >> 4) & 0x0F0F0F0Fu) | (B & 0xF0F0F0F0u);     // even / odd stripes: n0 | n1 << 4
+    const uint32_t X2 = (C & 0x0F0F0F0Fu) | (D & 0x0F0F0F0Fu) << 4, Y2 = ((C >> 4) & 0x0F0F0F0Fu) | (D & 0xF0F0F0F0u);  // n2 | act << 4
+    out[4 * h + 0] = cm2_perm(X2, X, 0x05010400u); out[4 * h + 1] = cm2_perm(X2, X, 0x07030602u);
+    out[4 * h + 2] = cm2_perm(Y2, Y, 0x05010400u); out[4 * h + 3] = cm2_perm(Y2, Y, 0x07030602u);
+  }
+}
+
 // A lane's position in one pass's byte stream: whole words are OR-ed into a zeroed buffer (the first and the last word of a
 // lane's range are shared with its neighbours; a word may be written before it is complete and again when it is).
 struct Cm2Stream {

@@ -398,6 +398,30 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
           cm2_stream_put8(st[0], O.p0); cm2_stream_put4(st[1], O.p1); cm2_stream_put4(st[2], O.hdr); cm2_stream_put8(st[2], O.p2);
         }
       for (int q = 0; q < 3; q++) cm2_stream_end(st[q]);
+      {  // the counts of all 16 stripes of a column at once (cm2_counts_swar on row masks) and their packed form, against cm2_counts_w
+        uint64_t V[66] = {0}, Z[66] = {0}, Bm[66] = {0}, Mm[66] = {0}, T[66] = {0}, T2[66] = {0};   // [x + 1]
+        for (int s = 0; s < nstr; s++)
+          for (int x = 0; x < w; x++) {
+            const uint32_t c = cw[s + 1][x + 1];
+            V[x + 1] |= (uint64_t)((c >> CW_VAL) & 0xF) << (4 * s); Z[x + 1] |= (uint64_t)((c >> CW_SIG0) & 0xF) << (4 * s);
+            Bm[x + 1] |= (uint64_t)((c >> CW_BIT) & 0xF) << (4 * s); Mm[x + 1] |= (uint64_t)((c >> CW_M) & 0xF) << (4 * s);
+            T[x + 1] |= (uint64_t)(((c >> CW_SIG0) | (c >> CW_S1)) & 0xF) << (4 * s);
+            T2[x + 1] |= (uint64_t)(((c >> CW_SIG0) | (c >> CW_S1) | (c >> CW_S2)) & 0xF) << (4 * s);
+          }
+        for (int x = 0; x < 64; x++) {
+          Cm2Counts cc; uint32_t pk[8];
+          cm2_counts_swar(cc, V[x + 1], Z[x + 1], Bm[x + 1], Mm[x + 1], T[x], T2[x], T[x + 2], T2[x + 2]);
+          cm2_pack_pk(cc, pk);
+          for (int s = 0; s < 16; s++) {
+            int n3[3]; bool plain = false;
+            cm2_counts_w(&cw[s][x], &cw[s + 1][x], &cw[s + 2][x], n3, &plain);
+            const int act = !plain && (n3[0] | n3[1] | n3[2]);
+            const int want = n3[0] | n3[1] << 4 | n3[2] << 8 | act << 12;
+            const int got = ((const uint16_t*)pk)[CM2_PK_AT(s)];
+            if (got != want) return -13;
+          }
+        }
+      }
       {  // the kernel's form: 64 "lanes" x 16 consecutive columns through the sliding window of spread columns, counts from raw words
         static uint8_t zcx[1024];
         for (int i = 0; i < 512; i++) zcx[i] = cx.zc[i];
