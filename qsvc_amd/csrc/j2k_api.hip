@@ -264,6 +264,7 @@ struct J2kState {
   T2Pool* pool = nullptr;
   DevBuf coefA, llA, llB, sbtab_d, planes_d, cbs_d, nbps_d, mags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
   DevBuf joboff_d, order_d, segs_d, cnt_d, dist_d;  // Tier-1: first job of each block, MQ slot table, decision segments
+  DevBuf t1tabs_d;                                  // lookup tables of the context-modelling kernel (built at first use)
   DevBuf nbeff_d, njobs_d;                          // device job list: bit-planes as the Tier-1 kernels see them, total jobs
   size_t jobs_cap = 0;                              // jobs the segment / count (/ distortion) buffers were last sized for
   bool jobs_cap_dist = false;
@@ -307,7 +308,7 @@ void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->llA, &s->llB, &s->sbtab_d, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d, &s->nbeff_d, &s->njobs_d};
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d, &s->nbeff_d, &s->njobs_d, &s->t1tabs_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   for (auto& e : s->copied) if (e) (void)hipEventDestroy(e);
@@ -640,11 +641,16 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
                      (const uint8_t*)S.segs_d.p, (const int*)S.cnt_d.p, (const long long*)S.dist_d.p, (uint8_t*)S.outbuf.p, J2K_OUTCAP,
                      (CbOut*)S.res_d.p, (int*)S.plen_d.p, (long long*)S.pdist_d.p, want_dist ? 1 : 0, (int*)S.err_d.p);
     };
+    if (!S.t1tabs_d.p) {
+      if ((r = S.t1tabs_d.ensure(c, T1_TABLES_BYTES))) return r;
+      launch_t1_tables(c->st, (uint8_t*)S.t1tabs_d.p);
+    }
     pf.begin(c, "j2k_t1_cm");
     for (int k = 0; k < nparts; k++) {
       if (njobs && cut[k + 1] > cut[k])  // one context-modelling wave per block, its bit-planes one after the other (plane p = job joboff[block] + p)
         launch_t1_cm2(c->st, (const CbDesc*)S.cbs_d.p, ncb, nbp, (const int*)S.joboff_d.p, (const int*)S.order_d.p + cut[k],
-                      cut[k + 1] - cut[k], (const unsigned long long*)S.mags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p, want_dist ? 1 : 0);
+                      cut[k + 1] - cut[k], (const unsigned long long*)S.mags.p, (uint8_t*)S.segs_d.p, (int*)S.cnt_d.p, (long long*)S.dist_d.p, want_dist ? 1 : 0,
+                      (const uint8_t*)S.t1tabs_d.p);
       if (k + 1 < nparts) {
         HIPCHK(c, hipEventRecord(S.cm_done[k], c->st));
         HIPCHK(c, hipStreamWaitEvent(S.mq_st[k], S.cm_done[k], 0));

@@ -53,7 +53,9 @@ void launch_t1_pack_blk(hipStream_t st, const CbDesc* cbs, int ncb, const PlaneD
 void launch_t1_joblist(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, int cap_jobs, int* nb_eff, int* joboff, int* order, int nslots,
                        int* njobs_out, int* err);
 void launch_t1_cm2(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int count,
-                   const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist);
+                   const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist, const uint8_t* tabs);
+#define T1_TABLES_BYTES 4672   // = CM2_TAB_BYTES (t1_cm2.h)
+void launch_t1_tables(hipStream_t st, uint8_t* tabs);   // the table block of k_t1_cm2, once per context
 void launch_gather(hipStream_t st, const uint8_t* outbuf, int outcap, const unsigned long long* offs, const int* lens, int ncb,
                    uint8_t* dst);
 }  // namespace qsvc

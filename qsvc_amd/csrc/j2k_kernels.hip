@@ -475,15 +475,29 @@ __device__ __forceinline__ uint64_t cm2_transpose64(uint64_t v, int lane) {
   return (uint64_t)lo | (uint64_t)hi << 32;
 }
 
-#define CM2_OUT_BYTES 10240  // the largest pass segment (clean-up: 10 decisions per stripe column at most)
+#define CM2_OUT_BYTES 9984    // (with the list of the sparse form at CM2_LIST_AT: 480 entries)  // the largest pass segment (clean-up: 10 decisions per stripe column at most)
+static_assert(T1_TABLES_BYTES == CM2_TAB_BYTES, "table block size");
+__global__ void __launch_bounds__(64) k_t1_tables(uint8_t* tabs) {
+  const int t = threadIdx.x;
+  for (int i = t; i < 1536; i += 64) tabs[CM2_TAB_ZC + i] = (uint8_t)t1_zc_from_nb(i & 511, i < 512 ? 0 : (i < 1024 ? 1 : 3));
+  for (int i = t; i < 512; i += 64) tabs[CM2_TAB_REF + i] = (uint8_t)(((i >> 4) & 1) ? 16 : ((i & 0x1EF) ? 15 : 14));
+  for (int i = t; i < 256; i += 64) tabs[CM2_TAB_SIGN + i] = cm2_sign_entry(i);
+  ((uint32_t*)(tabs + CM2_TAB_SP))[t] = CM2_SPREAD_INIT((uint32_t)t);
+  if (t < 16) ((uint32_t*)(tabs + CM2_TAB_CMP4))[t] = cm2_cmp4_entry(t);
+  for (int i = t; i < 256; i += 64) ((uint64_t*)(tabs + CM2_TAB_CMP8))[i] = cm2_cmp8_entry(i);
+}
+void launch_t1_tables(hipStream_t st, uint8_t* tabs) { hipLaunchKernelGGL(k_t1_tables, dim3(1), dim3(64), 0, st, tabs); }
+
 __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff, const int* order,
-                                                const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist) {
+                                                const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist, const uint8_t* tabs) {
   __shared__ uint32_t s_cw[18][66];
-  __shared__ uint32_t s_sp[64];
-  __shared__ uint8_t s_zc[1024];  // [0..511] zero coding, [512..1023] refinement (t1_cm2.h, cm2_emit3w)
+  __shared__ __attribute__((aligned(16))) uint32_t s_sp[64];
+  __shared__ __attribute__((aligned(16))) uint8_t s_zc[1024];  // [0..511] zero coding, [512..1023] refinement (t1_cm2.h, cm2_emit3w)
   __shared__ __attribute__((aligned(16))) uint8_t s_out[CM2_OUT_BYTES + 16];  // zeroed per plane; the streams OR whole words into it
-  __shared__ uint8_t s_sign[256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_sign[256];
   __shared__ __attribute__((aligned(16))) uint32_t s_pk[64][8];   // per column: its 16 stripes' decisions per pass + "listed" flag (cm2_pack_pk)
+  __shared__ __attribute__((aligned(16))) uint64_t s_cmp8[256];
+  __shared__ __attribute__((aligned(16))) uint32_t s_cmp4[16];
   // order != nullptr: workgroup k models block order[k] (the MQ stage's slot table: longest blocks first; ncb = an idle slot)
   const int lane = threadIdx.x, b = order ? order[blockIdx.x] : (int)blockIdx.x;
   if (b >= ncb) return;
@@ -493,12 +507,17 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
   if (nb <= 0) return;  // (the whole workgroup)
   const size_t job0 = (size_t)joboff[b];
   const unsigned long long* mg = mags + (size_t)b * 1024;
-  // tables, once per block
-  s_sp[lane] = CM2_SPREAD_INIT((uint32_t)lane);
-  for (int i = lane; i < 256; i += 64) s_sign[i] = cm2_sign_entry(i);
+  // tables, once per block: 16-byte copies out of the context's table block
   {
-    const int oc = orient == 1 ? 1 : (orient == 3 ? 3 : 0);
-    for (int i = lane; i < 512; i += 64) { s_zc[i] = (uint8_t)t1_zc_from_nb(i, oc); s_zc[512 + i] = (uint8_t)(((i >> 4) & 1) ? 16 : ((i & 0x1EF) ? 15 : 14)); }
+    const int oc = orient == 1 ? 1 : (orient == 3 ? 2 : 0);
+    const uint4* zc = (const uint4*)(tabs + CM2_TAB_ZC + 512 * oc);
+    const uint4* rf = (const uint4*)(tabs + CM2_TAB_REF);
+    if (lane < 32) ((uint4*)s_zc)[lane] = zc[lane]; else ((uint4*)s_zc)[lane] = rf[lane - 32];
+    if (lane < 16) ((uint4*)s_sign)[lane] = ((const uint4*)(tabs + CM2_TAB_SIGN))[lane];
+    else if (lane < 32) ((uint4*)s_sp)[lane - 16] = ((const uint4*)(tabs + CM2_TAB_SP))[lane - 16];
+    else if (lane < 36) ((uint4*)s_cmp4)[lane - 32] = ((const uint4*)(tabs + CM2_TAB_CMP4))[lane - 32];
+    ((uint4*)s_cmp8)[lane] = ((const uint4*)(tabs + CM2_TAB_CMP8))[lane];
+    ((uint4*)s_cmp8)[lane + 64] = ((const uint4*)(tabs + CM2_TAB_CMP8))[lane + 64];
   }
   for (int i = lane; i < 18 * 66; i += 64) (&s_cw[0][0])[i] = 0;
   // The block's magnitudes stay in registers for all of its bit-planes (lane = column x: 16 stripes x 4 rows).  The state of a
@@ -640,7 +659,7 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
         Cm2Win c;
         cm2_win_at(c, s_sp, &s_cw[0][0], 66, s, x);
         Cm2Out3 O;
-        cm2_emit3w(O, s_zc, s_sign, c);
+        cm2_emit3s(O, s_zc, s_sign, s_cmp8, s_cmp4, c);
         Cm2Stream T0, T1, T2;
         cm2_stream_begin(T0, s_out, e.o0); cm2_stream_begin(T1, s_out + base1, e.o1); cm2_stream_begin(T2, s_out + base2, e.o2);
         cm2_stream_put8(T0, O.p0); cm2_stream_put4(T1, O.p1); cm2_stream_put4(T2, O.hdr); cm2_stream_put8(T2, O.p2);
@@ -684,7 +703,7 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
           if (col_on) { Cm2Bytes run1; run1.a = T1_CTX_RUN; run1.n = 1; cm2_stream_put4(T2, run1); }
         } else if (col_on) {
           Cm2Out3 O;
-          cm2_emit3w(O, s_zc, s_sign, c);
+          cm2_emit3s(O, s_zc, s_sign, s_cmp8, s_cmp4, c);
           cm2_stream_put8(T0, O.p0); cm2_stream_put4(T1, O.p1); cm2_stream_put4(T2, O.hdr); cm2_stream_put8(T2, O.p2);
           if (want_dist) cm2_dist3(cx, own, mg[lane * 16 + j], d3);
         }
@@ -733,9 +752,9 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
 }
 // order == nullptr: every block, in index order; else the `count` slots order[0 .. count)
 void launch_t1_cm2(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int count,
-                   const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist) {
+                   const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist, const uint8_t* tabs) {
   const int n = order ? count : ncb;
-  if (n > 0) hipLaunchKernelGGL(k_t1_cm2, dim3(n), dim3(64), 0, st, cbs, ncb, nbps, joboff, order, mags, segs, cnt, dist, want_dist);
+  if (n > 0) hipLaunchKernelGGL(k_t1_cm2, dim3(n), dim3(64), 0, st, cbs, ncb, nbps, joboff, order, mags, segs, cnt, dist, want_dist, tabs);
 }
 
 // gather: segment of block b (bytes 1..len of its lane buffer) -> dst + offs[b]

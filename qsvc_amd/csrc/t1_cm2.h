@@ -48,6 +48,20 @@ T1HD uint32_t cm2_colword(uint64_t m, int p, int rows, bool col_ok) {
 T1HD uint32_t cm2_six(uint32_t up, uint32_t mid, uint32_t dn, int f) {
   return ((up >> (f + 3)) & 1) | (((mid >> f) & 0xF) << 1) | (((dn >> f) & 1) << 5);
 }
+// v_perm_b32: byte k of the result = byte sel[k] of {b (0..3), a (4..7)}
+T1HD uint32_t cm2_perm(uint32_t a, uint32_t b, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(a, b, sel);
+#else
+  const uint64_t ab = (uint64_t)b | (uint64_t)a << 32;
+  uint32_t r = 0;
+  for (int k = 0; k < 4; k++) {
+    const uint32_t q = (sel >> (8 * k)) & 0xFF;   // 0..7: that byte; 12: 0x00; 13 and above: 0xFF (8..11, the sign replications, are not used here)
+    r |= (q >= 13 ? 0xFFu : (q == 12 ? 0u : (uint32_t)((ab >> (8 * (q & 7))) & 0xFF))) << (8 * k);
+  }
+  return r;
+#endif
+}
 // 6-row vector -> every third bit (bit r -> 3r): one column of the 18-bit neighbourhood word of t1_core.h
 #define CM2_SPREAD_INIT(v) (((v) & 1) | (((v) & 2) << 2) | (((v) & 4) << 4) | (((v) & 8) << 6) | (((v) & 16) << 8) | (((v) & 32) << 10))
 
@@ -359,7 +373,7 @@ T1HD void cm2_win_at(Cm2Win& c, const uint32_t* sp, const uint32_t* cw, int cwst
 // Sparse bit-planes (most columns "plain"): the columns that are not plain are listed -- column, and where its decisions go in
 // each of the three streams -- and worked off 64 at a time, instead of every lane walking all of its 16 columns.
 struct Cm2Entry { uint16_t col, o0, o1, o2; };   // col = stripe * 64 + x; byte offsets into the three streams
-#define CM2_LIST_MAX 512
+#define CM2_LIST_MAX 480
 #define CM2_LIST_AT 6144            // the list lives in the upper part of the (then small) stream buffer
 // the centre column is four insignificant zeros without a significant neighbour: its only decision is RUN = 0 (clean-up pass)
 T1HD bool cm2_plain_run(const Cm2Win& c) {
@@ -421,6 +435,87 @@ T1HD void cm2_emit3w(Cm2Out3& O, const uint8_t* zcx, const uint8_t* signlut, con
     const uint32_t lo = x2[0] | x2[1] << (8 * c0), hi = x2[2] | x2[3] << (8 * c2);
     O.p2.a = (uint64_t)lo | (uint64_t)hi << (8 * (c0 + c1));
     O.p2.n = c0 + c1 + c2 + c3;
+  }
+}
+// The same column with its four rows side by side in one register (a context byte and a sign byte per row): the rows' decision
+// bytes are looked up row by row, everything after that -- the decision bits, which bytes belong to which pass and their order
+// -- happens on all four rows at once: a pass's string is a byte compaction of [A0, B0, A1, B1, A2, B2, A3, B3] (A = zero coding /
+// refinement decision, B = sign decision) by the pass's membership masks, done by v_perm with selectors from a table.
+// cmp8[EA | EB << 4]: the two selector words that move the kept bytes (A_k where EA has bit k, B_k where EB has) to the front, zeros
+// behind; cmp4[E]: the same for the four A bytes alone (refinement pass).
+T1HD uint64_t cm2_cmp8_entry(int m) {
+  uint64_t sel = 0;
+  int n = 0;
+  for (int k = 0; k < 4; k++) {
+    if ((m >> k) & 1) sel |= (uint64_t)(2 * k) << (8 * n++);
+    if ((m >> (4 + k)) & 1) sel |= (uint64_t)(2 * k + 1) << (8 * n++);
+  }
+  for (; n < 8; n++) sel |= (uint64_t)0x0C << (8 * n);
+  return sel;
+}
+T1HD uint32_t cm2_cmp4_entry(int m) {
+  uint32_t sel = 0;
+  int n = 0;
+  for (int k = 0; k < 4; k++) if ((m >> k) & 1) sel |= (uint32_t)k << (8 * n++);
+  for (; n < 4; n++) sel |= 0x0Cu << (8 * n);
+  return sel;
+}
+T1HD int cm2_popc8(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)__popc(v);
+#else
+  return cm2_popc4(v) + cm2_popc4(v >> 4);
+#endif
+}
+T1HD void cm2_emit3s(Cm2Out3& O, const uint8_t* zcx, const uint8_t* signlut, const uint64_t* cmp8, const uint32_t* cmp4, const Cm2Win& c) {
+  const uint32_t w = c.w;
+  const uint32_t val4 = (w >> CW_VAL) & 0xF;
+  const uint32_t bit4 = (w >> CW_BIT) & 0xF, M4 = (w >> CW_M) & val4, sig04 = (w >> CW_SIG0) & val4;
+  const uint32_t mu4 = (w >> CW_MU) & 0xF, neg4 = (w >> CW_NEG) & 0xF;
+  const uint32_t C4 = val4 & ~sig04 & ~M4;
+  const uint32_t S14 = M4 & bit4, S24 = C4 & bit4;
+  const uint32_t fref = c.AB[0] | c.AB[1] << 1 | c.AB[2] << 2;
+  const uint32_t f0 = c.Q[0] | c.P[1] << 1 | c.P[2] << 2;
+  const uint32_t f2 = fref | c.DL[0] | c.DB[1] << 1 | c.DB[2] << 2;
+  const uint32_t fchi = c.X[0] | c.X[1] << 1 | c.X[2] << 2;
+  const uint32_t G1 = (c.B1 & 0x1248) << 1, G2 = (c.D1 & 0x1248) << 1;
+  const uint32_t rl = (val4 == 0xF && f2 == 0 && M4 == 0) ? ~0u : 0u;
+  const uint32_t lowest = bit4 & (0u - bit4);
+  const uint32_t skipA4 = rl & (2 * lowest - 1) & 0xF, skipB4 = rl & (lowest - 1) & 0xF;
+  const uint32_t fk = (lowest >> 1) - (lowest >> 3);
+  const uint32_t hdr3 = (uint32_t)(T1_CTX_RUN | 32) | (uint32_t)(T1_CTX_UNI | ((fk >> 1) << 5)) << 8 | (uint32_t)(T1_CTX_UNI | ((fk & 1) << 5)) << 16;
+  O.hdr.a = rl & (bit4 ? hdr3 : (uint32_t)T1_CTX_RUN);
+  O.hdr.n = (int)(rl & (bit4 ? 3u : 1u));
+  const uint32_t EA2 = C4 & ~skipA4, EB2 = S24 & ~skipB4;
+  uint32_t A4 = 0, B4 = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t mM = cm2_m(M4, k), m1 = cm2_m(sig04, k);
+    const uint32_t cmask = (1u << (3 * k + 2)) - 1;
+    const uint32_t fz = cm2_pick(m1, fref, cm2_pick(mM, f0 | (G1 & cmask), f2 | (G2 & cmask)));
+    const uint32_t nb = (fz >> (3 * k)) & 0x1FF;
+    const uint32_t li = (nb & 0x1EF) | (m1 & (0x200u | (cm2_m(mu4, k) & 0x10u)));
+    const uint32_t idx = ((nb & 0xAA) >> 1) | ((fchi >> (3 * k)) & 0xAA);
+    A4 |= (uint32_t)zcx[li] << (8 * k);
+    B4 |= (uint32_t)signlut[idx] << (8 * k);
+  }
+  // the decision bits: bit 5 of every row's byte (0x00204081 puts bit k of a nibble at bit 8 k)
+  A4 |= ((bit4 * 0x00204081u) & 0x01010101u) << 5;
+  B4 ^= ((neg4 * 0x00204081u) & 0x01010101u) << 5;
+  O.p1.a = cm2_perm(0u, A4, cmp4[sig04]);
+  O.p1.n = cm2_popc4(sig04);
+  const uint32_t Ilo = cm2_perm(B4, A4, 0x05010400u), Ihi = cm2_perm(B4, A4, 0x07030602u);   // A0 B0 A1 B1 | A2 B2 A3 B3
+  {
+    const uint32_t m = M4 | S14 << 4;
+    const uint64_t sel = cmp8[m];
+    O.p0.a = (uint64_t)cm2_perm(Ihi, Ilo, (uint32_t)sel) | (uint64_t)cm2_perm(Ihi, Ilo, (uint32_t)(sel >> 32)) << 32;
+    O.p0.n = cm2_popc8(m);
+  }
+  {
+    const uint32_t m = EA2 | EB2 << 4;
+    const uint64_t sel = cmp8[m];
+    O.p2.a = (uint64_t)cm2_perm(Ihi, Ilo, (uint32_t)sel) | (uint64_t)cm2_perm(Ihi, Ilo, (uint32_t)(sel >> 32)) << 32;
+    O.p2.n = cm2_popc8(m);
   }
 }
 // the distortion sums of one column (lossy layers only), by pass
@@ -497,17 +592,6 @@ T1HD void cm2_counts_swar(Cm2Counts& o, uint64_t V, uint64_t Z, uint64_t B, uint
   o.n2 = cm2_nib_pop(C & ~skipA) + cm2_nib_pop(S2 & ~skipB) + rl + 2 * (rl & hasbit);
   o.act = cm2_nib_any(o.n0 | o.n1 | o.n2) & ~(rl & ~hasbit);
 }
-// v_perm_b32: byte k of the result = byte sel[k] of {b (0..3), a (4..7)}
-T1HD uint32_t cm2_perm(uint32_t a, uint32_t b, uint32_t sel) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_perm(a, b, sel);
-#else
-  const uint64_t ab = (uint64_t)b | (uint64_t)a << 32;
-  uint32_t r = 0;
-  for (int k = 0; k < 4; k++) r |= (uint32_t)((ab >> (8 * ((sel >> (8 * k)) & 7))) & 0xFF) << (8 * k);
-  return r;
-#endif
-}
 // the four nibble arrays as one 16-bit word per stripe -- n0 | n1 << 4 | n2 << 8 | act << 12 -- in the order CM2_PK_AT gives
 #define CM2_PK_AT(s) (8 * ((s) >> 3) + 4 * ((s) & 1) + (((s) & 7) >> 1))   // halfword index of stripe s within the column's 32 bytes
 T1HD void cm2_pack_pk(const Cm2Counts& c, uint32_t out[8]) {
@@ -519,6 +603,16 @@ T1HD void cm2_pack_pk(const Cm2Counts& c, uint32_t out[8]) {
     out[4 * h + 2] = cm2_perm(Y2, Y, 0x05010400u); out[4 * h + 3] = cm2_perm(Y2, Y, 0x07030602u);
   }
 }
+
+// The lookup tables of the context-modelling kernel, built once per context in device memory (k_t1_tables) and copied into LDS by
+// every workgroup: byte offsets into the table block.
+#define CM2_TAB_ZC 0        // [3][512] zero coding by neighbourhood, orientation classes LL/LH, HL, HH (t1_zc_from_nb)
+#define CM2_TAB_REF 1536    // [512] refinement: bit 4 = "refined before", the other bits = significant neighbours
+#define CM2_TAB_SIGN 2048   // [256] cm2_sign_entry
+#define CM2_TAB_SP 2304     // [64] u32 CM2_SPREAD_INIT
+#define CM2_TAB_CMP4 2560   // [16] u32 cm2_cmp4_entry
+#define CM2_TAB_CMP8 2624   // [256] u64 cm2_cmp8_entry
+#define CM2_TAB_BYTES 4672
 
 // A lane's position in one pass's byte stream: whole words are OR-ed into a zeroed buffer (the first and the last word of a
 // lane's range are shared with its neighbours; a word may be written before it is complete and again when it is).
