@@ -584,12 +584,18 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
       *(uint4*)&s_pk[lane][0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
       *(uint4*)&s_pk[lane][4] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     }
-    auto nib = [](uint64_t v, int s) { return (uint32_t)(v >> (4 * s)) & 0xFu; };
+    // the column words of the 16 stripes: a nibble transpose of the eight masks (cm2_colwords8); lanes beyond the width hold 0 in every mask
+    const uint64_t F[8] = {Zc, Bc, NEGc, MUc, VALc, Mc, S1c, S2c};
 #pragma unroll
-    for (int s = 0; s < 16; s++)
-      if (s < nstr)   // (uniform; lanes beyond the width hold 0 in every mask)
-        s_cw[s + 1][lane + 1] = nib(Zc, s) << CW_SIG0 | nib(Bc, s) << CW_BIT | nib(NEGc, s) << CW_NEG | nib(MUc, s) << CW_MU | nib(VALc, s) << CW_VAL |
-                                nib(Mc, s) << CW_M | nib(S1c, s) << CW_S1 | nib(S2c, s) << CW_S2;
+    for (int hh = 0; hh < 2; hh++) {
+      uint32_t f[8], o8[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) f[q] = (uint32_t)(F[q] >> (32 * hh));
+      cm2_colwords8(f, o8);
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (8 * hh + k < nstr) s_cw[8 * hh + k + 1][lane + 1] = o8[k];   // (uniform)
+    }
   }
   __syncthreads();
   Cm2Ctx cx;

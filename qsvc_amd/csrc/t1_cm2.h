@@ -604,6 +604,24 @@ T1HD void cm2_pack_pk(const Cm2Counts& c, uint32_t out[8]) {
   }
 }
 
+// The column words of eight stripes (8 h .. 8 h + 7) of one column from the 32-bit halves of its eight field masks, in the order of
+// the fields in the word (SIG0, BIT, NEG, MU, VAL, M, S1, S2; nibble s of a half = stripe 8 h + s): an 8 x 8 nibble transpose --
+// pairs of fields to bytes, then byte permutes -- instead of eight extractions and inserts per stripe.
+T1HD void cm2_colwords8(const uint32_t f[8], uint32_t out[8]) {
+  uint32_t X[4], Y[4];   // byte k of X[q]: fields 2 q, 2 q + 1 of stripe 2 k; of Y[q]: of stripe 2 k + 1
+  for (int q = 0; q < 4; q++) {
+    X[q] = (f[2 * q] & 0x0F0F0F0Fu) | (f[2 * q + 1] & 0x0F0F0F0Fu) << 4;
+    Y[q] = ((f[2 * q] >> 4) & 0x0F0F0F0Fu) | (f[2 * q + 1] & 0xF0F0F0F0u);
+  }
+  for (int odd = 0; odd < 2; odd++) {
+    const uint32_t* S = odd ? Y : X;
+    const uint32_t lo01 = cm2_perm(S[1], S[0], 0x05010400u), hi01 = cm2_perm(S[3], S[2], 0x05010400u);   // low / high halfwords of stripes 0, 2 (+ odd)
+    const uint32_t lo23 = cm2_perm(S[1], S[0], 0x07030602u), hi23 = cm2_perm(S[3], S[2], 0x07030602u);   // of stripes 4, 6 (+ odd)
+    out[0 + odd] = cm2_perm(hi01, lo01, 0x05040100u); out[2 + odd] = cm2_perm(hi01, lo01, 0x07060302u);
+    out[4 + odd] = cm2_perm(hi23, lo23, 0x05040100u); out[6 + odd] = cm2_perm(hi23, lo23, 0x07060302u);
+  }
+}
+
 // The lookup tables of the context-modelling kernel, built once per context in device memory (k_t1_tables) and copied into LDS by
 // every workgroup: byte offsets into the table block.
 #define CM2_TAB_ZC 0        // [3][512] zero coding by neighbourhood, orientation classes LL/LH, HL, HH (t1_zc_from_nb)

@@ -412,6 +412,18 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
           Cm2Counts cc; uint32_t pk[8];
           cm2_counts_swar(cc, V[x + 1], Z[x + 1], Bm[x + 1], Mm[x + 1], T[x], T2[x], T[x + 2], T2[x + 2]);
           cm2_pack_pk(cc, pk);
+          {  // the column words rebuilt from the masks by the nibble transpose
+            uint64_t F[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            static const int at[8] = {CW_SIG0, CW_BIT, CW_NEG, CW_MU, CW_VAL, CW_M, CW_S1, CW_S2};
+            for (int s = 0; s < 16; s++)
+              for (int q = 0; q < 8; q++) F[q] |= (uint64_t)((cw[s + 1][x + 1] >> at[q]) & 0xF) << (4 * s);
+            for (int hh = 0; hh < 2; hh++) {
+              uint32_t f[8], o8[8];
+              for (int q = 0; q < 8; q++) f[q] = (uint32_t)(F[q] >> (32 * hh));
+              cm2_colwords8(f, o8);
+              for (int k = 0; k < 8; k++) if (o8[k] != cw[8 * hh + k + 1][x + 1]) return -15;
+            }
+          }
           for (int s = 0; s < 16; s++) {
             int n3[3]; bool plain = false;
             cm2_counts_w(&cw[s][x], &cw[s + 1][x], &cw[s + 2][x], n3, &plain);
