@@ -54,7 +54,7 @@ void launch_t1_joblist(hipStream_t st, const CbDesc* cbs, int ncb, const int* nb
                        int* njobs_out, int* err);
 void launch_t1_cm2(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, const int* joboff, const int* order, int count,
                    const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist, const uint8_t* tabs);
-#define T1_TABLES_BYTES 4672   // = CM2_TAB_BYTES (t1_cm2.h)
+#define T1_TABLES_BYTES 4608   // = CM2_TAB_BYTES (t1_cm2.h)
 void launch_t1_tables(hipStream_t st, uint8_t* tabs);   // the table block of k_t1_cm2, once per context
 void launch_gather(hipStream_t st, const uint8_t* outbuf, int outcap, const unsigned long long* offs, const int* lens, int ncb,
                    uint8_t* dst);

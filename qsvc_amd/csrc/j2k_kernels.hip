@@ -475,6 +475,7 @@ __device__ __forceinline__ uint64_t cm2_transpose64(uint64_t v, int lane) {
   return (uint64_t)lo | (uint64_t)hi << 32;
 }
 
+#define CM2_CW_STRIDE 67
 #define CM2_OUT_BYTES 9984    // (with the list of the sparse form at CM2_LIST_AT: 480 entries)  // the largest pass segment (clean-up: 10 decisions per stripe column at most)
 static_assert(T1_TABLES_BYTES == CM2_TAB_BYTES, "table block size");
 __global__ void __launch_bounds__(64) k_t1_tables(uint8_t* tabs) {
@@ -483,21 +484,19 @@ __global__ void __launch_bounds__(64) k_t1_tables(uint8_t* tabs) {
   for (int i = t; i < 512; i += 64) tabs[CM2_TAB_REF + i] = (uint8_t)(((i >> 4) & 1) ? 16 : ((i & 0x1EF) ? 15 : 14));
   for (int i = t; i < 256; i += 64) tabs[CM2_TAB_SIGN + i] = cm2_sign_entry(i);
   ((uint32_t*)(tabs + CM2_TAB_SP))[t] = CM2_SPREAD_INIT((uint32_t)t);
-  if (t < 16) ((uint32_t*)(tabs + CM2_TAB_CMP4))[t] = cm2_cmp4_entry(t);
   for (int i = t; i < 256; i += 64) ((uint64_t*)(tabs + CM2_TAB_CMP8))[i] = cm2_cmp8_entry(i);
 }
 void launch_t1_tables(hipStream_t st, uint8_t* tabs) { hipLaunchKernelGGL(k_t1_tables, dim3(1), dim3(64), 0, st, tabs); }
 
 __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff, const int* order,
                                                 const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist, const uint8_t* tabs) {
-  __shared__ uint32_t s_cw[18][66];
+  __shared__ uint32_t s_cw[18][CM2_CW_STRIDE];   // one-cell apron of zeros; odd stride: the emission lanes (stripe, 16-column run) read 2-way, the best 64 lanes can get
   __shared__ __attribute__((aligned(16))) uint32_t s_sp[64];
   __shared__ __attribute__((aligned(16))) uint8_t s_zc[1024];  // [0..511] zero coding, [512..1023] refinement (t1_cm2.h, cm2_emit3w)
   __shared__ __attribute__((aligned(16))) uint8_t s_out[CM2_OUT_BYTES + 16];  // zeroed per plane; the streams OR whole words into it
   __shared__ __attribute__((aligned(16))) uint8_t s_sign[256];
   __shared__ __attribute__((aligned(16))) uint32_t s_pk[64][8];   // per column: its 16 stripes' decisions per pass + "listed" flag (cm2_pack_pk)
   __shared__ __attribute__((aligned(16))) uint64_t s_cmp8[256];
-  __shared__ __attribute__((aligned(16))) uint32_t s_cmp4[16];
   // order != nullptr: workgroup k models block order[k] (the MQ stage's slot table: longest blocks first; ncb = an idle slot)
   const int lane = threadIdx.x, b = order ? order[blockIdx.x] : (int)blockIdx.x;
   if (b >= ncb) return;
@@ -515,11 +514,10 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
     if (lane < 32) ((uint4*)s_zc)[lane] = zc[lane]; else ((uint4*)s_zc)[lane] = rf[lane - 32];
     if (lane < 16) ((uint4*)s_sign)[lane] = ((const uint4*)(tabs + CM2_TAB_SIGN))[lane];
     else if (lane < 32) ((uint4*)s_sp)[lane - 16] = ((const uint4*)(tabs + CM2_TAB_SP))[lane - 16];
-    else if (lane < 36) ((uint4*)s_cmp4)[lane - 32] = ((const uint4*)(tabs + CM2_TAB_CMP4))[lane - 32];
     ((uint4*)s_cmp8)[lane] = ((const uint4*)(tabs + CM2_TAB_CMP8))[lane];
     ((uint4*)s_cmp8)[lane + 64] = ((const uint4*)(tabs + CM2_TAB_CMP8))[lane + 64];
   }
-  for (int i = lane; i < 18 * 66; i += 64) (&s_cw[0][0])[i] = 0;
+  for (int i = lane; i < 18 * CM2_CW_STRIDE; i += 64) (&s_cw[0][0])[i] = 0;
   // The block's magnitudes stay in registers for all of its bit-planes (lane = column x: 16 stripes x 4 rows).  The state of a
   // plane is a handful of 64-bit masks in two layouts: by COLUMN (lane = x, bit y) where the column words are put together, by ROW
   // (lane = y, bit x) where the membership recurrence runs; a bit-matrix transpose across the wave (cm2_transpose64) takes the
@@ -663,9 +661,9 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
         const Cm2Entry e = list[k];
         const int s = e.col >> 6, x = e.col & 63;
         Cm2Win c;
-        cm2_win_at(c, s_sp, &s_cw[0][0], 66, s, x);
+        cm2_win_at(c, s_sp, &s_cw[0][0], CM2_CW_STRIDE, s, x);
         Cm2Out3 O;
-        cm2_emit3s(O, s_zc, s_sign, s_cmp8, s_cmp4, c);
+        cm2_emit3s(O, s_zc, s_sign, s_cmp8, c);
         Cm2Stream T0, T1, T2;
         cm2_stream_begin(T0, s_out, e.o0); cm2_stream_begin(T1, s_out + base1, e.o1); cm2_stream_begin(T2, s_out + base2, e.o2);
         cm2_stream_put8(T0, O.p0); cm2_stream_put4(T1, O.p1); cm2_stream_put4(T2, O.hdr); cm2_stream_put8(T2, O.p2);
@@ -709,7 +707,7 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
           if (col_on) { Cm2Bytes run1; run1.a = T1_CTX_RUN; run1.n = 1; cm2_stream_put4(T2, run1); }
         } else if (col_on) {
           Cm2Out3 O;
-          cm2_emit3s(O, s_zc, s_sign, s_cmp8, s_cmp4, c);
+          cm2_emit3s(O, s_zc, s_sign, s_cmp8, c);
           cm2_stream_put8(T0, O.p0); cm2_stream_put4(T1, O.p1); cm2_stream_put4(T2, O.hdr); cm2_stream_put8(T2, O.p2);
           if (want_dist) cm2_dist3(cx, own, mg[lane * 16 + j], d3);
         }

@@ -442,7 +442,7 @@ T1HD void cm2_emit3w(Cm2Out3& O, const uint8_t* zcx, const uint8_t* signlut, con
 // -- happens on all four rows at once: a pass's string is a byte compaction of [A0, B0, A1, B1, A2, B2, A3, B3] (A = zero coding /
 // refinement decision, B = sign decision) by the pass's membership masks, done by v_perm with selectors from a table.
 // cmp8[EA | EB << 4]: the two selector words that move the kept bytes (A_k where EA has bit k, B_k where EB has) to the front, zeros
-// behind; cmp4[E]: the same for the four A bytes alone (refinement pass).
+// behind (the refinement pass, A bytes only, reads entry EA | 0 and keeps the first word).
 T1HD uint64_t cm2_cmp8_entry(int m) {
   uint64_t sel = 0;
   int n = 0;
@@ -453,13 +453,6 @@ T1HD uint64_t cm2_cmp8_entry(int m) {
   for (; n < 8; n++) sel |= (uint64_t)0x0C << (8 * n);
   return sel;
 }
-T1HD uint32_t cm2_cmp4_entry(int m) {
-  uint32_t sel = 0;
-  int n = 0;
-  for (int k = 0; k < 4; k++) if ((m >> k) & 1) sel |= (uint32_t)k << (8 * n++);
-  for (; n < 4; n++) sel |= 0x0Cu << (8 * n);
-  return sel;
-}
 T1HD int cm2_popc8(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (int)__popc(v);
@@ -467,7 +460,7 @@ T1HD int cm2_popc8(uint32_t v) {
   return cm2_popc4(v) + cm2_popc4(v >> 4);
 #endif
 }
-T1HD void cm2_emit3s(Cm2Out3& O, const uint8_t* zcx, const uint8_t* signlut, const uint64_t* cmp8, const uint32_t* cmp4, const Cm2Win& c) {
+T1HD void cm2_emit3s(Cm2Out3& O, const uint8_t* zcx, const uint8_t* signlut, const uint64_t* cmp8, const Cm2Win& c) {
   const uint32_t w = c.w;
   const uint32_t val4 = (w >> CW_VAL) & 0xF;
   const uint32_t bit4 = (w >> CW_BIT) & 0xF, M4 = (w >> CW_M) & val4, sig04 = (w >> CW_SIG0) & val4;
@@ -502,9 +495,9 @@ T1HD void cm2_emit3s(Cm2Out3& O, const uint8_t* zcx, const uint8_t* signlut, con
   // the decision bits: bit 5 of every row's byte (0x00204081 puts bit k of a nibble at bit 8 k)
   A4 |= ((bit4 * 0x00204081u) & 0x01010101u) << 5;
   B4 ^= ((neg4 * 0x00204081u) & 0x01010101u) << 5;
-  O.p1.a = cm2_perm(0u, A4, cmp4[sig04]);
-  O.p1.n = cm2_popc4(sig04);
   const uint32_t Ilo = cm2_perm(B4, A4, 0x05010400u), Ihi = cm2_perm(B4, A4, 0x07030602u);   // A0 B0 A1 B1 | A2 B2 A3 B3
+  O.p1.a = cm2_perm(Ihi, Ilo, (uint32_t)cmp8[sig04]);
+  O.p1.n = cm2_popc4(sig04);
   {
     const uint32_t m = M4 | S14 << 4;
     const uint64_t sel = cmp8[m];
@@ -628,9 +621,8 @@ T1HD void cm2_colwords8(const uint32_t f[8], uint32_t out[8]) {
 #define CM2_TAB_REF 1536    // [512] refinement: bit 4 = "refined before", the other bits = significant neighbours
 #define CM2_TAB_SIGN 2048   // [256] cm2_sign_entry
 #define CM2_TAB_SP 2304     // [64] u32 CM2_SPREAD_INIT
-#define CM2_TAB_CMP4 2560   // [16] u32 cm2_cmp4_entry
-#define CM2_TAB_CMP8 2624   // [256] u64 cm2_cmp8_entry
-#define CM2_TAB_BYTES 4672
+#define CM2_TAB_CMP8 2560   // [256] u64 cm2_cmp8_entry
+#define CM2_TAB_BYTES 4608
 
 // A lane's position in one pass's byte stream: whole words are OR-ed into a zeroed buffer (the first and the last word of a
 // lane's range are shared with its neighbours; a word may be written before it is complete and again when it is).

@@ -452,10 +452,10 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
             Cm2Out3 O;
             cm2_emit3w(O, zcx, signlut, win);
             {  // the four-rows-at-once form must give the same four strings, zeros behind them
-              static uint64_t cmp8[256]; static uint32_t cmp4[16]; static bool have = false;
-              if (!have) { for (int i = 0; i < 256; i++) cmp8[i] = cm2_cmp8_entry(i); for (int i = 0; i < 16; i++) cmp4[i] = cm2_cmp4_entry(i); have = true; }
+              static uint64_t cmp8[256]; static bool have = false;
+              if (!have) { for (int i = 0; i < 256; i++) cmp8[i] = cm2_cmp8_entry(i); have = true; }
               Cm2Out3 S;
-              cm2_emit3s(S, zcx, signlut, cmp8, cmp4, win);
+              cm2_emit3s(S, zcx, signlut, cmp8, win);
               if (S.p0.a != O.p0.a || S.p0.n != O.p0.n || S.p1.a != O.p1.a || S.p1.n != O.p1.n || S.hdr.a != O.hdr.a || S.hdr.n != O.hdr.n ||
                   S.p2.a != O.p2.a || S.p2.n != O.p2.n) return -14;
             }
