@@ -638,6 +638,10 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
   if (nact <= CM2_LIST_MAX && base2 + tot3[2] + 16 <= CM2_LIST_AT) {
     // ---- sparse plane: plain columns put their RUN byte, the others are listed and worked off 64 at a time ---------------
     Cm2Entry* list = (Cm2Entry*)(s_out + CM2_LIST_AT);
+    // (the RUN bytes of the lane's plain columns through a sequential stream: whole words by plain stores, zeros where the listed
+    // columns' clean-up decisions are OR-ed in afterwards)
+    Cm2Seq R2;
+    cm2_seq_begin(R2, s_out + base2, off3[2], nullptr);
     if (lane_live) {
       int o0 = off3[0], o1 = off3[1], o2 = off3[2], lp = apos;
 #pragma unroll
@@ -648,12 +652,14 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
           Cm2Entry e;
           e.col = (uint16_t)(ls * 64 + lx0 + j); e.o0 = (uint16_t)o0; e.o1 = (uint16_t)o1; e.o2 = (uint16_t)o2;
           list[lp++] = e;
+          cm2_seq_skip_b(R2, n2);
         } else if (n2) {
-          cm2_or_word((uint32_t*)(s_out + base2) + (o2 >> 2), (uint32_t)T1_CTX_RUN << (8 * (o2 & 3)));
+          cm2_seq_put1_b(R2, (uint32_t)T1_CTX_RUN);
         }
         o0 += n0; o1 += n1; o2 += n2;
       }
     }
+    cm2_seq_end(R2);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
     for (int base = 0; base < nact; base += 64) {
       const int k = base + lane;
@@ -684,10 +690,12 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
       for (int o = lane * 16; o < tot3[pass]; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(src + o);
     }
   } else if (base2 + tot3[2] <= CM2_OUT_BYTES) {
-    Cm2Stream T0, T1, T2;
-    cm2_stream_begin(T0, s_out, off3[0]);
-    cm2_stream_begin(T1, s_out + base1, off3[1]);
-    cm2_stream_begin(T2, s_out + base2, off3[2]);
+    // (the lane's dummy word for stores that are not due yet: the packed counts are dead from here to the next plane)
+    uint32_t* const trash = &s_pk[0][0] + lane;
+    Cm2Seq T0, T1, T2;
+    cm2_seq_begin(T0, s_out, off3[0], trash);
+    cm2_seq_begin(T1, s_out + base1, off3[1], trash);
+    cm2_seq_begin(T2, s_out + base2, off3[2], trash);
     if (lane_live) {
       Cm2Win c;
       c.w = 0; c.B1 = c.D1 = c.Bn = c.Dn = 0;
@@ -704,17 +712,17 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
         const bool col_on = lx0 + j < w;
         const bool plain = !col_on || cm2_plain_run(c);
         if (!__any(!plain)) {
-          if (col_on) { Cm2Bytes run1; run1.a = T1_CTX_RUN; run1.n = 1; cm2_stream_put4(T2, run1); }
+          if (col_on) { Cm2Bytes run1; run1.a = T1_CTX_RUN; run1.n = 1; cm2_seq_put4(T2, run1); }
         } else if (col_on) {
           Cm2Out3 O;
           cm2_emit3s(O, s_zc, s_sign, s_cmp8, c);
-          cm2_stream_put8(T0, O.p0); cm2_stream_put4(T1, O.p1); cm2_stream_put4(T2, O.hdr); cm2_stream_put8(T2, O.p2);
+          cm2_seq_put8(T0, O.p0); cm2_seq_put4(T1, O.p1); cm2_seq_put4(T2, O.hdr); cm2_seq_put8(T2, O.p2);
           if (want_dist) cm2_dist3(cx, own, mg[lane * 16 + j], d3);
         }
         own = nm;
       }
     }
-    cm2_stream_end(T0); cm2_stream_end(T1); cm2_stream_end(T2);
+    cm2_seq_end(T0); cm2_seq_end(T1); cm2_seq_end(T2);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
     if (lane < 16)  // the tails of the last 16-byte chunks: the idle decision (t1_core.h, T1_PAD)
       for (int pass = pass0; pass < 3; pass++) {

@@ -660,6 +660,60 @@ T1HD void cm2_stream_put4(Cm2Stream& s, const Cm2Bytes& b) {  // up to 4 bytes
 }
 T1HD void cm2_stream_end(Cm2Stream& s) { if (s.fill) cm2_or_word(s.wp, s.pend); }
 
+// The same for a lane that appends a whole contiguous range (its 16 columns' strings one after the other), without LDS atomics
+// (measured: the kernel's largest single cost): a word leaves with a plain store once it is complete -- until then the store is
+// pointed at a per-lane dummy word, which is cheaper than an exec-mask branch -- and only what is left at the end, the partial
+// last word the next lane's range begins in, is OR-ed in.  A completed FIRST word may lack the bytes of the previous lane's tail:
+// that lane ORs them in at its end, and since the wave runs its lanes in lockstep every plain store of the loop is older than
+// every OR behind the loop (the LDS keeps a wave's accesses in order).
+struct Cm2Seq {
+  uint32_t* wp;     // the word the next byte falls into
+  uint32_t pend;    // its bytes so far
+  uint32_t fill;    // how many (0..3)
+  uint32_t* trash;  // a word of this lane's own nobody reads
+};
+T1HD void cm2_seq_begin(Cm2Seq& s, uint8_t* base /*4-byte aligned*/, int byte_off, uint32_t* trash) {
+  s.wp = (uint32_t*)base + (byte_off >> 2); s.pend = 0; s.fill = (uint32_t)(byte_off & 3); s.trash = trash;
+}
+T1HD void cm2_seq_put8(Cm2Seq& s, const Cm2Bytes& b) {  // up to 8 bytes (zeros behind them)
+  const uint64_t sh = b.a << (8 * s.fill);
+  const uint32_t lo = s.pend | (uint32_t)sh, mid = (uint32_t)(sh >> 32), hi = ((uint32_t)(b.a >> 32) >> 8) >> (24 - 8 * s.fill);
+  const uint32_t total = s.fill + (uint32_t)b.n, adv = total >> 2;
+  *(adv >= 1 ? s.wp : s.trash) = lo;
+  *(adv >= 2 ? s.wp + 1 : s.trash) = mid;
+  s.pend = adv == 0 ? lo : (adv == 1 ? mid : hi);
+  s.wp += adv; s.fill = total & 3;
+}
+T1HD void cm2_seq_put4(Cm2Seq& s, const Cm2Bytes& b) {  // up to 4 bytes
+  const uint64_t sh = (uint64_t)(uint32_t)b.a << (8 * s.fill);
+  const uint32_t lo = s.pend | (uint32_t)sh, mid = (uint32_t)(sh >> 32);
+  const uint32_t total = s.fill + (uint32_t)b.n, adv = total >> 2;
+  *(adv ? s.wp : s.trash) = lo;
+  s.pend = adv ? mid : lo;
+  s.wp += adv; s.fill = total & 3;
+}
+T1HD void cm2_seq_skip(Cm2Seq& s, int n) {  // n bytes that others fill in later (they OR into the zeros left here)
+  const uint32_t total = s.fill + (uint32_t)n, adv = total >> 2;
+  *(adv ? s.wp : s.trash) = s.pend;
+  s.pend = adv ? 0u : s.pend;
+  s.wp += adv; s.fill = total & 3;
+}
+// (the forms with a branch around the store: where there is no dummy word to point it at)
+T1HD void cm2_seq_put1_b(Cm2Seq& s, uint32_t byte) {
+  const uint32_t lo = s.pend | byte << (8 * s.fill);
+  const uint32_t total = s.fill + 1, adv = total >> 2;
+  if (adv) *s.wp = lo;
+  s.pend = adv ? 0u : lo;
+  s.wp += adv; s.fill = total & 3;
+}
+T1HD void cm2_seq_skip_b(Cm2Seq& s, int n) {
+  const uint32_t total = s.fill + (uint32_t)n, adv = total >> 2;
+  if (adv && s.pend) *s.wp = s.pend;
+  s.pend = adv ? 0u : s.pend;
+  s.wp += adv; s.fill = total & 3;
+}
+T1HD void cm2_seq_end(Cm2Seq& s) { if (s.fill) cm2_or_word(s.wp, s.pend); }
+
 template <class Sink>
 T1HD void cm2_column(Sink& K, const Cm2Ctx& cx, int pass, const uint32_t u[3], const uint32_t m[3], const uint32_t d[3],
                      uint64_t mag, long long& dist) {

@@ -468,6 +468,36 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
           }
         }
         for (int pass = 0; pass < 3; pass++) if (w3[pass] != e3[pass]) return -10;
+        {  // the lanes' ranges through the atomic-free sequential streams: all the loops first, then all the ends (the wave's lockstep)
+          std::vector<uint32_t> qb[3];
+          for (int q = 0; q < 3; q++) qb[q].assign(T1_SEG_BYTES / 4 + 8, 0);
+          Cm2Seq sq[64][3];
+          uint32_t trash[64];
+          int off[3] = {0, 0, 0};
+          for (int th = 0; th < 64; th++) {
+            const int ls = th >> 2, lx0 = (th & 3) * 16;
+            for (int q = 0; q < 3; q++) cm2_seq_begin(sq[th][q], (uint8_t*)qb[q].data(), off[q], &trash[th]);
+            if (ls >= nstr || lx0 >= w) continue;
+            for (int j = 0; j < 16 && lx0 + j < w; j++) {
+              int n3[3];
+              cm2_counts_w(&cw[ls][lx0 + j], &cw[ls + 1][lx0 + j], &cw[ls + 2][lx0 + j], n3);
+              for (int q = 0; q < 3; q++) off[q] += n3[q];
+            }
+          }
+          for (int th = 63; th >= 0; th--) {  // (any order of the lanes within the loop phase)
+            const int ls = th >> 2, lx0 = (th & 3) * 16;
+            if (ls >= nstr || lx0 >= w) continue;
+            for (int j = 0; j < 16 && lx0 + j < w; j++) {
+              Cm2Win win; Cm2Out3 O;
+              cm2_win_at(win, sp, &cw[0][0], 66, ls, lx0 + j);
+              cm2_emit3w(O, zcx, signlut, win);
+              cm2_seq_put8(sq[th][0], O.p0); cm2_seq_put4(sq[th][1], O.p1); cm2_seq_put4(sq[th][2], O.hdr); cm2_seq_put8(sq[th][2], O.p2);
+            }
+          }
+          for (int th = 0; th < 64; th++) for (int q = 0; q < 3; q++) cm2_seq_end(sq[th][q]);
+          for (int pass = 0; pass < 3; pass++)
+            if (off[pass] != (int)e3[pass].size() || memcmp(qb[pass].data(), e3[pass].data(), e3[pass].size())) return -16;
+        }
         // the sparse form: plain columns put their RUN byte, the others are listed with their stream offsets and worked off in any order
         {
           std::vector<uint32_t> sb[3];
