@@ -264,6 +264,9 @@ struct J2kState {
   T2Pool* pool = nullptr;
   DevBuf coefA, llA, llB, sbtab_d, planes_d, cbs_d, nbps_d, mags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
   DevBuf joboff_d, order_d, segs_d, cnt_d, dist_d;  // Tier-1: first job of each block, MQ slot table, decision segments
+  DevBuf tilemap_d;                                 // the DWT levels' workgroup lists (dwt_build_tilemap)
+  std::vector<uint32_t> tilemap; std::vector<int> tile_first; std::vector<int> tile_key;   // ... and the geometry they were built for
+  std::vector<uint8_t> up_tilemap; const void* up_tilemap_at = nullptr;
   DevBuf t1tabs_d;                                  // lookup tables of the context-modelling kernel (built at first use)
   DevBuf nbeff_d, njobs_d;                          // device job list: bit-planes as the Tier-1 kernels see them, total jobs
   size_t jobs_cap = 0;                              // jobs the segment / count (/ distortion) buffers were last sized for
@@ -308,7 +311,7 @@ void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->llA, &s->llB, &s->sbtab_d, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d, &s->nbeff_d, &s->njobs_d, &s->t1tabs_d};
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d, &s->nbeff_d, &s->njobs_d, &s->t1tabs_d, &s->tilemap_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   for (auto& e : s->copied) if (e) (void)hipEventDestroy(e);
@@ -531,8 +534,19 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     HIPCHK(c, hipMemsetAsync(S.nbps_d.p, 0, (size_t)ncb * 4, c->st));
     int minW = maxW, minH = maxH;
     for (const PlaneDesc& q : S.planes) { if (q.W < minW) minW = q.W; if (q.H < minH) minH = q.H; }
+    const uint32_t* tm = nullptr;
+    if (dwt_tilemap_fits(np, maxW, maxH)) {  // one workgroup per tile that exists (the planes of a batch differ in size)
+      std::vector<int> key;
+      key.reserve(2 * np + 1);
+      key.push_back(maxL);
+      for (const PlaneDesc& q : S.planes) { key.push_back(q.W); key.push_back(q.H); }
+      if (key != S.tile_key) { dwt_build_tilemap(S.planes.data(), np, maxL, S.tilemap, S.tile_first); S.tile_key.swap(key); }
+      if ((r = S.tilemap_d.ensure(c, S.tilemap.size() * 4 + 16))) return r;
+      if ((r = upload_if_changed(c, S.tilemap_d.p, S.tilemap.data(), S.tilemap.size() * 4, S.up_tilemap, S.up_tilemap_at))) return r;
+      tm = (const uint32_t*)S.tilemap_d.p;
+    }
     launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, minW, minH, (const DwtSb*)S.sbtab_d.p, maxL, rev, S.llA.p, S.llB.p,
-                     (unsigned long long*)S.mags.p, (int*)S.nbps_d.p, nullptr, ilog2i(cbw), ilog2i(cbh), (int*)S.err_d.p);
+                     (unsigned long long*)S.mags.p, (int*)S.nbps_d.p, nullptr, ilog2i(cbw), ilog2i(cbh), (int*)S.err_d.p, tm, S.tile_first.data());
     launch_t1_nbps(c->st, (const CbDesc*)S.cbs_d.p, ncb, (int*)S.nbps_d.p, (int*)S.err_d.p);
     pf.end(c);
   } else {  // Clevels = 0 (motion-field planes): level shift, then quantise + pack per code-block
@@ -941,7 +955,7 @@ int qsvc_j2k_dwt(qsvc_ctx* c, const uint8_t* plane, int H, int W, int reversible
   // the same tile kernel as the encoder's, with the subbands written to a Mallat-layout plane instead of the Tier-1 layout
   if (L == 0) launch_level_shift(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, S.coefA.p, reversible != 0);
   else launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, W, H, nullptr, L, reversible != 0, S.llA.p, S.llB.p, nullptr, nullptr,
-                        S.coefA.p, 6, 6, (int*)S.err_d.p);
+                        S.coefA.p, 6, 6, (int*)S.err_d.p, nullptr, nullptr);
   HIPCHK(c, hipMemcpyAsync(out, S.coefA.p, N * 4, hipMemcpyDeviceToHost, c->st));
   HIPCHK(c, hipStreamSynchronize(c->st));
   HIPCHK(c, hipGetLastError());

@@ -15,6 +15,7 @@
 // LDS bank conflicts.  A lifting step only writes samples of one parity and only reads samples of the other, so each step is
 // a plain parallel map over the tile with one barrier after it.  No MFMA: there is no contraction here.
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <type_traits>
 #include <stdlib.h>
 #include "j2k_kernels.h"
@@ -120,7 +121,14 @@ struct DwtArgs {
   void* plane_out;           // OUT_PLANE: the Mallat-layout plane of the unit-test entry point (int32 / float32)
   int cbwl, cbhl;            // log2 of the code-block size
   int* err;
+  const uint32_t* tilemap;   // this level's workgroups: plane << 20 | tile row << 10 | tile column (nullptr: the 3-D grid, planes of one size)
 };
+// (a batch's planes differ in size -- luma / chroma -- and an empty workgroup still costs its dispatch: with a common 3-D grid half of
+// config 3's level-1 workgroups were empty, about 10 of the launch's 62 us)
+__device__ __forceinline__ void dwt_tile_of(const DwtArgs& a, int& plane, int& tx, int& ty) {
+  if (a.tilemap) { const uint32_t t = a.tilemap[blockIdx.x]; plane = (int)(t >> 20); ty = (int)((t >> 10) & 1023u); tx = (int)(t & 1023u); }
+  else { plane = blockIdx.z; ty = blockIdx.y; tx = blockIdx.x; }
+}
 
 // LL stride of a plane's level-l low band (elements): a multiple of 4 so that rows stay 8 / 16-byte aligned
 __host__ __device__ __forceinline__ int dwt_ll_stride(int w) { return (w + 3) & ~3; }
@@ -134,12 +142,14 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
   __shared__ TT sTpad[(NR + 2) * DT_NCP];   // one padding row above and below the staged tile (interior sweeps read them)
   TT* const sT = sTpad + DT_NCP;
   const int tid = threadIdx.x;
-  const PlaneDesc pd = a.planes[blockIdx.z];
+  int plane_i, tile_x, tile_y;
+  dwt_tile_of(a, plane_i, tile_x, tile_y);
+  const PlaneDesc pd = a.planes[plane_i];
   int w = pd.W, h = pd.H;
   for (int l = 0; l < a.lev; l++) { w = (w + 1) >> 1; h = (h + 1) >> 1; }
   const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, hw = w >> 1, hh = h >> 1;
-  const int tx0 = blockIdx.x * DT_TW, ty0 = blockIdx.y * DT_TH;
-  if (tx0 >= lw || ty0 >= lh) return;                      // planes of one batch differ in size (luma / chroma)
+  const int tx0 = tile_x * DT_TW, ty0 = tile_y * DT_TH;
+  if (tx0 >= lw || ty0 >= lh) return;                      // (3-D grid: planes of one batch may differ in size)
   const int gc0 = 2 * tx0 - DT_CL, gr0 = 2 * ty0 - HALO;   // global coordinates of the staged tile's origin
 
   // ---- stage the tile: rows [gr0, gr0 + NR) x columns [gc0, gc0 + DT_NC), zero outside the signal -----------------------
@@ -290,7 +300,7 @@ __global__ void __launch_bounds__(256) k_dwt_tile(DwtArgs a) {
   }
   if (OUT_PLANE) return;
   // ---- HL, LH, HH (and the last LL): quantise, pack 4 rows of a stripe column, store into the block's Tier-1 layout ---------
-  const DwtSb* sbp = a.sbtab + (size_t)blockIdx.z * a.nsb;
+  const DwtSb* sbp = a.sbtab + (size_t)plane_i * a.nsb;
   const int lane = tid & 63, wv = tid >> 6;
   const int span = a.cbwl >= 6 ? 64 : (1 << a.cbwl);            // lanes of one code-block
   const bool tall = (1 << a.cbhl) >= DT_TH;                      // the tile's stripes of a subband lie in one block row
@@ -374,11 +384,13 @@ __global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
   __shared__ uint32_t sX[NR * DP_STR];   // staged input pairs
   __shared__ uint32_t sV[NR * DP_STR];   // after the vertical lifting
   const int tid = threadIdx.x;
-  const PlaneDesc pd = a.planes[blockIdx.z];
+  int plane_i, tile_x, tile_y;
+  dwt_tile_of(a, plane_i, tile_x, tile_y);
+  const PlaneDesc pd = a.planes[plane_i];
   int w = pd.W, h = pd.H;
   for (int l = 0; l < a.lev; l++) { w = (w + 1) >> 1; h = (h + 1) >> 1; }
   const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, hw = w >> 1, hh = h >> 1;
-  const int tx0 = blockIdx.x * DT_TW, ty0 = blockIdx.y * DT_TH;
+  const int tx0 = tile_x * DT_TW, ty0 = tile_y * DT_TH;
   if (tx0 >= lw || ty0 >= lh) return;
   const int gc0 = 2 * tx0 - DT_CL, gr0 = 2 * ty0 - HALO;
   // ---- stage: 4 samples per thread-load; the signal's ends mirrored ----------------------------------------------------------
@@ -480,7 +492,7 @@ __global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
         if (y + r < lh) *(uint32_t*)(lout + (size_t)(y + r) * ostr + x) = Lw[r];   // columns in [lw, ostr) are padding, never read back
   }
   // HL / LH / HH (and LL of the last level): sign-magnitude, 4 rows of a stripe column per u64, into the block's Tier-1 words
-  const DwtSb* sbp = a.sbtab + (size_t)blockIdx.z * a.nsb;
+  const DwtSb* sbp = a.sbtab + (size_t)plane_i * a.nsb;
   const int lane = tid & 63;
   const int span2 = a.cbwl >= 6 ? 32 : (1 << (a.cbwl - 1));   // lanes (of 2 columns) per code-block
 #pragma unroll
@@ -518,9 +530,27 @@ __global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
 }
 
 // Forward DWT of a batch of planes sharing L >= 1 levels.  mode 0: Tier-1 magnitudes; mode 1: Mallat plane (unit tests).
+// Workgroup list of every level of a batch (dwt_tile_of): host side.  first[l] .. first[l + 1] = level l's entries.
+void dwt_build_tilemap(const PlaneDesc* planes, int nplanes, int L, std::vector<uint32_t>& map, std::vector<int>& first) {
+  map.clear(); first.assign(L + 1, 0);
+  for (int l = 0; l < L; l++) {
+    first[l] = (int)map.size();
+    for (int p = 0; p < nplanes; p++) {
+      int w = planes[p].W, h = planes[p].H;
+      for (int k = 0; k < l; k++) { w = (w + 1) >> 1; h = (h + 1) >> 1; }
+      const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, gx = (lw + DT_TW - 1) / DT_TW, gy = (lh + DT_TH - 1) / DT_TH;
+      for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) map.push_back((uint32_t)p << 20 | (uint32_t)ty << 10 | (uint32_t)tx);
+    }
+  }
+  first[L] = (int)map.size();
+}
+bool dwt_tilemap_fits(int nplanes, int maxW, int maxH) { return nplanes < 4096 && (maxW + 1) / 2 <= 1024 * DT_TW && (maxH + 1) / 2 <= 1024 * DT_TH; }
+
+// d_tilemap / first (dwt_build_tilemap; nullptr: a 3-D grid over the largest plane)
 void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, int minW0, int minH0, const DwtSb* d_sbtab, int L,
                       bool reversible, void* llA, void* llB, unsigned long long* mags, int* maxmag, void* plane_out,
-                      int cbw_log2, int cbh_log2, int* err) {
+                      int cbw_log2, int cbh_log2, int* err, const uint32_t* d_tilemap, const int* first) {
   int w = maxW, h = maxH, minW = minW0, minH = minH0;   // the largest and the smallest plane of the batch at this level
   for (int l = 0; l < L; l++) {
     const int lw = (w + 1) >> 1, lh = (h + 1) >> 1;
@@ -529,7 +559,9 @@ void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, in
     a.llin = (l & 1) ? llA : llB;    // LL_l lives in A for odd l, in B for even l >= 2
     a.llout = (l & 1) ? llB : llA;   // LL_{l+1}
     a.mags = mags; a.maxmag = maxmag; a.plane_out = plane_out; a.cbwl = cbw_log2; a.cbhl = cbh_log2; a.err = err;
+    a.tilemap = d_tilemap ? d_tilemap + first[l] : nullptr;
     dim3 grid((lw + DT_TW - 1) / DT_TW, (lh + DT_TH - 1) / DT_TH, nplanes), block(256);
+    if (d_tilemap) grid = dim3(first[l + 1] - first[l], 1, 1);
 #define DWT_LAUNCH(REV, U8, PL) hipLaunchKernelGGL((k_dwt_tile<REV, U8, PL>), grid, block, 0, st, a)
     if (plane_out) {
       if (reversible) { if (l == 0) DWT_LAUNCH(true, true, true); else DWT_LAUNCH(true, false, true); }

@@ -1,5 +1,6 @@
 // qsvc_amd/csrc/j2k_kernels.h -- device-side structures and launch wrappers of j2k_kernels.hip
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "t1_core.h"
@@ -41,7 +42,10 @@ struct DwtSb {       // one subband of one plane as the DWT kernel addresses its
 // forward DWT, L >= 1 levels (j2k_dwt.hip); plane_out != nullptr selects the Mallat-plane form of the unit-test entry point
 void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, int minW, int minH, const DwtSb* d_sbtab, int L,
                       bool reversible, void* llA, void* llB, unsigned long long* mags, int* maxmag, void* plane_out,
-                      int cbw_log2, int cbh_log2, int* err);
+                      int cbw_log2, int cbh_log2, int* err, const uint32_t* d_tilemap, const int* first);
+// the levels' workgroup lists of a batch whose planes differ in size (no empty workgroups): map[first[l] .. first[l + 1]) = level l
+void dwt_build_tilemap(const PlaneDesc* planes, int nplanes, int L, std::vector<uint32_t>& map, std::vector<int>& first);
+bool dwt_tilemap_fits(int nplanes, int maxW, int maxH);
 // planes without a decomposition level: level shift into a 32-bit plane, then launch_t1_pack_blk
 void launch_level_shift(hipStream_t st, const PlaneDesc* d_planes, int nplanes, int maxW, int maxH, void* A, bool reversible);
 void launch_t1_nbps(hipStream_t st, const CbDesc* cbs, int ncb, int* nbps, int* err);

@@ -28,18 +28,21 @@ __global__ void __launch_bounds__(256) k_pyr_level(const T* src, size_t src_pic_
 // evicts the tile loop from the instruction cache when both run on one CU.)
 template <class T>
 __global__ void __launch_bounds__(256) k_pyr_margin(const T* src, size_t src_pic_stride, int src_row_stride, int16_t* dst, size_t dst_pic_stride, int H, int W,
-                                                     int l, int R, int C, int Rf, int Cf, int gyR) {
-  const bool rows = (int)blockIdx.y < gyR;
-  const int x = (rows ? 0 : C) + blockIdx.x * 64 + threadIdx.x;
-  const int y = rows ? R + blockIdx.y * 4 + threadIdx.y : (blockIdx.y - gyR) * 4 + threadIdx.y;
+                                                     int l, int R, int C, int Rf, int Cf, int gxR, int nR, int gxC) {
+  // (one linear block index over both roles: an empty workgroup still costs its dispatch, a common 2-D grid would launch 16 x as many)
+  const int b = blockIdx.x;
+  const bool rows = b < nR;
+  const int q = rows ? b : b - nR, gx = rows ? gxR : gxC, by = q / gx, bx = q - by * gx;
+  const int x = (rows ? 0 : C) + bx * 64 + threadIdx.x;
+  const int y = (rows ? R : 0) + by * 4 + threadIdx.y;
   pyr_thread<T>(src, src_pic_stride, src_row_stride, dst, dst_pic_stride, H, W, l, rows ? Rf : R, Cf, x, y, blockIdx.z);
 }
 template <class T>
 static void launch_pyr_margin(hipStream_t st, const T* src, size_t src_pic_stride, int16_t* dst, int W, int H, int P, int l, int R, int C, int Rf, int Cf) {
-  const int gyR = Rf > R ? (Rf - R + 3) / 4 : 0, gyC = Cf > C ? (R + 3) / 4 : 0;
-  if (gyR + gyC == 0) return;
-  const int gx = gyR ? (Cf + 63) / 64 : (Cf - C + 63) / 64;
-  hipLaunchKernelGGL(k_pyr_margin<T>, dim3(gx, gyR + gyC, P), dim3(64, 4), 0, st, src, src_pic_stride, W, dst, (size_t)H * W, H, W, l, R, C, Rf, Cf, gyR);
+  const int gyR = Rf > R ? (Rf - R + 3) / 4 : 0, gxR = (Cf + 63) / 64, gyC = Cf > C ? (R + 3) / 4 : 0, gxC = Cf > C ? (Cf - C + 63) / 64 : 1;
+  const int nR = gyR * gxR, nC = gyC * gxC;
+  if (nR + nC == 0) return;
+  hipLaunchKernelGGL(k_pyr_margin<T>, dim3(nR + nC, 1, P), dim3(64, 4), 0, st, src, src_pic_stride, W, dst, (size_t)H * W, H, W, l, R, C, Rf, Cf, gxR, nR, gxC);
 }
 void launch_pyr_level_u8(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int P, int R, int C) {
   dim3 block(64, 4);
