@@ -825,10 +825,11 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
 
 
 // Bounds the Tier-1 working set.  The decision slots are sized for the worst case (22.5 KB per code-block and bit-plane, up to
-// 15 planes): a long or large sequence is coded in consecutive groups of planes whose slots fit QSVC_T1_BUDGET_GB (default 32).
+// 15 planes): a long or large sequence is coded in consecutive groups of planes whose slots fit QSVC_T1_BUDGET_GB (default 48: the 33 pictures of a 4K GOP window stay one group -- every further
+// group costs a whole MQ chain of its own and the host's Tier-2 between the groups -- and four such contexts fit 288 GB in the worst case).
 // The code-streams do not depend on the grouping (planes are independent).
 static int j2k_encode_planes(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8_t* out, size_t cap, size_t* offs) {
-  static const double budget_gb = [] { const char* e = getenv("QSVC_T1_BUDGET_GB"); double v = e ? atof(e) : 32.0; return v > 0.001 ? v : 0.001; }();
+  static const double budget_gb = [] { const char* e = getenv("QSVC_T1_BUDGET_GB"); double v = e ? atof(e) : 48.0; return v > 0.001 ? v : 0.001; }();
   const size_t max_blocks = (size_t)(budget_gb * 1e9 / (15.0 * T1_SEG_BYTES));
   if (!c->j2k) c->j2k = new J2kState();
   c->j2k->st_cb = 0; c->j2k->st_pass = 0; c->j2k->st_sym = 0;
