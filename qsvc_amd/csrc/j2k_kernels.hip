@@ -56,50 +56,67 @@ void launch_t1_nbps(hipStream_t st, const CbDesc* cbs, int ncb, int* nbps, int* 
 // gets bit 4; the host re-runs the stage with its own job list and larger buffers.
 __global__ void __launch_bounds__(1024) k_t1_joblist(const CbDesc* cbs, int ncb, const int* nbps, int cap_jobs, int* nb_eff, int* joboff,
                                                       int* order, int nslots, int* njobs_out, int* err) {
-  constexpr int STAGE = 16384;      // blocks whose (bit-planes, area) pairs are staged in LDS with coalesced loads (a 1080p GOP: 15 657)
+  // The blocks go through LDS in chunks of STAGE (a 1080p GOP: 15 657 blocks, one chunk; a 4K GOP window: seven): coalesced loads
+  // of the (bit-planes, area) pairs, then thread t owns 16 consecutive blocks of the chunk -- what the running sum of joboff needs.
+  constexpr int STAGE = 16384, PER = STAGE / 1024;
   __shared__ int s_scan[1024];
   __shared__ int s_hist[1024];      // 15 * 64 + 2 = 962 in use
   __shared__ uint16_t s_blk[STAGE]; // nb | area64 << 4
-  const int tid = threadIdx.x, per = (ncb + 1023) / 1024, b0 = tid * per, b1 = b0 + per < ncb ? b0 + per : ncb;
-  const bool staged = ncb <= STAGE;
-  if (staged)
-    for (int b = tid; b < ncb; b += 1024) {
-      const int nb = nbps[b] > 15 ? 15 : nbps[b];
-      s_blk[b] = (uint16_t)(nb | ((((int)cbs[b].w * cbs[b].h + 63) >> 6) << 4));
+  const int tid = threadIdx.x;
+  auto stage = [&](int c0, int n) {
+    for (int b = tid; b < n; b += 1024) {
+      const int nb = nbps[c0 + b] > 15 ? 15 : nbps[c0 + b];
+      s_blk[b] = (uint16_t)(nb | ((((int)cbs[c0 + b].w * cbs[c0 + b].h + 63) >> 6) << 4));
     }
+  };
+  auto scan1024 = [&](int* a) {  // inclusive, in place
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int v = tid >= o ? a[tid - o] : 0;
+      __syncthreads();
+      a[tid] += v;
+      __syncthreads();
+    }
+  };
+  // the jobs of the whole batch (decides whether the buffers hold them)
+  int sum = 0;
+  for (int b = tid; b < ncb; b += 1024) sum += nbps[b] > 15 ? 15 : nbps[b];
+  s_scan[tid] = sum;
   s_hist[tid] = 0;
   __syncthreads();
-  auto nb_of = [&](int b) { return staged ? (int)(s_blk[b] & 15) : (nbps[b] > 15 ? 15 : nbps[b]); };
-  auto area_of = [&](int b) { return staged ? (int)(s_blk[b] >> 4) : (((int)cbs[b].w * cbs[b].h + 63) >> 6); };
-  int sum = 0;
-  for (int b = b0; b < b1; b++) sum += nb_of(b);
-  s_scan[tid] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan
-    const int v = tid >= o ? s_scan[tid - o] : 0;
-    __syncthreads();
-    s_scan[tid] += v;
-    __syncthreads();
-  }
+  scan1024(s_scan);
   const int total = s_scan[1023];
   const bool over = total > cap_jobs;
   if (tid == 0) { *njobs_out = total; if (over) atomicOr(err, 4); }
-  int run = s_scan[tid] - sum;
-  for (int b = b0; b < b1; b++) {
-    const int nb = nb_of(b), ne = over ? 0 : nb;
-    nb_eff[b] = ne;
-    joboff[b] = over ? 0 : run;
-    run += nb;
-    atomicAdd(&s_hist[15 * 64 - ne * area_of(b) + 1], 1);
-  }
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan over the counts at [key + 1]: s_hist[k] = first slot of key k
-    const int v = tid >= o ? s_hist[tid - o] : 0;
+  // first job of every block + the histogram of the sort keys
+  int carry = 0;
+  for (int c0 = 0; c0 < ncb; c0 += STAGE) {
+    const int n = ncb - c0 < STAGE ? ncb - c0 : STAGE;
+    stage(c0, n);
     __syncthreads();
-    s_hist[tid] += v;
+    const int b0 = tid * PER < n ? tid * PER : n, b1 = b0 + PER < n ? b0 + PER : n;
+    int mine = 0;
+    for (int b = b0; b < b1; b++) mine += s_blk[b] & 15;
+    s_scan[tid] = mine;
+    __syncthreads();
+    scan1024(s_scan);
+    int run = carry + s_scan[tid] - mine;
+    for (int b = b0; b < b1; b++) {
+      const int nb = s_blk[b] & 15, ne = over ? 0 : nb;
+      nb_eff[c0 + b] = ne;
+      joboff[c0 + b] = over ? 0 : run;
+      run += nb;
+      atomicAdd(&s_hist[15 * 64 - ne * (s_blk[b] >> 4) + 1], 1);
+    }
+    carry += s_scan[1023];
     __syncthreads();
   }
-  for (int b = b0; b < b1; b++) order[atomicAdd(&s_hist[15 * 64 - (over ? 0 : nb_of(b)) * area_of(b)], 1)] = b;
+  scan1024(s_hist);   // over the counts at [key + 1]: s_hist[k] = first slot of key k
+  for (int c0 = 0; c0 < ncb; c0 += STAGE) {
+    const int n = ncb - c0 < STAGE ? ncb - c0 : STAGE;
+    if (ncb > STAGE) { __syncthreads(); stage(c0, n); __syncthreads(); }   // (a single chunk is still there)
+    for (int b = tid; b < n; b += 1024) order[atomicAdd(&s_hist[15 * 64 - (over ? 0 : (s_blk[b] & 15)) * (s_blk[b] >> 4)], 1)] = c0 + b;
+  }
   for (int k = ncb + tid; k < nslots; k += 1024) order[k] = ncb;
 }
 void launch_t1_joblist(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, int cap_jobs, int* nb_eff, int* joboff, int* order, int nslots,
