@@ -551,7 +551,7 @@ def main():
         streaming = None
         if iso:
             groups = {
-                dwt_key: ["k_dwt_tile", "k_t1_nbps"],
+                dwt_key: ["k_dwt_tile", "k_dwt53_pk", "k_t1_nbps"],
                 "predict": ["k_pred_", "k_mv_hist", "k_chroma_up"],
                 "update": ["k_upd_"],
                 "me_search_l0": ["k_me_piece<unsigned char", "k_me_search8<unsigned char", "k_me_search<unsigned char"],
