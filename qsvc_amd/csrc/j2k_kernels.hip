@@ -540,17 +540,20 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
   // (lane = y, bit x) where the membership recurrence runs; a bit-matrix transpose across the wave (cm2_transpose64) takes the
   // plane's bits to the row layout and the membership back.  Both are carried from plane to plane:
   // sig0(p) = sig0(p+1) | bit(p+1), mu(p) = sig0(p+1).
-  uint32_t mlo[16], mhi[16];
-  uint64_t NEGc = 0;   // sign bits (lane = column)
+  // ... as bit-planes: P[p] = bit p of the column's 64 samples (cm2_bitplanes: four 16 x 16 bit transposes per block instead of a
+  // sample-by-sample extraction per plane); P[15] is the column's sign mask
+  uint64_t P[16];
+  {
+    uint32_t m32[32];
 #pragma unroll
-  for (int s = 0; s < 16; s++) {
-    unsigned long long m = 0;
-    if (s < nstr && lane < w) m = mg[s * 64 + lane];
-    mlo[s] = (uint32_t)m; mhi[s] = (uint32_t)(m >> 32);
-    const uint32_t tl = (mlo[s] >> 15) & 0x00010001u, th = (mhi[s] >> 15) & 0x00010001u;
-    const uint32_t neg4 = ((tl | tl >> 15) & 3) | (((th | th >> 15) & 3) << 2);
-    NEGc |= (uint64_t)neg4 << (4 * s);
+    for (int s = 0; s < 16; s++) {
+      unsigned long long m = 0;
+      if (s < nstr && lane < w) m = mg[s * 64 + lane];
+      m32[2 * s] = (uint32_t)m; m32[2 * s + 1] = (uint32_t)(m >> 32);
+    }
+    cm2_bitplanes(m32, P);
   }
+  const uint64_t NEGc = P[15];
   const uint64_t VALc = lane < w ? (h == 64 ? ~0ull : ((1ull << h) - 1)) : 0ull;   // samples of the block in this column
   uint64_t Zc = 0, Bc = 0;   // by column: significant before the plane; the plane's bits (of the plane above on entry)
   uint64_t Zr = 0, Br = 0;   // the same by row
@@ -561,16 +564,7 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
   const uint64_t MUc = Zc;   // significant before the plane above: "refined before" of the refinement pass
   Zc |= Bc;
   Zr |= Br;
-  {
-    uint32_t blo = 0, bhi = 0;
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-      const uint32_t tl = (mlo[s] >> p) & 0x00010001u, th = (mhi[s] >> p) & 0x00010001u;
-      const uint32_t bit4 = ((tl | tl >> 15) & 3) | (((th | th >> 15) & 3) << 2);
-      if (s < 8) blo |= bit4 << (4 * s); else bhi |= bit4 << (4 * s - 32);
-    }
-    Bc = (uint64_t)blo | (uint64_t)bhi << 32;
-  }
+  Bc = P[p];   // (p is uniform: an indexed register read)
   Br = cm2_transpose64(Bc, lane);
   // membership: fixpoint of cm2_row_update over the 64 rows (t1_cm2.h)
   uint64_t Mc;

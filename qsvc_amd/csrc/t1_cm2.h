@@ -597,6 +597,30 @@ T1HD void cm2_pack_pk(const Cm2Counts& c, uint32_t out[8]) {
   }
 }
 
+// The bit-planes of one column's 64 samples at once: m[2 s], m[2 s + 1] = the four 16-bit words (sign << 15 | magnitude) of stripe
+// s's rows 0, 1 | 2, 3 as the Tier-1 layout packs them; P[p] = bit p of every sample (bit y = row y), so P[15] is the column's sign
+// mask.  Four 16 x 16 bit-matrix transposes on halfword pairs (the classic masked block swaps, two rows per register) instead of
+// extracting one plane's bits sample by sample for every plane: ~500 operations per block against ~190 per bit-plane.
+T1HD void cm2_bitplanes(const uint32_t m[32], uint64_t P[16]) {
+  uint32_t R[4][8];
+  for (int g = 0; g < 4; g++) {
+    uint32_t* r = R[g];
+    for (int i = 0; i < 8; i++) {
+      uint32_t x = m[8 * g + i];
+      const uint32_t t = ((x >> 15) ^ x) & 0x0000AAAAu;   // rows 2 i / 2 i + 1 are the halves of one word: swap across the halves
+      x ^= t; x ^= t << 15;
+      r[i] = x;
+    }
+    for (int i = 0; i < 8; i += 2) { const uint32_t t = ((r[i] >> 2) ^ r[i + 1]) & 0x33333333u; r[i + 1] ^= t; r[i] ^= t << 2; }
+    for (int i = 0; i < 8; i++) if (!(i & 2)) { const uint32_t t = ((r[i] >> 4) ^ r[i + 2]) & 0x0F0F0F0Fu; r[i + 2] ^= t; r[i] ^= t << 4; }
+    for (int i = 0; i < 4; i++) { const uint32_t t = ((r[i] >> 8) ^ r[i + 4]) & 0x00FF00FFu; r[i + 4] ^= t; r[i] ^= t << 8; }
+  }
+  for (int p = 0; p < 16; p++) {   // plane p of group g: halfword p & 1 of R[g][p >> 1]
+    const uint32_t sel = (p & 1) ? 0x07060302u : 0x05040100u;
+    P[p] = (uint64_t)cm2_perm(R[1][p >> 1], R[0][p >> 1], sel) | (uint64_t)cm2_perm(R[3][p >> 1], R[2][p >> 1], sel) << 32;
+  }
+}
+
 // The column words of eight stripes (8 h .. 8 h + 7) of one column from the 32-bit halves of its eight field masks, in the order of
 // the fields in the word (SIG0, BIT, NEG, MU, VAL, M, S1, S2; nibble s of a half = stripe 8 h + s): an 8 x 8 nibble transpose --
 // pairs of fields to bytes, then byte permutes -- instead of eight extractions and inserts per stripe.

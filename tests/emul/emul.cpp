@@ -302,6 +302,20 @@ extern "C" int emul_t1_block_cm2(const int32_t* vals, int w, int h, int orient, 
   std::vector<uint8_t> segs((size_t)(nb ? nb : 1) * T1_SEG_BYTES);
   std::vector<int> cnt((size_t)(nb ? nb : 1) * 3, 0);
   std::vector<long long> dist((size_t)(nb ? nb : 1) * 3, 0);
+  {  // the bit-planes of every column at once (cm2_bitplanes) against the samples
+    for (int x = 0; x < 64; x++) {
+      uint32_t m32[32]; uint64_t P[16];
+      for (int s = 0; s < 16; s++) {
+        const uint64_t m = (s < nstr && x < w) ? mags[s * 64 + x] : 0;
+        m32[2 * s] = (uint32_t)m; m32[2 * s + 1] = (uint32_t)(m >> 32);
+      }
+      cm2_bitplanes(m32, P);
+      for (int y = 0; y < 64; y++) {
+        const uint32_t v = (uint32_t)(((y >> 2) < nstr && x < w ? mags[(y >> 2) * 64 + x] : 0) >> (16 * (y & 3))) & 0xFFFF;
+        for (int q = 0; q < 16; q++) if (((P[q] >> y) & 1) != ((v >> q) & 1)) return -17;
+      }
+    }
+  }
   for (int p = 0; p < nb; p++) {
     uint32_t cw[18][66];  // one-cell apron of zeros
     memset(cw, 0, sizeof cw);
