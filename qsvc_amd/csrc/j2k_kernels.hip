@@ -702,6 +702,7 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
     }
   } else if (base2 + tot3[2] <= CM2_OUT_BYTES) {
     // (the lane's dummy word for stores that are not due yet: the packed counts are dead from here to the next plane)
+    const bool chk_plain = nact <= 768;
     uint32_t* const trash = &s_pk[0][0] + lane;
     Cm2Seq T0, T1, T2;
     cm2_seq_begin(T0, s_out, off3[0], trash);
@@ -721,8 +722,9 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
         // In the upper bit-planes most columns are a run of four zeros without a significant neighbour: one RUN decision.  When
         // that holds for the column in work of EVERY lane, the wave skips the general form.
         const bool col_on = lx0 + j < w;
-        const bool plain = !col_on || cm2_plain_run(c);
-        if (!__any(!plain)) {
+        // (with three quarters of the columns listed as not plain the test would never hold for all 64 lanes: not made)
+        const bool plain = chk_plain && (!col_on || cm2_plain_run(c));
+        if (chk_plain && !__any(!plain)) {
           if (col_on) { Cm2Bytes run1; run1.a = T1_CTX_RUN; run1.n = 1; cm2_seq_put4(T2, run1); }
         } else if (col_on) {
           Cm2Out3 O;
