@@ -729,7 +729,9 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
         } else if (col_on) {
           Cm2Out3 O;
           cm2_emit3s(O, s_zc, s_sign, s_cmp8, c);
-          cm2_seq_put8(T0, O.p0); cm2_seq_put4(T1, O.p1); cm2_seq_put4(T2, O.hdr); cm2_seq_put8(T2, O.p2);
+          cm2_seq_put8(T0, O.p0); cm2_seq_put4(T1, O.p1);
+          if (__any(O.hdr.n != 0)) cm2_seq_put4(T2, O.hdr);
+          cm2_seq_put8(T2, O.p2);
           if (want_dist) cm2_dist3(cx, own, mg[lane * 16 + j], d3);
         }
         own = nm;

@@ -472,14 +472,20 @@ T1HD void cm2_emit3s(Cm2Out3& O, const uint8_t* zcx, const uint8_t* signlut, con
   const uint32_t f2 = fref | c.DL[0] | c.DB[1] << 1 | c.DB[2] << 2;
   const uint32_t fchi = c.X[0] | c.X[1] << 1 | c.X[2] << 2;
   const uint32_t G1 = (c.B1 & 0x1248) << 1, G2 = (c.D1 & 0x1248) << 1;
+  // run-length mode (four insignificant rows without a significant neighbour): rare in the planes that cost the time, so its
+  // header and row masks are only worked out when some lane of the wave has such a column
   const uint32_t rl = (val4 == 0xF && f2 == 0 && M4 == 0) ? ~0u : 0u;
-  const uint32_t lowest = bit4 & (0u - bit4);
-  const uint32_t skipA4 = rl & (2 * lowest - 1) & 0xF, skipB4 = rl & (lowest - 1) & 0xF;
-  const uint32_t fk = (lowest >> 1) - (lowest >> 3);
-  const uint32_t hdr3 = (uint32_t)(T1_CTX_RUN | 32) | (uint32_t)(T1_CTX_UNI | ((fk >> 1) << 5)) << 8 | (uint32_t)(T1_CTX_UNI | ((fk & 1) << 5)) << 16;
-  O.hdr.a = rl & (bit4 ? hdr3 : (uint32_t)T1_CTX_RUN);
-  O.hdr.n = (int)(rl & (bit4 ? 3u : 1u));
-  const uint32_t EA2 = C4 & ~skipA4, EB2 = S24 & ~skipB4;
+  uint32_t EA2 = C4, EB2 = S24;
+  O.hdr.a = 0; O.hdr.n = 0;
+  if (t1_any_lane(rl != 0)) {
+    const uint32_t lowest = bit4 & (0u - bit4);
+    const uint32_t skipA4 = rl & (2 * lowest - 1) & 0xF, skipB4 = rl & (lowest - 1) & 0xF;
+    const uint32_t fk = (lowest >> 1) - (lowest >> 3);
+    const uint32_t hdr3 = (uint32_t)(T1_CTX_RUN | 32) | (uint32_t)(T1_CTX_UNI | ((fk >> 1) << 5)) << 8 | (uint32_t)(T1_CTX_UNI | ((fk & 1) << 5)) << 16;
+    O.hdr.a = rl & (bit4 ? hdr3 : (uint32_t)T1_CTX_RUN);
+    O.hdr.n = (int)(rl & (bit4 ? 3u : 1u));
+    EA2 = C4 & ~skipA4; EB2 = S24 & ~skipB4;
+  }
   uint32_t A4 = 0, B4 = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
