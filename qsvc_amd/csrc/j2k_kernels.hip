@@ -791,7 +791,15 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t* outbuf, int outca
   if (b >= ncb) return;
   const uint8_t* s = outbuf + (size_t)b * outcap + 1;
   uint8_t* d = dst + offs[b];
-  for (int i = threadIdx.x; i < lens[b]; i += 256) d[i] = s[i];
+  const int n = lens[b];
+  // bytes up to the destination's first 16-byte boundary, then 16 bytes per thread and step (aligned stores, unaligned loads: the
+  // source starts one byte into its slot), then the tail
+  const int head = (int)((16 - ((uintptr_t)d & 15)) & 15), h = head < n ? head : n, nv = (n - h) >> 4;
+  if ((int)threadIdx.x < h) d[threadIdx.x] = s[threadIdx.x];
+  typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u4u;
+  for (int i = threadIdx.x; i < nv; i += 256) *(uint4*)(d + h + 16 * i) = __builtin_bit_cast(uint4, *(const u4u*)(s + h + 16 * i));
+  const int t0 = h + 16 * nv;
+  if (t0 + (int)threadIdx.x < n) d[t0 + threadIdx.x] = s[t0 + threadIdx.x];
 }
 void launch_gather(hipStream_t st, const uint8_t* outbuf, int outcap, const unsigned long long* offs, const int* lens, int ncb,
                    uint8_t* dst) {
