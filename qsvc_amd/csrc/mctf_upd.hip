@@ -28,8 +28,31 @@ struct UpdSrc {
   int BX, lbs, nby, nbx;  // field stride, log2(block size), blocks that can carry a residue
 };
 __device__ __forceinline__ uint64_t run_mask(int lo, int hi) { return (~0ull << (8 * lo)) & (~0ull >> (64 - 8 * hi)); }
+// The reference's default update factor 0.25 without floating point: v + 0.25 r is exact in float (two fraction bits), the clamp
+// and the truncating conversion of update.cpp:93-115 make it min(max(4 v + r, 0) >> 2, 255) -- on packed 16-bit lanes, four
+// instead of eleven instructions per sample.
+__device__ __forceinline__ uint64_t upd_apply8_quarter(uint64_t v, uint64_t r) {
+  uint32_t out[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const uint32_t vw = (uint32_t)(v >> (32 * h)), uw = (uint32_t)(r >> (32 * h)) ^ 0x80808080u;   // residue + 128, unsigned bytes
+    uint32_t t[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint32_t sel = q ? 0x0c030c02u : 0x0c010c00u;   // bytes 2 q, 2 q + 1 -> the two 16-bit lanes
+      const s16x2 V = S2(__builtin_amdgcn_perm(0u, vw, sel)), R = S2(pk_sub(__builtin_amdgcn_perm(0u, uw, sel), 0x00800080u));
+      const s16x2 z = {0, 0}, m = {255, 255}, four = {4, 4};
+      s16x2 T = V * four + R;
+      T = __builtin_elementwise_max(T, z) >> 2;
+      t[q] = U(__builtin_elementwise_min(T, m));
+    }
+    out[h] = __builtin_amdgcn_perm(t[1], t[0], 0x06040200u);
+  }
+  return (uint64_t)out[0] | (uint64_t)out[1] << 32;
+}
 // the 8 targets' values after one source run (signed residue bytes, 0 = no source)
 __device__ __forceinline__ uint64_t upd_apply8(uint64_t v, uint64_t r, float uf) {
+  if (uf == 0.25f) return upd_apply8_quarter(v, r);   // (uniform)
   uint64_t o = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
