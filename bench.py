@@ -7,7 +7,7 @@ HBM roofline and the CPU path timed beside it.
 Workload (BASELINE.json configs[2]): 1920x1080 4:2:0, one 16-picture GOP pair =
 17 pictures per GPU, TRLs=4 (3 MCTF levels: ME + predict + update, block 8, search range 4->8->16), then the
 JPEG 2000 stage (reversible 5/3, Clevels=4, 64x64 code-blocks, EBCOT Tier-1, Tier-2 with SOP) for every
-temporal subband picture.  `--sessions S` (default 12, with GPU_MAX_HW_QUEUES=12 so that every session's stream has its own hardware queue; measured: 6 -> 3237, 8 -> 3700, 12 -> 4112, 16 -> 4035 fps) such sequences are encoded concurrently per GPU, one encoder context
+temporal subband picture.  `--sessions S` (default 12, with GPU_MAX_HW_QUEUES=12 so that every session's stream has its own hardware queue; round 2: 6 -> 3237, 8 -> 3700, 12 -> 4112, 16 -> 4035 fps; end of round 3, 20-step runs: 10 to 16 sessions within a few per cent of each other around 8 300) such sequences are encoded concurrently per GPU, one encoder context
 and host thread each: EBCOT Tier-1 is a long serial chain per code-block that leaves most of the chip idle, and
 independent sequences fill it.  One step = every session finishing one whole encode, from pictures
 resident in HBM to code-streams in host memory.  Synthetic input (seeded pan + noise), no reference numbers exist
@@ -145,8 +145,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the non-headline decode extra")
     ap.add_argument("--no-iso", action="store_true", help="skip the single-sequence pass (profiling runs: exactly warmup + steps encodes per session)")
