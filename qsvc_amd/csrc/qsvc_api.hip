@@ -79,7 +79,7 @@ static void free_seq(qsvc_ctx* c) {
   for (auto& l : c->lv) {
     l.low.release(); l.high.release(); l.pred.release(); l.mv_raw.release(); l.mv_filt.release(); l.hist.release();
     l.low_n = l.high_n = l.pred_n = 0; l.mv_raw_n = l.mv_filt_n = 0; l.mv_bs = 0; l.types.clear();
-    l.types_d.release(); l.types_pin.release(); l.types_d_ok = false; l.mv_bound = -1;
+    l.types_d.release(); l.types_pin.release(); l.types_d_ok = false; l.types_allB = false; l.mv_bound = -1;
     l.halo[0] = l.halo[1] = nullptr;
     l.pending = false; l.hhist.release();
   }
@@ -114,7 +114,7 @@ void qsvc_destroy(qsvc_ctx* c) {
   for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); }
   c->margin.release(); c->cup.release(); c->ovl[0].release(); c->ovl[1].release();
   if (c->comm) qsvc_comm_destroy(c);
-  c->scal.release(); c->tmp16[0].release(); c->tmp16[1].release(); c->hhist.release();
+  c->scal.release(); c->allB.release(); c->tmp16[0].release(); c->tmp16[1].release(); c->hhist.release();
   j2k_release(c);
   j2k_decode_release(c);
   for (auto& s : c->segs) for (auto& p : s.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -218,7 +218,7 @@ int qsvc_put_frame_types(qsvc_ctx* c, int t, int nB, const char* types) {
   if (!c || !types || t < 1 || t > QSVC_MAX_T || nB < 0) return QSVC_ERR_INVALID;
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   c->lv[t].types.assign(types, types + nB);
-  c->lv[t].types_d_ok = false;
+  c->lv[t].types_d_ok = false; c->lv[t].types_allB = false;
   return QSVC_OK;
 }
 int qsvc_get_frame_types(qsvc_ctx* c, int t, int b_pictures, char* types) {
@@ -393,7 +393,7 @@ static int apply_I_pictures(qsvc_ctx* c, int t) {
   return QSVC_OK;
 }
 static int types_to_device_pinned(qsvc_ctx* c, Level& lv, int nB) {
-  lv.types_d_ok = false;
+  lv.types_d_ok = false; lv.types_allB = false;
   if (!nB) return QSVC_OK;
   if (!lv.types_pin.ensure((size_t)nB)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%d)", nB);
   int r = lv.types_d.ensure(c, (size_t)nB + 16);
@@ -520,8 +520,16 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
     }
   }
   // frame_types_t on the device for `update` (page-locked source: nothing the caller can touch is read after this call returns)
-  lv.types_d_ok = false;
-  if (g.nB) {
+  lv.types_d_ok = false; lv.types_allB = false;
+  bool allB = g.nB > 0 && g.nB <= QSVC_ALLB_MAX;
+  for (int i = 0; i < g.nB && allB; i++) allB = lv.types[i] == 'B';
+  if (allB) {  // (the usual case, and what a deferred decision assumes: no copy between predict and update)
+    if (!c->allB.p) {
+      if ((r = c->allB.ensure(c, QSVC_ALLB_MAX + 16))) return r;
+      HIPCHK(c, hipMemsetAsync(c->allB.p, 'B', QSVC_ALLB_MAX + 16, c->st));
+    }
+    lv.types_d_ok = true; lv.types_allB = true;
+  } else if (g.nB) {
     if (!lv.types_pin.ensure((size_t)g.nB)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%d)", g.nB);
     if ((r = lv.types_d.ensure(c, (size_t)g.nB + 16))) return r;
     memcpy(lv.types_pin.p, lv.types.data(), (size_t)g.nB);
@@ -558,7 +566,7 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   const bool resident = lv.mv_bound >= 0 && lv.types_d_ok && !have_halo;
   int reach = resident ? lv.mv_bound : 0;
   uint8_t halo_types[2][16] = {{0}, {0}};
-  const uint8_t* types_dev = (const uint8_t*)lv.types_d.p;
+  const uint8_t* types_dev = lv.types_allB ? (const uint8_t*)c->allB.p : (const uint8_t*)lv.types_d.p;
   if (!resident) {
     HIPCHK(c, hipMemsetAsync(c->scal.p, 0, 16, c->st));
     if (g.nB) launch_mv_maxabs(c->st, (const int16_t*)lv.mv_filt.p, (size_t)g.nB * 4 * fld, (int*)c->scal.p);

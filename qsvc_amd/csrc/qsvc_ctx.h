@@ -1,5 +1,6 @@
 // qsvc_amd/csrc/qsvc_ctx.h -- the context behind the C ABI (internal).
 #pragma once
+#define QSVC_ALLB_MAX 4096
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -47,7 +48,7 @@ struct Level {  // the device-resident "files" of temporal subband t
   int mv_raw_n = 0, mv_filt_n = 0, mv_bs = 0;
   DevBuf hist;                   // [nB][3][256] u32
   std::string types;             // frame_types_t
-  DevBuf types_d; PinBuf types_pin; bool types_d_ok = false;  // the same on the device (written by decorrelate; put_frame_types invalidates)
+  DevBuf types_d; PinBuf types_pin; bool types_d_ok = false; bool types_allB = false;   // types_allB: every picture 'B', update reads the context's constant run of 'B';  // the same on the device (written by decorrelate; put_frame_types invalidates)
   int mv_bound = -1;             // >= 0: no component of motion_t / motion_filtered_t exceeds it (set by motion_estimate, cleared by put_motion)
   const void* halo[2] = {nullptr, nullptr};
   bool ragged = false;           // Q7: decorrelate ran on a picture the block grid does not tile
@@ -98,6 +99,7 @@ struct qsvc_ctx {
   const void* cup_src = nullptr; int cup_mul = 0, cup_n = 0;  // what `cup` currently holds (reset by anything that writes pictures)
   DevBuf cup;                // chroma x2 interpolation of the even pictures of the level in work: [nB+1][2][H][W] u8
   DevBuf mvtmp[2], scal, tmp16[2];
+  DevBuf allB;   // QSVC_ALLB_MAX bytes of 'B': frame_types_t of a level without 'I' pictures, already on the device
   DevBuf halo_tx[2], halo_rx[2];  // boundary records: [0] left neighbour, [1] right neighbour
   uint8_t halo_tb[2][16];
   void* comm = nullptr;            // ncclComm_t (RCCL), line topology
