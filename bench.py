@@ -70,7 +70,13 @@ def cpu_baseline(reversible=True, frames=None):
     full = GOPS * 2 ** (TRLS - 1) + 1
     # a bounded sample (about 10-30 s of one core): the whole sequence of one GPU step at 1080p (17 pictures, 3 levels); at 4K the
     # first 5 pictures through 2 temporal levels (the per-picture cost of a level does not depend on the level count)
-    frames, trls = (full, TRLS) if W * H <= 1920 * 1088 else (5, 3)
+    if frames is None:
+        frames, trls = (full, TRLS) if W * H <= 1920 * 1088 else (5, 3)
+    else:  # --cpu-baseline-pictures: a prefix of 2^j + 1 pictures through as many temporal levels as it carries (at most TRLS - 1)
+        j = (frames - 1).bit_length() - 1
+        if frames < 3 or frames > full or (1 << j) + 1 != frames:
+            raise SystemExit(f"--cpu-baseline-pictures must be 2^j + 1 between 3 and {full}, got {frames}")
+        trls = min(TRLS, j + 1)
     clip = make_clip("pan_noise", frames, W, H, 43)
     t0 = time.perf_counter()
     if O.have_ref():
@@ -148,6 +154,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-pictures", type=int, default=None,
+                    help="pictures of the step's sequence the single-core CPU baseline codes (2^j + 1; default: the whole sequence at "
+                         "1080p, 5 at 4K).  The baseline is a reported figure, not part of the timed region; `sample` says what ran")
     ap.add_argument("--no-decode", action="store_true", help="skip the non-headline decode extra")
     ap.add_argument("--no-iso", action="store_true", help="skip the single-sequence pass (profiling runs: exactly warmup + steps encodes per session)")
     ap.add_argument("--clip", default="pan_noise")
@@ -600,7 +609,7 @@ def main():
                                 "milliseconds of the CPU stages of session 0 (rate allocation, Tier-2)")
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.reversible)
+                line["cpu_baseline"] = cpu_baseline(args.reversible, args.cpu_baseline_pictures)
             except Exception as ex:  # the baseline is a reported extra; never fail the GPU measurement on it
                 line["cpu_baseline"] = {"error": repr(ex)}
         sys.stdout.flush()
