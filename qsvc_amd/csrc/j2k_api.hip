@@ -953,6 +953,7 @@ int qsvc_j2k_dwt(qsvc_ctx* c, const uint8_t* plane, int H, int W, int reversible
   PlaneDesc pd{0, {0, 0}, (const uint8_t*)S.up_d.p, W, W, H, 0};
   HIPCHK(c, hipMemcpyAsync(S.up_d.p, plane, N, hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipMemcpyAsync(S.planes_d.p, &pd, sizeof pd, hipMemcpyHostToDevice, c->st));
+  S.up_planes_at = nullptr;  // the encoder's plane table no longer is what planes_d holds: its next call uploads again
   HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
   // the same tile kernel as the encoder's, with the subbands written to a Mallat-layout plane instead of the Tier-1 layout
   if (L == 0) launch_level_shift(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, S.coefA.p, reversible != 0);

@@ -10,6 +10,9 @@ void launch_pyr_ll_tile(hipStream_t st, const uint8_t* frames, size_t F, int W, 
 bool pyr_tile16_applies(int W, int ny, int nx);
 void launch_pyr_ll_tile16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int ny, int nx, int R, int C);  // LL (rows < R, columns < C) of the level below's ny x nx quadrant
 void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int l, int R, int C);
+// mctf_replay.hip: the literal analyse / synthesise replay of geometries with an odd size along the pyramid (Q5)
+void launch_rp_load(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int slot0, int slot_step, int pic0, int pic_step, int count);
+void launch_rp_dwt(hipStream_t st, int16_t* planes, int16_t* tmp, size_t plane_stride, int count, int W, int ny, int nx, int inverse);
 void launch_me_search(hipStream_t st, const MeArgs& a, int mv_bound);
 bool me_piece_applies(const MeArgs& a);          // mctf_me.hip
 void launch_me_piece(hipStream_t st, const MeArgs& a, int ring_blocks);  // a.ring set: the ring role rides in the same launch

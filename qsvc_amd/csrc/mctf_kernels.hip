@@ -95,15 +95,15 @@ void launch_me_search(hipStream_t st, const MeArgs& a0, int mv_bound) {
   dim3 block(64);
   if (a.g.bs == 8 && a.g.bord == 0) {
     dim3 grid((a.nbx + 7) / 8, a.nby, a.g.nB);
-    if (a.l == 0) hipLaunchKernelGGL(k_me_search8<uint8_t>, grid, block, 0, st, a);
+    if (!a.snap) hipLaunchKernelGGL(k_me_search8<uint8_t>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_me_search8<int16_t>, grid, block, 0, st, a);
   } else if (a.g.bs * a.g.bs <= 64) {
     dim3 grid((a.nbx + 3) / 4, a.nby, a.g.nB);
-    if (a.l == 0) hipLaunchKernelGGL((k_me_search<uint8_t, 16>), grid, block, 0, st, a);
+    if (!a.snap) hipLaunchKernelGGL((k_me_search<uint8_t, 16>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_me_search<int16_t, 16>), grid, block, 0, st, a);
   } else {
     dim3 grid(a.nbx, a.nby, a.g.nB);
-    if (a.l == 0) hipLaunchKernelGGL((k_me_search<uint8_t, 64>), grid, block, 0, st, a);
+    if (!a.snap) hipLaunchKernelGGL((k_me_search<uint8_t, 64>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_me_search<int16_t, 64>), grid, block, 0, st, a);
   }
 }

@@ -140,11 +140,12 @@ __global__ void __launch_bounds__(256) k_me_piece(MeArgs a, int npx, int ring_gr
 #pragma unroll
   for (int k = 0; k < 18; k++) sad[k] = 0;
   if (go) {
-    const size_t N = a.l == 0 ? a.g.F : a.snap_pic_stride;
-    const T* base = a.l == 0 ? (const T*)a.frames : (const T*)a.snap;
-    const T* r0 = base + (size_t)(2 * i) * N;
-    const T* pr = base + (size_t)(2 * i + 1) * N;
-    const T* r1 = base + (size_t)(2 * i + 2) * N;
+    const size_t N = !a.snap ? a.g.F : a.snap_pic_stride;
+    const T* base = !a.snap ? (const T*)a.frames : (const T*)a.snap;
+    const int i0 = (!a.snap ? 2 : a.pic_mul) * i;
+    const T* r0 = base + (size_t)i0 * N;
+    const T* pr = base + (size_t)(i0 + 1) * N;
+    const T* r1 = base + (size_t)(i0 + 2) * N;
     const int y = by * bs + 8 * (li / SUB), x = bx * bs + 8 * (li % SUB);
     MePiece<T> pc;
     pc.load_pred(pr, (uint32_t)(y * W + x), W);
@@ -198,7 +199,7 @@ bool me_piece_applies(const MeArgs& a) {
   return a.g.bord == 0 && (bs == 8 || bs == 16 || bs == 32 || bs == 64) && (size_t)a.g.H * a.g.W < (1u << 30);
 }
 void launch_me_piece(hipStream_t st, const MeArgs& a, int ring_blocks) {
-  if (a.l == 0) launch_piece<uint8_t>(st, a, ring_blocks);
+  if (!a.snap) launch_piece<uint8_t>(st, a, ring_blocks);
   else launch_piece<int16_t>(st, a, ring_blocks);
 }
 

@@ -52,8 +52,11 @@ QHD void pyr_thread(const T* src, size_t src_pic_stride, int src_row_stride, int
 struct MeArgs {
   LevelGeom g;
   const uint8_t* frames;   // low_{t-1}
-  const void* snap;        // level-l snapshots (int16) or nullptr at l == 0 (u8 luma is read directly)
+  const void* snap;        // level-l snapshots (int16), or nullptr: the u8 luma of the frames is read directly (level 0)
   size_t snap_pic_stride;  // elements
+  int pic_mul = 2;         // B picture i searches snapshot planes pic_mul*i (PREV), +1 (predicted), +2 (NEXT): 2 = one plane per
+                           // picture of low_{t-1}; 3 = one plane per ROLE (the literal replay of Q5 geometries, mctf_replay.hip,
+                           // where a picture's state depends on the role it plays)
   const int16_t* mv_prev;  // level l+1 result [nB][4][BY][BX] (stride BX) or nullptr at the coarsest level
   int16_t* mv_out;         // level l result, same layout
   int l;                   // DWT level of this search
@@ -98,13 +101,13 @@ QHD void me_block_setup(const MeArgs& a, int i, MePlane<T>& r0, MePlane<T>& r1, 
   const uint8_t* y0 = frame_y(a.frames, a.g, 2 * i);
   const uint8_t* y1 = frame_y(a.frames, a.g, 2 * i + 2);
   const uint8_t* yp = frame_y(a.frames, a.g, 2 * i + 1);
-  if (a.l == 0) {
+  if (!a.snap) {
     r0.snap = (const T*)y0; r1.snap = (const T*)y1; pr.snap = (const T*)yp;
   } else {
     const T* s = (const T*)a.snap;
-    r0.snap = s + (size_t)(2 * i) * a.snap_pic_stride;
-    r1.snap = s + (size_t)(2 * i + 2) * a.snap_pic_stride;
-    pr.snap = s + (size_t)(2 * i + 1) * a.snap_pic_stride;
+    r0.snap = s + (size_t)(a.pic_mul * i) * a.snap_pic_stride;
+    r1.snap = s + (size_t)(a.pic_mul * i + 2) * a.snap_pic_stride;
+    pr.snap = s + (size_t)(a.pic_mul * i + 1) * a.snap_pic_stride;
   }
   r0.stride = r1.stride = pr.stride = a.g.W;
   r0.luma0 = y0; r1.luma0 = y1; pr.luma0 = yp;

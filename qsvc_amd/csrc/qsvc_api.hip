@@ -110,7 +110,7 @@ void qsvc_destroy(qsvc_ctx* c) {
   (void)hipStreamSynchronize(c->st);
   free_seq(c);
   for (auto& b : c->snap) b.release();
-  c->mvtmp[0].release(); c->mvtmp[1].release();
+  c->mvtmp[0].release(); c->mvtmp[1].release(); c->rp[0].release(); c->rp[1].release();
   for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); }
   c->margin.release(); c->cup.release(); c->ovl[0].release(); c->ovl[1].release();
   if (c->comm) qsvc_comm_destroy(c);
@@ -276,6 +276,56 @@ int qsvc_set_mctf_options(qsvc_ctx* c, int block_overlaping, int border_size, in
   return QSVC_OK;
 }
 
+// Q5 (mctf_replay.hip): the search pyramid of a picture with an odd size along the way, as me_for_image walks it
+// (motion_estimate.cpp:283-358): L analysis levels at floor-halved sizes, the search, then per level one synthesis at the
+// ceil-halved size and the next search, on one int16 plane per (B picture, role).
+static int me_replay(qsvc_ctx* c, const LevelGeom& g, Level& lv, const uint8_t* frames, int L) {
+  const size_t N = (size_t)g.H * g.W, fld = (size_t)g.BY * g.BX, mvbytes = (size_t)g.nB * 4 * fld * sizeof(int16_t);
+  const int planes = 3 * g.nB;
+  int r;
+  if ((r = c->rp[0].ensure(c, (size_t)planes * N * sizeof(int16_t)))) return r;
+  if ((r = c->rp[1].ensure(c, (size_t)planes * N * sizeof(int16_t)))) return r;
+  if ((r = c->mvtmp[0].ensure(c, mvbytes))) return r;
+  if ((r = c->mvtmp[1].ensure(c, mvbytes))) return r;
+  int16_t* A = (int16_t*)c->rp[0].p; int16_t* T = (int16_t*)c->rp[1].p;
+  Prof pf;
+  pf.begin(c, "me_pyramid");
+  // pre-pass: PREV of B picture i >= 1 is even picture 2i after the whole walk it went through as NEXT of picture i-1
+  // (the reference swaps its two reference planes, motion_estimate.cpp:902-906, and reloads only the new NEXT)
+  if (g.nB > 1) {
+    launch_rp_load(c->st, frames, g.F, g.W, g.H, A, 3, 3, 2, 2, g.nB - 1);
+    for (int k = 0; k < L; k++) launch_rp_dwt(c->st, A + 3 * N, T + 3 * N, 3 * N, g.nB - 1, g.W, imax(g.H >> k, 1), imax(g.W >> k, 1), 0);
+    for (int l = L - 1; l >= 0; l--) launch_rp_dwt(c->st, A + 3 * N, T + 3 * N, 3 * N, g.nB - 1, g.W, desp(g.H, l), desp(g.W, l), 1);
+  }
+  launch_rp_load(c->st, frames, g.F, g.W, g.H, A, 0, 3, 0, 2, 1);        // PREV of picture 0: even picture 0 as read
+  launch_rp_load(c->st, frames, g.F, g.W, g.H, A, 1, 3, 1, 2, g.nB);     // predicted pictures
+  launch_rp_load(c->st, frames, g.F, g.W, g.H, A, 2, 3, 2, 2, g.nB);     // NEXT references
+  for (int k = 0; k < L; k++) launch_rp_dwt(c->st, A, T, N, planes, g.W, imax(g.H >> k, 1), imax(g.W >> k, 1), 0);  // dwt2d.cpp:78-79
+  pf.end(c);
+  const int16_t* prev = nullptr;
+  int bound = 0;
+  for (int l = L; l >= 0; l--) {
+    if (l < L) {
+      pf.begin(c, "me_pyramid");
+      launch_rp_dwt(c->st, A, T, N, planes, g.W, desp(g.H, l), desp(g.W, l), 1);   // motion_estimate.cpp:307-309
+      pf.end(c);
+    }
+    MeArgs a;
+    a.g = g; a.frames = frames; a.snap = A; a.snap_pic_stride = N; a.pic_mul = 3;
+    a.mv_prev = prev; a.mv_out = l == 0 ? (int16_t*)lv.mv_raw.p : (int16_t*)c->mvtmp[l & 1].p;
+    a.l = l; a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l);
+    a.zero_words = nullptr; a.zero_count = 0;
+    pf.begin(c, l == 0 ? "me_search_l0" : "me_search_coarse");
+    launch_me_search(c->st, a, bound);
+    pf.end(c);
+    prev = a.mv_out;
+    bound = imin(2 * (bound + 1), g.S);
+  }
+  lv.hist_zeroed = false;
+  HIPCHK(c, hipGetLastError());
+  return QSVC_OK;
+}
+
 int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   if (!c) return QSVC_ERR_INVALID;
   (void)hipSetDevice(c->dev);
@@ -285,10 +335,12 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   int lg = ilog2_exact(S);
   if (lg < 0 || S > 128) return c->fail(QSVC_ERR_UNSUPPORTED, "search_range %d is not a power of two <= 128", S);
   if (!c->pending.empty() && !c->resolving) c->calls.push_back({0, t, P, bs, S, 0, 0.0f});
-  int L = lg - 1 < 0 ? 0 : lg - 1;  // motion_estimate.cpp:277
-  // the level-l search state equals the l-level analysis only while every intermediate size is even (Q5)
-  if ((g.H % (1 << L)) || (g.W % (1 << L)))
-    return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d not divisible by 2^%d (search_range %d)", g.W, g.H, L, S);
+  int L = lg - 1 < 0 ? 0 : lg - 1;  // motion_estimate.cpp:277 (search ranges 1 and 2: dwt_levels <= 0, one search on the pictures)
+  // the level-l search state equals the l-level analysis only while every intermediate size is even; otherwise (Q5) the
+  // reference's own analyse / synthesise walk is replayed literally (me_replay below)
+  const bool replay = (g.H % (1 << L)) || (g.W % (1 << L));
+  if (replay && ((g.H >> (L - 1)) < 2 || (g.W >> (L - 1)) < 2))
+    return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d too small for %d pyramid levels (search_range %d)", g.W, g.H, L, S);
   if (desp(g.BY, L) * bs + S + g.bord > 32767) return c->fail(QSVC_ERR_UNSUPPORTED, "picture too large");
   Level& lv = c->lv[t];
   size_t fld = (size_t)g.BY * g.BX, mvbytes = (size_t)g.nB * 4 * fld * sizeof(int16_t);
@@ -298,6 +350,7 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   if (g.nB == 0) return QSVC_OK;
   const uint8_t* frames = (const uint8_t*)c->lv[t - 1].low.p;
   size_t N = (size_t)g.H * g.W;
+  if (replay) return me_replay(c, g, lv, frames, L);
   if ((int)c->snap.size() < L + 1) c->snap.resize(L + 1);
   Prof pf;
   pf.begin(c, "me_pyramid");

@@ -94,6 +94,7 @@ struct qsvc_ctx {
   int opt_ov = 0, opt_bord = 0;  // --block_overlaping, --border_size (qsvc_set_mctf_options)
   std::vector<Level> lv;
   std::vector<DevBuf> snap;  // ME pyramid snapshots per DWT level
+  DevBuf rp[2];              // Q5 geometries (mctf_replay.hip): [3 nB][H][W] int16 role planes of the literal replay + scratch
   DevBuf margin;             // Q7 chroma margin state of the level being decorrelated
   DevBuf ovl[2];             // --block_overlaping: prediction planes in the Mallat layout, [nB][3][H][W] int16 each
   const void* cup_src = nullptr; int cup_mul = 0, cup_n = 0;  // what `cup` currently holds (reset by anything that writes pictures)

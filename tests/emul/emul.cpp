@@ -42,11 +42,66 @@ int emul_dwt53t(int16_t* plane, int stride, int H, int W, int levels, int invers
   return 0;
 }
 
+// one level of the in-place transform over the top-left ny x nx of a plane (what mctf_replay.hip's k_rp_dwt + k_rp_copy do)
+static void rp_dwt(int16_t* plane, int W, int ny, int nx, int inverse, std::vector<int16_t>& tmp) {
+  if (ny < 2 && nx < 2) return;
+  auto P = [&](int y, int x) { return (int)plane[(size_t)y * W + x]; };
+  for (int y = 0; y < ny; y++)
+    for (int x = 0; x < nx; x++) tmp[(size_t)y * W + x] = (int16_t)(inverse ? synthesize2d_sample(P, y, x, ny, nx) : analyze2d_coef(P, y, x, ny, nx));
+  for (int y = 0; y < ny; y++) for (int x = 0; x < nx; x++) plane[(size_t)y * W + x] = tmp[(size_t)y * W + x];
+}
+static void me_level_search(const MeArgs& a, int bs, int16_t* mv_out, int l, size_t fld) {
+  const LevelGeom& g = a.g;
+  if (l == 0) memset(mv_out, 0, sizeof(int16_t) * g.nB * 4 * fld);
+  for (int i = 0; i < g.nB; i++)
+    for (int by = 0; by < a.nby; by++)
+      for (int bx = 0; bx < a.nbx; bx++) {
+        int pvx, pvy, nvx, nvy, sad[18], tot[18] = {0};
+        me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
+        for (int lane = 0; lane < 64; lane++) {  // 64 lanes, summed like the wave reduction
+          if (!a.snap) { MePlane<uint8_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
+          else { MePlane<int16_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
+          for (int k = 0; k < 18; k++) tot[k] += sad[k];
+        }
+        me_block_store(a, i, by, bx, tot, pvx, pvy, nvx, nvy);
+      }
+}
+// the host logic of qsvc_api.hip's me_replay (Q5 geometries) over the same thread code
+static int emul_me_replay(const uint8_t* low, const LevelGeom& g, int L, int16_t* mv_out) {
+  const int W = g.W, H = g.H, nB = g.nB;
+  const size_t N = (size_t)H * W, fld = (size_t)g.BY * g.BX;
+  std::vector<int16_t> A((size_t)3 * nB * N, 0), tmp(N);
+  auto load = [&](int slot, int pic) { for (size_t k = 0; k < N; k++) A[(size_t)slot * N + k] = low[(size_t)pic * g.F + k]; };
+  for (int j = 1; j < nB; j++) {
+    load(3 * j, 2 * j);
+    for (int k = 0; k < L; k++) rp_dwt(&A[(size_t)3 * j * N], W, imax(H >> k, 1), imax(W >> k, 1), 0, tmp);
+    for (int l = L - 1; l >= 0; l--) rp_dwt(&A[(size_t)3 * j * N], W, desp(H, l), desp(W, l), 1, tmp);
+  }
+  load(0, 0);
+  for (int i = 0; i < nB; i++) { load(3 * i + 1, 2 * i + 1); load(3 * i + 2, 2 * i + 2); }
+  for (int p = 0; p < 3 * nB; p++)
+    for (int k = 0; k < L; k++) rp_dwt(&A[(size_t)p * N], W, imax(H >> k, 1), imax(W >> k, 1), 0, tmp);
+  std::vector<int16_t> mvb[2];
+  mvb[0].assign((size_t)nB * 4 * fld, 0); mvb[1].assign((size_t)nB * 4 * fld, 0);
+  const int16_t* prev = nullptr;
+  for (int l = L; l >= 0; l--) {
+    if (l < L) for (int p = 0; p < 3 * nB; p++) rp_dwt(&A[(size_t)p * N], W, desp(H, l), desp(W, l), 1, tmp);
+    MeArgs a;
+    a.g = g; a.frames = low; a.snap = A.data(); a.snap_pic_stride = N; a.pic_mul = 3;
+    a.mv_prev = prev; a.mv_out = l == 0 ? mv_out : mvb[l & 1].data(); a.l = l;
+    a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l); a.ring = 0;
+    me_level_search(a, g.bs, mv_out, l, fld);
+    prev = a.mv_out;
+  }
+  return 0;
+}
+
 int emul_motion_estimate(const uint8_t* low, int P, int W, int H, int bs, int S, int16_t* mv_out) {
   LevelGeom g = make_geom(P, W, H, bs, S);
   int L = ilog2i(S) - 1;
   if (L < 0) L = 0;
-  if ((1 << ilog2i(S)) != S || (H % (1 << L)) || (W % (1 << L))) return -2;
+  if ((1 << ilog2i(S)) != S) return -2;
+  if ((H % (1 << L)) || (W % (1 << L))) return emul_me_replay(low, g, L, mv_out);
   size_t N = (size_t)H * W, fld = (size_t)g.BY * g.BX;
   std::vector<std::vector<int16_t>> snap(L + 1);
   for (int l = 1; l <= L; l++) {
@@ -66,20 +121,8 @@ int emul_motion_estimate(const uint8_t* low, int P, int W, int H, int bs, int S,
     MeArgs a;
     a.g = g; a.frames = low; a.snap = l ? snap[l].data() : nullptr; a.snap_pic_stride = N;
     a.mv_prev = prev; a.mv_out = l == 0 ? mv_out : mvb[l & 1].data(); a.l = l;
-    a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l);
-    if (l == 0) memset(mv_out, 0, sizeof(int16_t) * g.nB * 4 * fld);
-    for (int i = 0; i < g.nB; i++)
-      for (int by = 0; by < a.nby; by++)
-        for (int bx = 0; bx < a.nbx; bx++) {
-          int pvx, pvy, nvx, nvy, sad[18], tot[18] = {0};
-          me_block_init_mv(a, i, by, bx, pvx, pvy, nvx, nvy);
-          for (int lane = 0; lane < 64; lane++) {  // 64 lanes, summed like the wave reduction
-            if (l == 0) { MePlane<uint8_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
-            else { MePlane<int16_t> r0, r1, pr; me_block_setup(a, i, r0, r1, pr); me_block_sads(r0, r1, pr, bs, by, bx, pvy, pvx, nvy, nvx, lane, 64, sad); }
-            for (int k = 0; k < 18; k++) tot[k] += sad[k];
-          }
-          me_block_store(a, i, by, bx, tot, pvx, pvy, nvx, nvy);
-        }
+    a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l); a.ring = 0;
+    me_level_search(a, bs, mv_out, l, fld);
     prev = a.mv_out;
   }
   return 0;

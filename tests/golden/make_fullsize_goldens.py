@@ -33,6 +33,11 @@ CASES = [
     ("cfg4_pan_noise_2levels", "pan_noise", 43, 9, 3840, 2160, 3, 16, 4),
     # BASELINE config 4 whole: 33 pictures, TRLs=5, search 4 -> 8 -> 16 -> 32 (L = 4 at the last level)
     ("cfg4_pan_noise", "pan_noise", 43, 33, 3840, 2160, 5, 16, 4),
+    # Q5 at full size: BASELINE's 1080p geometry one temporal level deeper (level 4: search 32, L = 4, 1080 % 16 = 8 -- the
+    # analyse / synthesise walk of motion_estimate.cpp:283-309 is not perfect reconstruction there), and the same search range
+    # with two B pictures (the PREV reference of the second is the state the first walk left)
+    ("q5_1080p_trls5", "edge", 47, 17, 1920, 1080, 5, 8, 4),
+    ("q5_1080p_s32", "pan_noise", 43, 5, 1920, 1080, 2, 8, 32),
 ]
 
 

@@ -45,6 +45,17 @@ CASES = [
     ("deep_pan_256x192", "pan_noise", 43, 129, 256, 192, 8, 16, 4, False),    # S = 4, 8, 16, 32, 64, 128, 128 (TRLs 8)
     ("deep_edge_s32_256x192", "edge", 47, 9, 256, 192, 4, 16, 32, False),     # started at --search_range=32: 32, 64, 128
     ("deep_sat_384x256", "saturating", 45, 17, 384, 256, 5, 32, 16, False),   # block 32: 16, 32, 64, 128
+    # search ranges 1 and 2 (79 call sites of --search_range=1 in trunk/tests): dwt_levels = -1 / 0 (motion_estimate.cpp:277),
+    # one search on the pictures themselves, prediction border 4 S = 4 / 8
+    ("s1_cif_pan", "pan_noise", 43, 9, 352, 288, 4, 32, 1, False),            # S = 1, 2, 4
+    ("s1_edge_360x200", "edge", 49, 9, 360, 200, 3, 8, 1, False),             # S = 1, 2; block 8, vectors leave the picture
+    ("s2_tiny_edge", "edge", 47, 5, 96, 64, 3, 16, 2, True),                  # S = 2, 4
+    ("s1_sat_q7_200x120", "saturating", 45, 5, 200, 120, 2, 32, 1, False),    # S = 1 on a picture the block grid does not tile
+    # Q5: an odd size along the search pyramid -- the analyse (floor) / synthesise (ceil) walk is not perfect reconstruction,
+    # the searched state is what the replay left, and a reference plane keeps it from one B picture to the next
+    ("q5_edge_360x200_s32", "edge", 49, 9, 360, 200, 3, 8, 32, False),        # S = 32 (200 % 16 = 8), 64; 4 B pictures
+    ("q5_pan_350x286", "pan_noise", 51, 9, 350, 286, 4, 16, 8, False),        # S = 8, 16, 32; ragged block grid as well (Q7)
+    ("q5_sat_1080ish_480x270", "saturating", 45, 5, 480, 270, 3, 8, 16, False),  # 1080p / 4: 270 % 8 = 6 at S = 16, then 32
 ]
 
 

@@ -130,10 +130,11 @@ def _fullsize_cases():
     return json.load(open(os.path.join(GOLDEN, "fullsize_digests.json")))
 
 
-@pytest.mark.parametrize("name", ["cfg3_pan_noise", "cfg3_edge", "cfg4_pan_noise_2levels", "cfg4_pan_noise"])
+@pytest.mark.parametrize("name", ["cfg3_pan_noise", "cfg3_edge", "cfg4_pan_noise_2levels", "cfg4_pan_noise", "q5_1080p_trls5", "q5_1080p_s32"])
 def test_fullsize_levels_match_reference_digests(eng, name):
     """BASELINE config 3 (all three 1080p levels: S = 4/8/16, 135x240 block grid), levels 1-2 of a 9-picture 4K clip and ALL FOUR
-    levels of config 4 (3840x2160, 33 pictures, block 16, S = 4/8/16/32, i.e. pyramids up to L = 4): motion_t, motion_filtered_t, frame_types_t, high_t, low_t == the compiled reference tools' files
+    levels of config 4 (3840x2160, 33 pictures, block 16, S = 4/8/16/32, i.e. pyramids up to L = 4), and 1080p at search range 32 (Q5: 1080 is
+    not a multiple of 16, the literal replay of mctf_replay.hip; `--TRLs=5` on BASELINE's headline geometry): motion_t, motion_filtered_t, frame_types_t, high_t, low_t == the compiled reference tools' files
     (motion_estimate.cpp:260-481, decorrelate.cpp:583-1075, update.cpp:506-656), by SHA-256 per picture and per file."""
     from helpers import sha
     from qsvc_amd import hip

@@ -266,3 +266,16 @@ def test_hip_motion_planes_equal_openjpeg_encoder(eng):
     r = np.random.default_rng(5).integers(-40, 40, size=(8, 135, 240)).astype(np.int16)
     for cs, pl in zip(eng.j2k_encode_planes_s16(r, hip.j2k_params(reversible=True, levels=0, layers=1)), r):
         assert_same_blocks(cs, openjpeg_encode(pl.view(np.uint16), 0, signed=True))
+
+
+def test_dwt_entry_point_between_two_encodes_of_one_geometry(eng):
+    """qsvc_j2k_dwt writes its own one-plane descriptor into the table the encoder caches by content: an encode, a transform of
+    another geometry and the same encode again must give the same stream (the table is uploaded again, not assumed resident)."""
+    from qsvc_amd import hip
+    pl = _luma("pan_noise", 176, 144, 5)
+    p = hip.j2k_params(reversible=True, levels=3)
+    a = eng.j2k_encode_plane(pl, p)
+    other = _luma("noise", 100, 76, 6)
+    np.testing.assert_array_equal(eng.j2k_dwt(other, True, 2), J.coefficients(other, True, 2))
+    b = eng.j2k_encode_plane(pl, p)
+    assert a == b == J.encode_plane(pl, reversible=True, levels=3)

@@ -37,7 +37,9 @@ def run_levels(eng, clip, W, H, TRLs, bs, S, always_B=0, uf=0.25, keep_predictio
     return out
 
 
-SUPPORTED = [n for n in golden_cases() if n != "odd_350x286"]  # incl. q7_200x120: pictures the block grid does not tile
+# every chain the reference's tools produced: incl. q7_200x120 (pictures the block grid does not tile), s1_* / s2_* (search
+# ranges 1 and 2: no pyramid) and odd_350x286 / q5_* (an odd size along the search pyramid: the literal replay, mctf_replay.hip)
+SUPPORTED = golden_cases()
 
 
 @pytest.mark.parametrize("name", SUPPORTED)
@@ -48,7 +50,8 @@ def test_hip_matches_reference_goldens(eng, name):
     check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "frame_types", "high", "low", "prediction"))
 
 
-@pytest.mark.parametrize("name", ["sat_360x200", "deep_pan_256x192", "cif_binary", "cif_pan"])
+@pytest.mark.parametrize("name", ["sat_360x200", "deep_pan_256x192", "cif_binary", "cif_pan", "s1_cif_pan", "s2_tiny_edge",
+                                  "q5_edge_360x200_s32"])
 def test_chained_levels_with_deferred_decisions(eng, name):
     """The whole level chain queued without reading anything in between (what `mctf compress` does): decorrelate defers its I/B
     decisions and the chain runs on as if every picture were 'B'; the first read takes the decisions and, where a picture is 'I'
@@ -128,13 +131,21 @@ def test_inverse_level_needs_its_inputs(eng):
         eng.un_update(2, 5, 16)  # needs 3 low pictures, high_2, motion_2, frame_types_2
 
 
-@pytest.mark.parametrize("name", ["odd_350x286"])
-def test_unsupported_geometries_fail_loudly(eng, name):
+def test_unsupported_geometries_fail_loudly(eng):
+    """What the GPU path still refuses: a search range that is not a power of two (the reference's rint(log2 S) pyramid depth with a
+    clamp that can fire), odd picture sizes (4:2:0), and a pyramid deeper than the picture allows."""
     from qsvc_amd import hip
-    z, m = load_golden(name)
-    clip = golden_input(z, m)
+    clip = make_clip("pan", 3, 64, 48, 1)
+    eng.seq_config(64, 48)
+    eng.put_frames(hip.LOW, 0, clip)
     with pytest.raises(hip.QsvcError):
-        run_levels(eng, clip, m["W"], m["H"], m["TRLs"], m["bs"], m["S"])
+        eng.motion_estimate(1, 3, 16, 6)
+    with pytest.raises(hip.QsvcError):
+        eng.seq_config(63, 48)
+    eng.seq_config(72, 18)          # 18 >> 5 = 0: no room for the six levels of search range 128
+    eng.put_frames(hip.LOW, 0, make_clip("pan", 3, 72, 18, 1))
+    with pytest.raises(hip.QsvcError):
+        eng.motion_estimate(1, 3, 8, 128)
 
 
 CASES = [

@@ -6,7 +6,7 @@ import pytest
 
 from helpers import golden_input, load_golden, sha
 
-CASES = ["tiny_pan", "tiny_sat", "tiny_binary", "q7_200x120"]
+CASES = ["tiny_pan", "tiny_sat", "tiny_binary", "q7_200x120", "s2_tiny_edge", "s1_sat_q7_200x120", "odd_350x286"]
 
 
 @pytest.fixture(scope="module")
