@@ -309,6 +309,32 @@ def ref_motion_residues(filtered: dict, BY: int, BX: int) -> dict:
         shutil.rmtree(d, ignore_errors=True)
 
 
+def ref_motion_fields(residues: dict, BY: int, BX: int) -> dict:
+    """motion_residue_t -> motion_t by the reference's bidirectional_/interlevel_motion_correlate binaries (oracle/_ref: the
+    decorrelators' sources without -D ANALYZE), called as motion_expand.py:131-170 does."""
+    d = tempfile.mkdtemp(prefix="qsvc_refmc_")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MALLOC_")}
+    try:
+        its = sorted(residues)
+        for t in its:
+            np.ascontiguousarray(residues[t], dtype="<i2").tofile(os.path.join(d, f"motion_residue_{t}"))
+
+        def run(tool, *args):
+            subprocess.check_call([os.path.join(REF_DIR, tool)] + list(args), cwd=d, env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+        top = its[-1]
+        run("bidirectional_motion_correlate", f"--blocks_in_x={BX}", f"--blocks_in_y={BY}", f"--fields={residues[top].shape[0]}",
+            f"--input=motion_residue_{top}", f"--output=motion_{top}")
+        for t in reversed(its[:-1]):
+            run("interlevel_motion_correlate", f"--blocks_in_x={BX}", f"--blocks_in_y={BY}",
+                f"--fields_in_predicted={residues[t].shape[0]}", f"--reference=motion_{t + 1}", f"--predicted=motion_{t}",
+                f"--residue=motion_residue_{t}")
+        return {t: np.fromfile(os.path.join(d, f"motion_{t}"), dtype="<i2").reshape(-1, 4, BY, BX) for t in its}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def ref_dwt(plane: np.ndarray, levels: int, inverse=False, filt="53") -> np.ndarray:
     p = np.ascontiguousarray(plane, dtype=np.int16)
     H, W = p.shape

@@ -122,13 +122,24 @@ def synthesize(argv=None):
         "pixels_in_y": ("288,288,288,288,288", str), "subpixel_accuracy": ("0,0,0,0", str), "border_size": (0, int),
         "block_overlaping": (0, int), "search_range": (4, int), "update_factor": (1.0 / 4, float)}, argv)
     _refuse_deferred(a)
-    from .. import hip
-    TRLs = a["TRLs"]
-    if TRLs < 2:
+    if a["TRLs"] < 2:
         return
+    from .. import hip
+    e = C.engine()
+    try:
+        run_synthesize(e, a)
+    except hip.QsvcError as ex:
+        C.die(str(ex))
+    finally:
+        e.close()
+
+
+def run_synthesize(e, a):
+    """The level loop of synthesize.py:103-170 on an open engine (also the last stage of `expand`, cli/expand_tools.py)."""
+    TRLs = a["TRLs"]
 
     def per_level(text, idx):  # the reference indexes its comma lists; a single value stands for every level
-        parts = text.split(",")
+        parts = str(text).split(",")
         return int(parts[idx] if len(parts) > 1 else parts[0])
 
     sizes = {(per_level(a["pixels_in_x"], TRLs - t), per_level(a["pixels_in_y"], TRLs - t)) for t in range(1, TRLs)}
@@ -136,23 +147,17 @@ def synthesize(argv=None):
         C.die("a different picture size per temporal subband (spatial scalability) is not implemented on this path")
     W, H = sizes.pop()
     P0 = schedule.pictures(a["GOPs"], TRLs)
-    e = C.engine()
-    try:
-        e.seq_config(W, H)
-        C.apply_mctf_options(e, a)
-        for t in range(TRLs - 1, 0, -1):
-            P, S = P0, a["search_range"]
-            for _ in range(1, t):  # synthesize.py:118-124,160-168
-                S = min(S * 2, 128)
-                P = (P + 1) // 2
-            bs = per_level(a["block_size"], (TRLs - 1) - t)
-            _load_subband(e, t, P // 2, bs, W, H, with_low=(t == TRLs - 1))
-            e.synthesize_step(t, P, bs, S, a["update_factor"])
-            _write_synth_level(e, t, 2 * (P // 2) + 1)
-    except hip.QsvcError as ex:
-        C.die(str(ex))
-    finally:
-        e.close()
+    e.seq_config(W, H)
+    C.apply_mctf_options(e, a)
+    for t in range(TRLs - 1, 0, -1):
+        P, S = P0, a["search_range"]
+        for _ in range(1, t):  # synthesize.py:118-124,160-168
+            S = min(S * 2, 128)
+            P = (P + 1) // 2
+        bs = per_level(a["block_size"], (TRLs - 1) - t)
+        _load_subband(e, t, P // 2, bs, W, H, with_low=(t == TRLs - 1))
+        e.synthesize_step(t, P, bs, S, a["update_factor"])
+        _write_synth_level(e, t, 2 * (P // 2) + 1)
 
 
 def _run_analyze(e, a, low0, keep=True):

@@ -1,0 +1,5 @@
+"""`mctf interlevel_motion_correlate` entry point -- see qsvc_amd/cli/expand_tools.py."""
+from .expand_tools import interlevel_motion_correlate as main
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,46 @@ def bidirectional_decorrelate(fields: np.ndarray) -> np.ndarray:
     return out
 
 
+def interlevel_correlate(residue: np.ndarray, reference: np.ndarray) -> np.ndarray:
+    """The decoder's counterpart (interlevel_motion_decorrelate.cpp:55-59 without ANALYZE, main :249-283): field_k = residue_k +
+    tdiv(reference_{k/2}, 2), int16 wrap; reference fields past the end of the file keep the last one read, a missing file is zeros."""
+    F = residue.shape[0]
+    out = np.empty_like(residue, dtype=np.int16)
+    for k in range(F):
+        r = k // 2
+        ref = reference[r] if r < reference.shape[0] else (reference[-1] if reference.shape[0] else np.zeros_like(residue[0]))
+        out[k] = (residue[k].astype(np.int32) + tdiv2(ref)).astype(np.int16)
+    return out
+
+
+def bidirectional_correlate(fields: np.ndarray) -> np.ndarray:
+    """NEXT += PREV (bidirectional_motion_decorrelate.cpp:42-44 without ANALYZE)."""
+    out = fields.astype(np.int16).copy()
+    out[:, 2] = (out[:, 2].astype(np.int32) + out[:, 0]).astype(np.int16)
+    out[:, 3] = (out[:, 3].astype(np.int32) + out[:, 1]).astype(np.int16)
+    return out
+
+
+def mux_components(comps: np.ndarray) -> np.ndarray:
+    """[4 comps][F][BY][BX] -> [F][4][BY][BX] planar fields: the 8-byte records motion_expand_j2k.py:115-141 writes
+    (2 bytes of each component in turn), i.e. demux_components undone."""
+    _, F, BY, BX = comps.shape
+    flat = np.empty((F, 4 * BY * BX), dtype=np.int16)
+    for c in range(4):
+        flat[:, c::4] = comps[c].reshape(F, BY * BX)
+    return flat.reshape(F, 4, BY, BX)
+
+
+def field_chain(residues: dict, TRLs: int) -> dict:
+    """{t: motion_residue_t} -> {t: motion_t} as motion_expand.py:131-170 chains the correlators: bidirectional on the coarsest
+    level, then interlevel from the level above down to level 1."""
+    top = TRLs - 1
+    fields = {top: bidirectional_correlate(residues[top])}
+    for it in range(top - 1, 0, -1):
+        fields[it] = interlevel_correlate(residues[it], fields[it + 1])
+    return fields
+
+
 def demux_components(residue: np.ndarray) -> np.ndarray:
     """[F][4][BY][BX] planar int16 -> [4 comps][F][BY][BX] as `demux 8 2c 2 | split --bytes=BY*BX*2` cuts it."""
     F, _, BY, BX = residue.shape

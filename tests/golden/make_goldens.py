@@ -118,7 +118,13 @@ def main():
     np.savez_compressed(os.path.join(HERE, "dwt_kat.npz"), **kat)
     print("dwt_kat", len(kat))
 
-    # the two motion decorrelators on adversarial fields (odd negatives for the C division, int16 wrap, short reference)
+    make_motion_kat()
+    make_header_size_goldens()
+
+
+def make_motion_kat():
+    """The two motion decorrelators AND their inverses (the same sources without -D ANALYZE) on adversarial fields: odd negatives
+    for the C division, int16 wrap, a reference file shorter than the predicted one (the tools keep the last field read)."""
     rng = np.random.default_rng(13)
     mk = {}
     for i, (f1, f2, BY, BX) in enumerate([(4, 2, 3, 5), (5, 2, 2, 2), (2, 1, 4, 3), (1, 0, 2, 3)]):
@@ -128,12 +134,14 @@ def main():
         r = O.ref_motion_residues({1: a, 2: b}, BY, BX) if f2 else None
         if r is not None:
             mk[f"inter_{i}"], mk[f"bidir_{i}"] = r[1], r[2]
+            # read the same arrays as residues: motion_2 = bidirectional correlate of b, motion_1 = a + motion_2 / 2
+            c = O.ref_motion_fields({1: a, 2: b}, BY, BX)
+            mk[f"corr_inter_{i}"], mk[f"corr_bidir_{i}"] = c[1], c[2]
         else:
             mk[f"bidir_{i}"] = O.ref_motion_residues({1: a}, BY, BX)[1]
+            mk[f"corr_bidir_{i}"] = O.ref_motion_fields({1: a}, BY, BX)[1]
     np.savez_compressed(os.path.join(HERE, "motion_kat.npz"), **mk)
     print("motion_kat", len(mk))
-
-    make_header_size_goldens()
 
 
 def make_header_size_goldens():
@@ -169,5 +177,7 @@ def make_header_size_goldens():
 if __name__ == "__main__":
     if sys.argv[1:] == ["header_size"]:
         make_header_size_goldens()
+    elif sys.argv[1:] == ["motion_kat"]:
+        make_motion_kat()
     else:
         main()

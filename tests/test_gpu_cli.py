@@ -138,6 +138,82 @@ def test_synthesize_chain_tools(oracle, tmp_path):
     np.testing.assert_array_equal(rd(tmp_path, "l1"), rd(tmp_path, "low_1"))
 
 
+@pytest.mark.parametrize("lossless,TRLs,GOPs,bs,kind", [(1, 4, 1, 16, "pan_noise"), (0, 3, 2, 32, "edge"), (1, 2, 1, 16, "binary")])
+def test_compress_then_expand_in_an_empty_directory(oracle, tmp_path, lossless, TRLs, GOPs, bs, kind):
+    """`mcj2k compress`, then -- as trunk/tests/MCJ2K-compress-expand.sh:36-40 does -- only the code-stream (`*.j2c *.mjc *type*`)
+    copied to an empty directory and `mcj2k expand` there: texture_expand, motion_expand (residues from their code-streams, the two
+    correlators), synthesize.  Lossless texture coding: the reconstructed low_0 == the restatement's inverse chain on the encoder's
+    subbands byte for byte, and every decoded intermediate (high_t, low_T, motion_t) == what the encoder had.  9/7 with layers: the
+    decoded subbands equal the restatement's decoder on the same streams, and low_0 its inverse chain on those."""
+    import glob, shutil
+    W, H = 128, 96
+    P = GOPs * 2 ** (TRLs - 1) + 1
+    clip = make_clip(kind, P, W, H, 8)
+    enc = tmp_path / "enc"; dec = tmp_path / "dec"
+    enc.mkdir(); dec.mkdir()
+    clip.tofile(enc / "low_0")
+    MCJ2K = os.path.join(ROOT, "bin", "mcj2k")
+    geo = [f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", f"--GOPs={GOPs}", f"--block_size={bs}", f"--block_size_min={bs}"]
+    r = subprocess.run([MCJ2K, "compress", *geo, "--SRLs=4", "--nLayers=3", f"--lossless={lossless}"], cwd=enc, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for pat in ("*.j2c", "*.mjc", "*type*"):
+        for f in glob.glob(str(enc / pat)):
+            shutil.copy(f, dec)
+    assert not (dec / "low_0").exists() and not (dec / "motion_filtered_1").exists()
+    r = subprocess.run([MCJ2K, "expand", *geo, "--SRLs=4"], cwd=dec, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = oracle.analyze(clip, W, H, TRLs, bs, 4)
+    F = W * H * 3 // 2
+    # motion: decoded fields == the encoder's filtered fields (lossless coding of the residues, the correlators undo the chain)
+    for t, lv in enumerate(want, 1):
+        np.testing.assert_array_equal(rd(dec, f"motion_{t}", np.int16), lv["motion_filtered"].reshape(-1), err_msg=f"motion_{t}")
+    # textures: what the decoder reconstructed of every subband
+    subs = {}
+    for t, lv in enumerate(want, 1):
+        subs[f"high_{t}"] = lv["high"]
+    subs[f"low_{TRLs - 1}"] = want[-1]["low"]
+    got = {}
+    for name, pics in subs.items():
+        got[name] = rd(dec, name).reshape(len(pics), F)
+        if lossless:
+            np.testing.assert_array_equal(got[name], pics, err_msg=name)
+        else:  # the restatement's decoder on the very streams
+            for i in range(len(pics)):
+                planes = [J.own_decode(open(dec / f"{name}_{comp}_{i:04d}.j2c", "rb").read()) for comp in "YUV"]
+                np.testing.assert_array_equal(got[name][i], np.concatenate([p.reshape(-1) for p in planes]), err_msg=f"{name}[{i}]")
+    low = got[f"low_{TRLs - 1}"]
+    for t in range(TRLs - 1, 0, -1):
+        lv = want[t - 1]
+        low = oracle.synthesize_step(low, got[f"high_{t}"], lv["motion_filtered"], lv["frame_types"], W, H, bs, min(4 * 2 ** (t - 1), 128))["low"]
+        np.testing.assert_array_equal(rd(dec, f"low_{t - 1}"), low.reshape(-1), err_msg=f"low_{t - 1}")
+    assert "mctf expand" in open(dec / "trace").read()
+
+
+def test_motion_expand_tools_from_files(oracle, tmp_path):
+    """`mctf motion_expand_j2k` + the two correlators as their own tools, and a missing component stream = a plane of zeros
+    (motion_expand_j2k.py:84-107)."""
+    from qsvc_amd import motion
+    W, H, TRLs, bs = 128, 96, 3, 32
+    BY, BX = H // bs, W // bs
+    rng = np.random.default_rng(10)
+    filt = {1: rng.integers(-9, 10, size=(2, 4, BY, BX)).astype(np.int16), 2: rng.integers(-9, 10, size=(1, 4, BY, BX)).astype(np.int16)}
+    for t in filt:
+        filt[t].astype("<i2").tofile(tmp_path / f"motion_filtered_{t}")
+    run(tmp_path, "motion_compress", f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", "--GOPs=1", f"--block_size={bs}", f"--block_size_min={bs}")
+    res = motion.residue_chain(filt, TRLs, bs, bs)
+    for t in filt:
+        os.remove(tmp_path / f"motion_residue_{t}")
+    os.remove(tmp_path / "motion_residue_1_comp2_0001.j2c")
+    run(tmp_path, "motion_expand_j2k", "--file=motion_residue_1", f"--blocks_in_y={BY}", f"--blocks_in_x={BX}", "--fields=2")
+    want1 = res[1].copy().reshape(2, -1)
+    want1[1, 2::4] = 0                                            # the missing component of field 1
+    np.testing.assert_array_equal(rd(tmp_path, "motion_residue_1", np.int16), want1.reshape(-1))
+    run(tmp_path, "motion_expand", f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", "--GOPs=1", f"--block_size={bs}")
+    top = motion.bidirectional_correlate(res[2])
+    np.testing.assert_array_equal(rd(tmp_path, "motion_2", np.int16), top.reshape(-1))
+    np.testing.assert_array_equal(rd(tmp_path, "motion_1", np.int16), motion.interlevel_correlate(want1.reshape(2, 4, BY, BX), top).reshape(-1))
+
+
 def test_unsupported_requests_exit_nonzero(tmp_path):
     make_clip("pan", 5, 64, 64, 1).tofile(tmp_path / "low_0")
     r = subprocess.run([MCTF, "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=3", "--subpixel_accuracy=2"],

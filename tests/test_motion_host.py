@@ -89,3 +89,46 @@ def test_interlevel_cli_missing_reference_reads_zeros(tmp_path):
               "--predicted=p", "--reference=absent", "--residue=r"], tmp_path)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "r").read_bytes() == a.astype("<i2").tobytes()  # /dev/zero fallback: residue == predicted
+
+
+# ---- the decoder's side (motion_expand.py:131-170): the same sources built without -D ANALYZE -----------------------------
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_correlators_vs_reference_binaries(i):
+    if f"corr_inter_{i}" in KAT:
+        top = motion.bidirectional_correlate(KAT[f"ref_{i}"])
+        assert top.dtype == np.int16 and np.array_equal(top, KAT[f"corr_bidir_{i}"])
+        assert np.array_equal(motion.interlevel_correlate(KAT[f"pred_{i}"], top), KAT[f"corr_inter_{i}"])
+    else:
+        assert np.array_equal(motion.bidirectional_correlate(KAT[f"pred_{i}"]), KAT[f"corr_bidir_{i}"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "mctf_*.npz"))))
+def test_field_chain_undoes_the_residue_chain_on_golden_fields(path):
+    g = np.load(path)
+    TRLs = int(g["meta"][3])
+    res = {t: g[f"motion_residue_{t}"] for t in range(1, TRLs)}
+    fields = motion.field_chain(res, TRLs)
+    for t in range(1, TRLs):
+        assert np.array_equal(fields[t], g[f"motion_filtered_{t}"]), (path, t)
+
+
+def test_mux_undoes_demux():
+    rng = np.random.default_rng(4)
+    r = rng.integers(-32768, 32768, size=(3, 4, 5, 7)).astype(np.int16)
+    assert np.array_equal(motion.mux_components(motion.demux_components(r)), r)
+
+
+def test_correlator_clis_write_the_reference_files(tmp_path):
+    i = 1  # 5 residue fields over 2 reference fields: the fifth reuses the last reference read
+    a, b = KAT[f"pred_{i}"], KAT[f"ref_{i}"]
+    BY, BX = a.shape[2:]
+    a.astype("<i2").tofile(tmp_path / "motion_residue_1")
+    b.astype("<i2").tofile(tmp_path / "motion_residue_2")
+    r = _mctf("bidirectional_motion_correlate", [f"--blocks_in_x={BX}", f"--blocks_in_y={BY}", "--fields=2",
+              "--input=motion_residue_2", "--output=motion_2"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "motion_2").read_bytes() == KAT[f"corr_bidir_{i}"].astype("<i2").tobytes()
+    r = _mctf("interlevel_motion_correlate", [f"--blocks_in_x={BX}", f"--blocks_in_y={BY}", "--fields_in_predicted=5",
+              "--reference=motion_2", "--predicted=motion_1", "--residue=motion_residue_1"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "motion_1").read_bytes() == KAT[f"corr_inter_{i}"].astype("<i2").tobytes()
