@@ -26,7 +26,7 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 def build(force: bool = False) -> str:
     """Compile the C restatement (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "libqsvc_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("mctf_oracle.c", "j2k_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("mctf_oracle.c", "mctf_subpel_oracle.c", "j2k_oracle.c")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "libqsvc_oracle.so"])
@@ -55,6 +55,9 @@ def lib() -> C.CDLL:
         L.qo_un_update.argtypes = L.qo_update.argtypes
         L.qo_correlate.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p, _u8p, C.c_char_p, _u8p, C.c_void_p]
         L.qo_correlate_ov.argtypes = L.qo_correlate.argtypes + [C.c_int]
+        L.qo_motion_estimate_sub.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p]
+        L.qo_decorrelate_sub.argtypes = L.qo_decorrelate.argtypes + [C.c_int, C.c_int]
+        L.qo_correlate_sub.argtypes = L.qo_correlate.argtypes + [C.c_int, C.c_int]
         L.qo_entropy.argtypes = [_i32p, C.c_int]
         L.qo_entropy.restype = C.c_float
         L.qo_frame_type.argtypes = [_i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -89,15 +92,18 @@ def bordered(luma: np.ndarray, b: int) -> np.ndarray:
     return out
 
 
-def motion_estimate(low: np.ndarray, W, H, bs, S, border_size=0) -> np.ndarray:
+def motion_estimate(low: np.ndarray, W, H, bs, S, border_size=0, subpixel_accuracy=0) -> np.ndarray:
     low = np.ascontiguousarray(low, dtype=np.uint8)
     P = low.shape[0]
     mv = np.zeros((P // 2, 4, H // bs, W // bs), dtype=np.int16)
-    assert lib().qo_motion_estimate_b(low, P, W, H, bs, S, border_size, mv) == 0
+    if subpixel_accuracy:  # the heap-image restatement (oracle/mctf_subpel_oracle.c)
+        assert lib().qo_motion_estimate_sub(low, P, W, H, bs, S, border_size, subpixel_accuracy, mv) == 0
+    else:
+        assert lib().qo_motion_estimate_b(low, P, W, H, bs, S, border_size, mv) == 0
     return mv
 
 
-def decorrelate(low, W, H, bs, S, mv, always_B=0, want_prediction=False, want_hists=False, block_overlaping=0):
+def decorrelate(low, W, H, bs, S, mv, always_B=0, want_prediction=False, want_hists=False, block_overlaping=0, subpixel_accuracy=0):
     low = np.ascontiguousarray(low, dtype=np.uint8)
     P = low.shape[0]
     nB = P // 2
@@ -107,9 +113,14 @@ def decorrelate(low, W, H, bs, S, mv, always_B=0, want_prediction=False, want_hi
     mvo = np.zeros_like(mv)
     pred = np.zeros((nB, F), dtype=np.uint8) if want_prediction else None
     hists = np.zeros((nB, 3, 256), dtype=np.int32) if want_hists else None
-    r = lib().qo_decorrelate_ov(low, P, W, H, bs, S, always_B, np.ascontiguousarray(mv), high, types, mvo,
-                                pred.ctypes.data if pred is not None else None,
-                                hists.ctypes.data if hists is not None else None, block_overlaping)
+    if subpixel_accuracy:
+        r = lib().qo_decorrelate_sub(low, P, W, H, bs, S, always_B, np.ascontiguousarray(mv), high, types, mvo,
+                                     pred.ctypes.data if pred is not None else None,
+                                     hists.ctypes.data if hists is not None else None, block_overlaping, subpixel_accuracy)
+    else:
+        r = lib().qo_decorrelate_ov(low, P, W, H, bs, S, always_B, np.ascontiguousarray(mv), high, types, mvo,
+                                    pred.ctypes.data if pred is not None else None,
+                                    hists.ctypes.data if hists is not None else None, block_overlaping)
     assert r == 0
     return dict(high=high, types=types.raw[:nB], mv=mvo, prediction=pred, hists=hists)
 
@@ -132,42 +143,50 @@ def un_update(low_t, P, W, H, bs, high, mv, types: bytes, update_factor=0.25) ->
     return out
 
 
-def correlate(even, P, W, H, bs, S, high, mv, types: bytes, block_overlaping=0) -> np.ndarray:
+def correlate(even, P, W, H, bs, S, high, mv, types: bytes, block_overlaping=0, subpixel_accuracy=0) -> np.ndarray:
     """even_t [P/2+1], high_t [P/2] -> odd_t [P/2] (decorrelate.cpp without ANALYZE)."""
     even = np.ascontiguousarray(even, dtype=np.uint8)
     out = np.zeros((P // 2, frame_bytes(W, H)), dtype=np.uint8)
-    assert lib().qo_correlate_ov(even, P, W, H, bs, S, np.ascontiguousarray(mv), np.ascontiguousarray(high), types, out, None, block_overlaping) == 0
+    if subpixel_accuracy:
+        assert lib().qo_correlate_sub(even, P, W, H, bs, S, np.ascontiguousarray(mv), np.ascontiguousarray(high), types, out, None,
+                                      block_overlaping, subpixel_accuracy) == 0
+    else:
+        assert lib().qo_correlate_ov(even, P, W, H, bs, S, np.ascontiguousarray(mv), np.ascontiguousarray(high), types, out, None, block_overlaping) == 0
     return out
 
 
-def synthesize_step(low_t, high, mv, types: bytes, W, H, bs, S, update_factor=0.25, block_overlaping=0):
+def synthesize_step(low_t, high, mv, types: bytes, W, H, bs, S, update_factor=0.25, block_overlaping=0, subpixel_accuracy=0):
     """One inverse temporal level (synthesize_step.py:96-151): un_update, correlate, merge -> low_{t-1}."""
     nB = high.shape[0]
     P = 2 * nB + 1
     even = un_update(low_t, P, W, H, bs, high, mv, types, update_factor)
-    odd = correlate(even, P, W, H, bs, S, high, mv, types, block_overlaping)
+    odd = correlate(even, P, W, H, bs, S, high, mv, types, block_overlaping, subpixel_accuracy)
     out = np.empty((P, frame_bytes(W, H)), dtype=np.uint8)
     out[0::2] = even
     out[1::2] = odd
     return dict(even=even, odd=odd, low=out)
 
 
-def analyze_step(low, W, H, bs, S, always_B=0, update_factor=0.25, want_prediction=False, block_overlaping=0, border_size=0):
-    """One temporal level (analyze_step.py:117-232) with the restatement."""
-    mv = motion_estimate(low, W, H, bs, S, border_size)
-    d = decorrelate(low, W, H, bs, S, mv, always_B, want_prediction=want_prediction, want_hists=True, block_overlaping=block_overlaping)
+def analyze_step(low, W, H, bs, S, always_B=0, update_factor=0.25, want_prediction=False, block_overlaping=0, border_size=0,
+                 subpixel_accuracy=0):
+    """One temporal level (analyze_step.py:117-232) with the restatement.  update.cpp ignores --subpixel_accuracy: it applies the
+    (sub-pixel) vectors as whole pixels."""
+    mv = motion_estimate(low, W, H, bs, S, border_size, subpixel_accuracy)
+    d = decorrelate(low, W, H, bs, S, mv, always_B, want_prediction=want_prediction, want_hists=True, block_overlaping=block_overlaping,
+                    subpixel_accuracy=subpixel_accuracy)
     lo = update(low, W, H, bs, d["high"], d["mv"], d["types"], update_factor)
     return dict(motion=mv, motion_filtered=d["mv"], high=d["high"], frame_types=d["types"], low=lo,
                 prediction=d["prediction"], hists=d["hists"])
 
 
-def analyze(low0, W, H, TRLs, bs, S=4, bs_min=None, always_B=0, update_factor=0.25, block_overlaping=0, border_size=0):
+def analyze(low0, W, H, TRLs, bs, S=4, bs_min=None, always_B=0, update_factor=0.25, block_overlaping=0, border_size=0, subpixel_accuracy=0):
     """The level loop of analyze.py:110-153."""
     bs_min = bs if bs_min is None else min(bs_min, bs)
     levels = []
     low = low0
     for t in range(1, TRLs):
-        r = analyze_step(low, W, H, bs, S, always_B, update_factor, block_overlaping=block_overlaping, border_size=border_size)
+        r = analyze_step(low, W, H, bs, S, always_B, update_factor, block_overlaping=block_overlaping, border_size=border_size,
+                         subpixel_accuracy=subpixel_accuracy)
         r.update(block_size=bs, search_range=S, pictures=low.shape[0])
         levels.append(r)
         low = r["low"]
@@ -182,7 +201,7 @@ def have_ref() -> bool:
 
 
 def ref_analyze_step(low: np.ndarray, W, H, bs, S, always_B=0, update_factor=0.25, t=1, workdir=None, timing=None,
-                     block_overlaping=0, border_size=0):
+                     block_overlaping=0, border_size=0, subpixel_accuracy=0):
     """Run the reference's split/motion_estimate/decorrelate/update binaries (oracle/_ref) on one level,
     exactly as analyze_step.py:117-232 invokes them.  Default glibc malloc (no MALLOC_PERTURB_)."""
     import time
@@ -209,14 +228,14 @@ def ref_analyze_step(low: np.ndarray, W, H, bs, S, always_B=0, update_factor=0.2
             f"--pixels_in_x={W}", f"--pixels_in_y={H}")
         run("motion_estimate", f"--block_size={bs}", f"--border_size={border_size}", f"--even_fn=even_{t}",
             f"--imotion_fn=imotion_{t}", f"--motion_fn=motion_{t}", f"--odd_fn=odd_{t}", f"--pictures={P}",
-            f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--search_range={S}", "--subpixel_accuracy=0")
+            f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--search_range={S}", f"--subpixel_accuracy={subpixel_accuracy}")
         run("decorrelate", f"--block_overlaping={block_overlaping}", f"--block_size={bs}", f"--even_fn=even_{t}",
             f"--frame_types_fn=frame_types_{t}", f"--high_fn=high_{t}", f"--motion_in_fn=motion_{t}",
             f"--motion_out_fn=motion_filtered_{t}", f"--odd_fn=odd_{t}", f"--pictures={P}", f"--pixels_in_x={W}",
-            f"--pixels_in_y={H}", f"--search_range={S}", "--subpixel_accuracy=0", f"--always_B={always_B}")
+            f"--pixels_in_y={H}", f"--search_range={S}", f"--subpixel_accuracy={subpixel_accuracy}", f"--always_B={always_B}")
         run("update", f"--block_size={bs}", f"--even_fn=even_{t}", f"--frame_types_fn=frame_types_{t}",
             f"--high_fn=high_{t}", f"--low_fn=low_{t}", f"--motion_fn=motion_filtered_{t}", f"--pictures={P}",
-            f"--pixels_in_x={W}", f"--pixels_in_y={H}", "--subpixel_accuracy=0", f"--update_factor={update_factor}")
+            f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--subpixel_accuracy={subpixel_accuracy}", f"--update_factor={update_factor}")
         nB = P // 2
         BY, BX = H // bs, W // bs
         rd = lambda n, dt=np.uint8: np.fromfile(os.path.join(d, n), dtype=dt)
@@ -233,12 +252,13 @@ def ref_analyze_step(low: np.ndarray, W, H, bs, S, always_B=0, update_factor=0.2
             shutil.rmtree(d, ignore_errors=True)
 
 
-def ref_analyze(low0, W, H, TRLs, bs, S=4, bs_min=None, always_B=0, update_factor=0.25, timing=None, block_overlaping=0, border_size=0):
+def ref_analyze(low0, W, H, TRLs, bs, S=4, bs_min=None, always_B=0, update_factor=0.25, timing=None, block_overlaping=0, border_size=0,
+                subpixel_accuracy=0):
     bs_min = bs if bs_min is None else min(bs_min, bs)
     levels, low = [], low0
     for t in range(1, TRLs):
         r = ref_analyze_step(low, W, H, bs, S, always_B, update_factor, t=t, timing=timing, block_overlaping=block_overlaping,
-                             border_size=border_size)
+                             border_size=border_size, subpixel_accuracy=subpixel_accuracy)
         r.update(block_size=bs, search_range=S, pictures=low.shape[0])
         levels.append(r)
         low = r["low"]
@@ -247,7 +267,7 @@ def ref_analyze(low0, W, H, TRLs, bs, S=4, bs_min=None, always_B=0, update_facto
     return levels
 
 
-def ref_synthesize_step(low_t, high, mv, types: bytes, W, H, bs, S, update_factor=0.25, t=1, block_overlaping=0):
+def ref_synthesize_step(low_t, high, mv, types: bytes, W, H, bs, S, update_factor=0.25, t=1, block_overlaping=0, subpixel_accuracy=0):
     """The reference's un_update / correlate / merge binaries (oracle/_ref) as synthesize_step.py:96-151 chains them."""
     nB = high.shape[0]
     P = 2 * nB + 1
@@ -265,10 +285,10 @@ def ref_synthesize_step(low_t, high, mv, types: bytes, W, H, bs, S, update_facto
 
         run("un_update", f"--block_size={bs}", f"--even_fn=even_{t}", f"--frame_types_fn=frame_types_{t}", f"--high_fn=high_{t}",
             f"--low_fn=low_{t}", f"--motion_fn=motion_{t}", f"--pictures={P}", f"--pixels_in_x={W}", f"--pixels_in_y={H}",
-            "--subpixel_accuracy=0", f"--update_factor={update_factor}")
+            f"--subpixel_accuracy={subpixel_accuracy}", f"--update_factor={update_factor}")
         run("correlate", f"--block_overlaping={block_overlaping}", f"--block_size={bs}", f"--even_fn=even_{t}", f"--frame_types_fn=frame_types_{t}",
             f"--high_fn=high_{t}", f"--motion_in_fn=motion_{t}", f"--odd_fn=odd_{t}", f"--pictures={P}", f"--pixels_in_x={W}",
-            f"--pixels_in_y={H}", f"--search_range={S}", "--subpixel_accuracy=0")
+            f"--pixels_in_y={H}", f"--search_range={S}", f"--subpixel_accuracy={subpixel_accuracy}")
         run("merge", f"--even=even_{t}", f"--low=low_{t - 1}", f"--odd=odd_{t}", f"--pictures={P}", f"--pixels_in_x={W}",
             f"--pixels_in_y={H}")
         F = frame_bytes(W, H)

@@ -50,7 +50,9 @@ def n4_cases():
 
 
 def load_n4(name):
-    """Goldens of the optional MCTF flags (tests/golden/make_n4_goldens.py): meta also holds block_overlaping and border_size."""
+    """Goldens of the optional MCTF flags (tests/golden/make_n4_goldens.py): meta also holds block_overlaping, border_size and (when
+    not zero) subpixel_accuracy."""
     z = np.load(os.path.join(GOLDEN, f"n4_{name}.npz"), allow_pickle=False)
-    frames, W, H, TRLs, bs, S, seed, ov, bord = (int(v) for v in z["meta"])
-    return z, dict(frames=frames, W=W, H=H, TRLs=TRLs, bs=bs, S=S, seed=seed, ov=ov, bord=bord, kind=str(z["kind"]))
+    frames, W, H, TRLs, bs, S, seed, ov, bord = (int(v) for v in z["meta"][:9])
+    sub = int(z["meta"][9]) if len(z["meta"]) > 9 else 0
+    return z, dict(frames=frames, W=W, H=H, TRLs=TRLs, bs=bs, S=S, seed=seed, ov=ov, bord=bord, sub=sub, kind=str(z["kind"]))

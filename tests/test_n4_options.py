@@ -11,17 +11,18 @@ from helpers import check_levels_against_golden, golden_input, load_n4, n4_cases
 def test_restatement_matches_reference_goldens(oracle, name):
     z, m = load_n4(name)
     clip = golden_input(z, m)
-    levels = oracle.analyze(clip, m["W"], m["H"], m["TRLs"], m["bs"], m["S"], block_overlaping=m["ov"], border_size=m["bord"])
+    levels = oracle.analyze(clip, m["W"], m["H"], m["TRLs"], m["bs"], m["S"], block_overlaping=m["ov"], border_size=m["bord"],
+                            subpixel_accuracy=m["sub"])
     for t, lv in enumerate(levels, 1):
         d = oracle.decorrelate(clip if t == 1 else levels[t - 2]["low"], m["W"], m["H"], m["bs"], min(m["S"] * 2 ** (t - 1), 128), lv["motion"],
-                               want_prediction=True, block_overlaping=m["ov"])
+                               want_prediction=True, block_overlaping=m["ov"], subpixel_accuracy=m["sub"])
         lv["prediction"] = d["prediction"]
     check_levels_against_golden(z, levels, what=("motion", "motion_filtered", "frame_types", "high", "low", "prediction"))
     low = levels[-1]["low"]
     for t in range(len(levels), 0, -1):
         lv = levels[t - 1]
         low = oracle.synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], m["W"], m["H"], m["bs"],
-                                     min(m["S"] * 2 ** (t - 1), 128), block_overlaping=m["ov"])["low"]
+                                     min(m["S"] * 2 ** (t - 1), 128), block_overlaping=m["ov"], subpixel_accuracy=m["sub"])["low"]
         assert sha(low) == str(z[f"synth_low_{t - 1}_sha"]), f"synth_low_{t - 1}"
 
 

@@ -53,3 +53,37 @@ def test_dwt_restatement_equals_reference_templates(oracle):
         x = rng.integers(-200, 400, size=(h, w)).astype(np.int16)
         np.testing.assert_array_equal(oracle.dwt53t(x, lv), oracle.ref_dwt(x, lv))
         np.testing.assert_array_equal(oracle.dwt53t(x, lv, inverse=True), oracle.ref_dwt(x, lv, inverse=True))
+
+
+# --subpixel_accuracy: the heap-image restatement (oracle/mctf_subpel_oracle.c) against the compiled tools
+SUBPEL = [
+    # kind, seed, frames, W, H, TRLs, bs, S, border_size, block_overlaping, subpixel_accuracy
+    ("pan_noise", 61, 5, 128, 96, 3, 16, 4, 0, 0, 1),
+    ("edge", 62, 9, 160, 96, 3, 8, 8, 0, 0, 2),
+    ("saturating", 63, 5, 128, 128, 2, 8, 4, 1, 0, 1),
+    ("binary", 64, 5, 64, 64, 2, 16, 4, 0, 0, 2),
+    ("pan", 65, 5, 98, 70, 2, 16, 8, 0, 0, 1),        # odd pyramid sizes (Q5) under the sub-pixel levels
+    ("edge", 66, 5, 120, 68, 2, 32, 4, 0, 2, 1),      # ragged block grid + overlap
+    ("noise", 67, 3, 96, 64, 2, 16, 2, 0, 0, 3),
+]
+
+
+@pytest.mark.parametrize("kind,seed,frames,W,H,TRLs,bs,S,bord,ov,sub", SUBPEL)
+def test_subpixel_restatement_equals_compiled_reference(oracle, kind, seed, frames, W, H, TRLs, bs, S, bord, ov, sub):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    clip = make_clip(kind, frames, W, H, seed)
+    got = oracle.analyze(clip, W, H, TRLs, bs, S, border_size=bord, block_overlaping=ov, subpixel_accuracy=sub)
+    want = oracle.ref_analyze(clip, W, H, TRLs, bs, S, border_size=bord, block_overlaping=ov, subpixel_accuracy=sub)
+    for t, (g, w) in enumerate(zip(got, want), 1):
+        for k in ("motion", "motion_filtered", "high", "low"):
+            np.testing.assert_array_equal(g[k], w[k], err_msg=f"{k}_{t}")
+        assert g["frame_types"] == w["frame_types"], f"frame_types_{t}"
+    low = want[-1]["low"]
+    for t in range(len(want), 0, -1):  # the inverse chain: correlate --subpixel_accuracy (un_update ignores the flag)
+        lv, St = want[t - 1], min(S * 2 ** (t - 1), 128)
+        a = oracle.synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], W, H, bs, St, block_overlaping=ov, subpixel_accuracy=sub)
+        b = oracle.ref_synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], W, H, bs, St, t=t, block_overlaping=ov,
+                                       subpixel_accuracy=sub)
+        np.testing.assert_array_equal(a["low"], b["low"], err_msg=f"synth_low_{t - 1}")
+        low = b["low"]
