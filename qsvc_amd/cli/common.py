@@ -92,7 +92,7 @@ def interleave(even: np.ndarray, odd: np.ndarray) -> np.ndarray:
 
 def apply_mctf_options(e, a):
     """--block_overlaping / --border_size / --subpixel_accuracy of the reference's tools -> the engine.
-    subpixel_accuracy other than 0 is refused by the library (QSVC_ERR_UNSUPPORTED), with the drivers' exit status."""
+    What the library refuses (QSVC_ERR_UNSUPPORTED) ends the tool with the drivers' exit status."""
     from .. import hip
     sp = a.get("subpixel_accuracy", 0)
     if isinstance(sp, str):  # synthesize takes a comma list, one entry per level

@@ -24,14 +24,6 @@ COMMON = {"pixels_in_x": (352, int), "pixels_in_y": (288, int), "always_B": (0, 
 EXT = {"reversible": (0, int), "lossless": (0, int), "base_step": (1.0 / 256, float), "keep_intermediates": (1, int)}
 
 
-def _refuse_deferred(a):
-    """--subpixel_accuracy > 0 (motion_estimate.cpp:361-412, decorrelate.cpp:656-686) is the one deferred MCTF option left: refused
-    before any work (the library refuses it too).  --block_overlaping and --border_size go to the engine (C.apply_mctf_options)."""
-    sp = a.get("subpixel_accuracy", 0)
-    if (any(int(x) for x in sp.split(",") if x != "") if isinstance(sp, str) else sp):
-        C.die("subpixel_accuracy other than 0 is not implemented on this path (SURVEY.md N4)")
-
-
 def _write_level(e, t, P, bs, W, H, low_prev, want_pred=True):
     """The cwd files one analyze_step leaves behind (analyze_step.py:117-232)."""
     from .. import hip
@@ -52,7 +44,6 @@ def _write_level(e, t, P, bs, W, H, low_prev, want_pred=True):
 
 def analyze_step(argv=None):
     a = C.parse("Performs a temporal analysis step.", dict(COMMON, pictures=(9, int), temporal_subband=(1, int)), argv)
-    _refuse_deferred(a)
     from .. import hip
     W, H, t, P = a["pixels_in_x"], a["pixels_in_y"], a["temporal_subband"], a["pictures"]
     bs = a["block_size"] or schedule.default_block_size(W, H)  # analyze_step.py:92-96
@@ -97,7 +88,6 @@ def synthesize_step(argv=None):
         "block_overlaping": (0, int), "block_size": (16, int), "pictures": (33, int), "pixels_in_x": (352, int),
         "pixels_in_y": (288, int), "search_range": (4, int), "subpixel_accuracy": (0, int), "temporal_subband": (0, int),
         "update_factor": (1.0 / 4, float)}, argv)
-    _refuse_deferred(a)
     from .. import hip
     W, H, t, bs = a["pixels_in_x"], a["pixels_in_y"], a["temporal_subband"], a["block_size"]
     nB = a["pictures"] // 2
@@ -121,7 +111,6 @@ def synthesize(argv=None):
         "GOPs": (1, int), "TRLs": (4, int), "block_size": ("16,16,16,16", str), "pixels_in_x": ("352,352,352,352,352", str),
         "pixels_in_y": ("288,288,288,288,288", str), "subpixel_accuracy": ("0,0,0,0", str), "border_size": (0, int),
         "block_overlaping": (0, int), "search_range": (4, int), "update_factor": (1.0 / 4, float)}, argv)
-    _refuse_deferred(a)
     if a["TRLs"] < 2:
         return
     from .. import hip
@@ -148,8 +137,9 @@ def run_synthesize(e, a):
     W, H = sizes.pop()
     P0 = schedule.pictures(a["GOPs"], TRLs)
     e.seq_config(W, H)
-    C.apply_mctf_options(e, a)
     for t in range(TRLs - 1, 0, -1):
+        # synthesize.py:133: --subpixel_accuracy is a list indexed like the picture sizes, one entry per temporal subband
+        C.apply_mctf_options(e, dict(a, subpixel_accuracy=per_level(a.get("subpixel_accuracy", 0) or 0, TRLs - t)))
         P, S = P0, a["search_range"]
         for _ in range(1, t):  # synthesize.py:118-124,160-168
             S = min(S * 2, 128)
@@ -189,7 +179,6 @@ def _resolve_blocks(a):
 
 def analyze(argv=None):
     a = C.parse("Performs the temporal analysis of a picture sequence.", dict(COMMON, **{"update_factor": (0.0, float)}), argv)
-    _refuse_deferred(a)
     a["_default_bs"] = 32
     _resolve_blocks(a)
     from .. import hip
@@ -262,7 +251,6 @@ def compress(argv=None):
     spec = dict(COMMON, clayers_motion=(0, str), quantization_step=(0, int), quantization_motion=("45000", str),
                 quantization_texture=("45000", str), SRLs=(5, int), nLayers=(5, int), **EXT)
     a = C.parse("Encodes a sequence of pictures.", spec, argv)
-    _refuse_deferred(a)
     a["_default_bs"] = schedule.default_block_size(a["pixels_in_x"], a["pixels_in_y"])  # compress.py:139-142
     _resolve_blocks(a)
     a["quantization_texture"] = int(str(a["quantization_texture"]).replace('"', ""))

@@ -1,6 +1,6 @@
 """`mctf motion_estimate` (trunk/src/motion_estimate.cpp:490-912): even_t, odd_t -> motion_t on the GPU.
-Flags as motion_estimate.cpp:516-530.  Differences, both deliberate: an existing motion file is
-overwritten (the reference exits 1, which aborts the pipeline); subpixel_accuracy other than 0 is refused."""
+Flags as motion_estimate.cpp:516-530 (incl. --border_size and --subpixel_accuracy).  One deliberate difference: an existing
+motion file is overwritten (the reference exits 1, which aborts the pipeline)."""
 from . import common as C
 
 

@@ -8,8 +8,8 @@ def main(argv=None):
         "block_size": (16, int), "even_fn": ("even", str), "frame_types_fn": ("frame_types", str), "high_fn": ("high", str),
         "low_fn": ("low", str), "motion_fn": ("motion", str), "pictures": (33, int), "pixels_in_x": (352, int),
         "pixels_in_y": (288, int), "subpixel_accuracy": (0, int), "update_factor": (1.0 / 4, float)}, argv)
-    if a["subpixel_accuracy"]:
-        C.die("subpixel_accuracy other than 0 is not implemented on this path (SURVEY.md N4)")
+    # --subpixel_accuracy is accepted and, as in update.cpp (which parses it at :266 and never uses it), has no effect: the vectors
+    # are applied as whole pixels
     from .. import hip
     W, H, bs, nB = a["pixels_in_x"], a["pixels_in_y"], a["block_size"], a["pictures"] // 2
     low = C.read_frames(a["low_fn"], W, H, nB + 1)

@@ -25,6 +25,17 @@ void launch_predict_run(hipStream_t st, const PredArgs& a);
 bool pred_fast_path(const PredArgs& a);          // launch_predict takes the mctf_pred.hip kernels (no interpolated chroma planes needed)
 // --block_overlaping >= 2: predict through per-block analysis + picture synthesis (two [nB][3][H][W] int16 work buffers)
 bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, int16_t* ppl1);
+bool launch_ovl_blocks(hipStream_t st, const PredArgs& a, int16_t* ppl0, int16_t* ppl1);   // the prediction planes only (into ppl0)
+// residue / histograms (or correlate) from full-resolution prediction planes ppl [nB][3][H][W]; clip: to 0..255 first
+void launch_pred_finish(hipStream_t st, const PredArgs& a, const int16_t* ppl, int clip);
+// mctf_subpel.hip (--subpixel_accuracy)
+void launch_sp_load(hipStream_t st, const uint8_t* frames, size_t F, const SpGeom& g, int16_t* dst, const int16_t* src16, int slot0, int slot_step,
+                    int pic0, int pic_step, int count, int is_ref);
+void launch_sp_search(hipStream_t st, const SpGeom& g, const uint8_t* frames, size_t F, const int16_t* planes, int nB, int BY, int BX, int bsl, int bordl,
+                      int lim, const int16_t* mv_in, int16_t* mv_out);
+uint8_t* launch_sp_refs(hipStream_t st, const uint8_t* frames, const LevelGeom& g, int mul, int count, int a, uint8_t* up, uint8_t* tmp);
+void launch_sp_predict(hipStream_t st, const LevelGeom& ge, const uint8_t* up, const int16_t* mv, int16_t* ppl);
+int16_t* launch_sp_down(hipStream_t st, int16_t* ppl, int16_t* tmp, int count, int H, int W, int a);
 void launch_pred_margin(hipStream_t st, const PredArgs& a);  // mctf_margin.hip (Q7)
 void launch_update(hipStream_t st, const UpdArgs& a);
 bool upd_run_applies(const UpdArgs& a);          // mctf_upd.hip

@@ -377,8 +377,9 @@ __global__ void __launch_bounds__(256) k_ovl_block(PredArgs a, int levels, int16
   const int tid = threadIdx.x, bx = blockIdx.x, by = blockIdx.y, i = blockIdx.z / 3, c = blockIdx.z % 3;
   const int ov = g.ov, bs = g.bs, n = bs + 2 * ov;
   const size_t plane = (size_t)g.H * g.W, fld = (size_t)g.BY * g.BX;
-  const uint8_t* r0 = c == 0 ? frame_y(a.frames, g, 2 * i) : a.cup + ((size_t)i * 2 + (c - 1)) * plane;
-  const uint8_t* r1 = c == 0 ? frame_y(a.frames, g, 2 * i + 2) : a.cup + ((size_t)(i + 1) * 2 + (c - 1)) * plane;
+  const uint8_t* r0 = a.up ? a.up + ((size_t)i * 3 + c) * plane : (c == 0 ? frame_y(a.frames, g, 2 * i) : a.cup + ((size_t)i * 2 + (c - 1)) * plane);
+  const uint8_t* r1 = a.up ? a.up + ((size_t)(i + 1) * 3 + c) * plane
+                           : (c == 0 ? frame_y(a.frames, g, 2 * i + 2) : a.cup + ((size_t)(i + 1) * 2 + (c - 1)) * plane);
   const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)by * g.BX + bx;
   const int y0 = by * bs + m[fld], x0 = bx * bs + m[0], y1 = by * bs + m[3 * fld], x1 = bx * bs + m[2 * fld];
   const BorderGeom bg = make_border(g.H, g.W, 4 * g.S + g.ov);
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(256) k_copy_region_planes(const int16_t* src, 
   if (x < nx && y < ny) dst[(size_t)blockIdx.z * plane + (size_t)y * stride + x] = src[(size_t)blockIdx.z * plane + (size_t)y * stride + x];
 }
 // residue / correlate from the synthesised prediction planes: luma (thread per sample) ...
-__global__ void __launch_bounds__(256) k_ovl_finish_luma(PredArgs a, const int16_t* ppl) {
+__global__ void __launch_bounds__(256) k_ovl_finish_luma(PredArgs a, const int16_t* ppl, int clip) {
   __shared__ unsigned h[2][256];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   h[0][tid] = 0; h[1][tid] = 0;
@@ -431,7 +432,8 @@ __global__ void __launch_bounds__(256) k_ovl_finish_luma(PredArgs a, const int16
   const LevelGeom& g = a.g;
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
   if (x < g.W && y < g.H) {
-    const int p = iclamp(ppl[((size_t)i * 3) * g.H * g.W + (size_t)y * g.W + x], 0, 255);  // decorrelate.cpp:841-848
+    int p = ppl[((size_t)i * 3) * g.H * g.W + (size_t)y * g.W + x];
+    if (clip) p = iclamp(p, 0, 255);  // decorrelate.cpp:841-848 (with --subpixel_accuracy the clip was done before the planes came down)
     const size_t off = (size_t)i * g.F + (size_t)y * g.W + x;
     if (a.odd_out) a.odd_out[(size_t)(2 * i + 1) * g.F + (size_t)y * g.W + x] = (uint8_t)correlate_sample(a.high[off], p, a.types[i]);
     else {
@@ -449,13 +451,13 @@ __global__ void __launch_bounds__(256) k_ovl_finish_luma(PredArgs a, const int16
   if (h[1][tid]) atomicAdd(&gh[256 + tid], h[1][tid]);
 }
 // ... and chroma: clip, chroma/2 (LL of a 1-level analysis, decorrelate.cpp:860-861), residue
-__global__ void __launch_bounds__(256) k_ovl_finish_chroma(PredArgs a, const int16_t* ppl) {
+__global__ void __launch_bounds__(256) k_ovl_finish_chroma(PredArgs a, const int16_t* ppl, int clip) {
   const LevelGeom& g = a.g;
   const int cw = g.W / 2, chh = g.H / 2;
   const int ci = blockIdx.x * 64 + threadIdx.x, cj = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z >> 1, c = 1 + (blockIdx.z & 1);
   if (ci >= cw || cj >= chh) return;
   const int16_t* pp = ppl + ((size_t)i * 3 + c) * g.H * g.W;
-  auto P = [&](int yy, int xx) { return iclamp(pp[(size_t)yy * g.W + xx], 0, 255); };
+  auto P = [&](int yy, int xx) { const int v = pp[(size_t)yy * g.W + xx]; return clip ? iclamp(v, 0, 255) : v; };
   const int ll = analyze_ll(P, cj, ci, g.H, g.W);
   const size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh + (size_t)cj * cw + ci, off = (size_t)i * g.F + coff;
   if (a.odd_out) a.odd_out[(size_t)(2 * i + 1) * g.F + coff] = (uint8_t)correlate_sample(a.high[off], ll, a.types[i]);
@@ -466,12 +468,11 @@ __global__ void __launch_bounds__(256) k_ovl_finish_chroma(PredArgs a, const int
   if (a.pred_dump) a.pred_dump[off] = (uint8_t)ll;
 }
 // ppl0 / ppl1: two [nB][3][H][W] int16 buffers.  Returns false when the geometry is outside this path.
-bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, int16_t* ppl1) {
+bool launch_ovl_blocks(hipStream_t st, const PredArgs& a, int16_t* ppl0, int16_t* ppl1) {
   const LevelGeom& g = a.g;
   int levels = 0;
   while ((1 << (levels + 1)) <= g.ov) levels++;
-  if ((1 << levels) != g.ov || levels < 1 || g.bs + 2 * g.ov > OVL_MAXN || (g.bs & (g.ov - 1)) || !a.cup || a.margin) return false;
-  if (!a.odd_out) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
+  if ((1 << levels) != g.ov || levels < 1 || g.bs + 2 * g.ov > OVL_MAXN || (g.bs & (g.ov - 1)) || (!a.cup && !a.up) || a.margin) return false;
   const size_t plane = (size_t)g.H * g.W;
   hipLaunchKernelGGL(k_ovl_block, dim3(g.BX, g.BY, g.nB * 3), dim3(256), 0, st, a, levels, ppl0);
   for (int lv = levels - 1; lv >= 0; lv--) {  // dwt2d::synthesize (dwt2d.cpp:128-175)
@@ -480,15 +481,24 @@ bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, in
     hipLaunchKernelGGL(k_dwt53t_synth_planes, grid, block, 0, st, ppl0, ppl1, plane, g.W, ny, nx);
     hipLaunchKernelGGL(k_copy_region_planes, grid, block, 0, st, ppl1, ppl0, plane, g.W, ny, nx);
   }
+  return true;
+}
+void launch_pred_finish(hipStream_t st, const PredArgs& a, const int16_t* ppl, int clip) {
+  const LevelGeom& g = a.g;
+  if (!a.odd_out) hipMemsetAsync(a.hist, 0, sizeof(unsigned) * 3 * 256 * g.nB, st);
   dim3 block(64, 4);
-  hipLaunchKernelGGL(k_ovl_finish_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a, ppl0);
-  hipLaunchKernelGGL(k_ovl_finish_chroma, dim3((g.W / 2 + 63) / 64, (g.H / 2 + 3) / 4, g.nB * 2), block, 0, st, a, ppl0);
+  hipLaunchKernelGGL(k_ovl_finish_luma, dim3((g.W + 63) / 64, (g.H + 3) / 4, g.nB), block, 0, st, a, ppl, clip);
+  hipLaunchKernelGGL(k_ovl_finish_chroma, dim3((g.W / 2 + 63) / 64, (g.H / 2 + 3) / 4, g.nB * 2), block, 0, st, a, ppl, clip);
   if (!a.odd_out) {
     size_t per_pic = (size_t)4 * g.BY * g.BX;
     int nblk = (int)((per_pic + 255) / 256);
     if (nblk > 64) nblk = 64;
     hipLaunchKernelGGL(k_mv_hist, dim3(nblk, g.nB), dim3(256), 0, st, a.mv, per_pic, a.hist);
   }
+}
+bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, int16_t* ppl1) {
+  if (!launch_ovl_blocks(st, a, ppl0, ppl1)) return false;
+  launch_pred_finish(st, a, ppl0, 1);
   return true;
 }
 

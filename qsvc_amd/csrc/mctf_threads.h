@@ -22,6 +22,16 @@ struct LevelGeom {
   size_t F;      // bytes per I420 frame
   int ov;        // --block_overlaping (decorrelate.cpp:539: the reference planes' border is 4*S + ov)
   int bord;      // --border_size of the motion search (motion_estimate.cpp:213-217,714)
+  int sub = 0;   // --subpixel_accuracy: the search planes are allocated at (H << sub) x (W << sub), every row of the picture keeps its
+                 // shifted pointer and Q1 does not apply to the whole-pixel levels (mctf_subpel.hip)
+};
+// geometry of the sub-pixel search planes (mctf_subpel.hip)
+struct SpGeom {
+  int H, W;      // the picture
+  int a;         // subpixel_accuracy
+  int Ha, Wa;    // H << a, W << a: the planes' interior
+  int b, ba;     // S + border_size: the border the picture was filled with; b << a: the border the planes were allocated with
+  int c0, c1;    // the low / high 16 bits of a row chunk's size field, glibc: align16(2 (Wa + 2 ba) + 8) | PREV_INUSE
 };
 
 QHD const uint8_t* frame_y(const uint8_t* frames, const LevelGeom& g, int pic) { return frames + (size_t)pic * g.F; }
@@ -98,6 +108,7 @@ QHD bool me_ring_block(const MeArgs& a, int idx, int& by, int& bx) {
 template <class T>
 QHD void me_block_setup(const MeArgs& a, int i, MePlane<T>& r0, MePlane<T>& r1, MePlane<T>& pr) {
   BorderGeom bg = make_border(a.g.H, a.g.W, a.g.S + a.g.bord);  // motion_estimate.cpp:714
+  if (a.g.sub) bg.safe = 1 << 30;  // planes of the up-sampled size: the rows of the picture all have shifted pointers (no Q1)
   const uint8_t* y0 = frame_y(a.frames, a.g, 2 * i);
   const uint8_t* y1 = frame_y(a.frames, a.g, 2 * i + 2);
   const uint8_t* yp = frame_y(a.frames, a.g, 2 * i + 1);
@@ -145,6 +156,8 @@ struct PredArgs {
   const uint8_t* cup;     // [nB+1][2][H][W] u8: chroma x2 interpolation of every even picture (launch_chroma_up), or nullptr
   int16_t* mv_copy;       // mctf_pred.hip only: motion_filtered_t starts as a copy of motion_t (decorrelate.cpp:1005-1025), or nullptr
   int hist_is_zero;       // mctf_pred.hip only: the histograms were zeroed by the motion search's last launch (no memset needed)
+  const uint8_t* up;      // --subpixel_accuracy with --block_overlaping >= 2 (k_ovl_block on the up-sampled geometry): [nB+1][3][H][W]
+                          // u8 references of all three components, or nullptr
 };
 // what correlate stores for one sample: the picture itself for 'I', clip(residue + prediction) for 'B'
 QHD int correlate_sample(int h, int p, int type) { return type == 'I' ? h : iclamp(h - 128 + p, 0, 255); }

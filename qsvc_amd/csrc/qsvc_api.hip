@@ -110,7 +110,7 @@ void qsvc_destroy(qsvc_ctx* c) {
   (void)hipStreamSynchronize(c->st);
   free_seq(c);
   for (auto& b : c->snap) b.release();
-  c->mvtmp[0].release(); c->mvtmp[1].release(); c->rp[0].release(); c->rp[1].release();
+  c->mvtmp[0].release(); c->mvtmp[1].release(); c->rp[0].release(); c->rp[1].release(); c->sp[0].release(); c->sp[1].release();
   for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); }
   c->margin.release(); c->cup.release(); c->ovl[0].release(); c->ovl[1].release();
   if (c->comm) qsvc_comm_destroy(c);
@@ -259,7 +259,7 @@ static int level_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g) {
   // Q7, reproduced by the margin state of PredArgs (mctf_threads.h)
   if (c->H < bs || c->W < bs) return c->fail(QSVC_ERR_INVALID, "picture %dx%d smaller than block_size %d", c->W, c->H, bs);
   g->W = c->W; g->H = c->H; g->bs = bs; g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
-  g->ov = c->opt_ov; g->bord = c->opt_bord;
+  g->ov = c->opt_ov; g->bord = c->opt_bord; g->sub = c->opt_sub;
   return QSVC_OK;
 }
 
@@ -267,12 +267,48 @@ int qsvc_set_mctf_options(qsvc_ctx* c, int block_overlaping, int border_size, in
   if (!c) return QSVC_ERR_INVALID;
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   if (block_overlaping < 0 || border_size < 0 || subpixel_accuracy < 0) return c->fail(QSVC_ERR_INVALID, "negative MCTF option");
-  if (subpixel_accuracy != 0)
-    return c->fail(QSVC_ERR_UNSUPPORTED, "subpixel_accuracy %d: sub-pixel motion (motion_estimate.cpp:361-412, decorrelate.cpp:656-686) is not implemented on this path", subpixel_accuracy);
+  if (subpixel_accuracy > 3)
+    return c->fail(QSVC_ERR_UNSUPPORTED, "subpixel_accuracy %d: at most 3 (planes of 8 x 8 times the picture) on this path", subpixel_accuracy);
   if (block_overlaping > 1 && (block_overlaping & (block_overlaping - 1)))
     return c->fail(QSVC_ERR_UNSUPPORTED, "block_overlaping %d is not a power of two", block_overlaping);
   if (border_size > 64) return c->fail(QSVC_ERR_UNSUPPORTED, "border_size %d", border_size);
-  c->opt_ov = block_overlaping; c->opt_bord = border_size;
+  c->opt_ov = block_overlaping; c->opt_bord = border_size; c->opt_sub = subpixel_accuracy;
+  return QSVC_OK;
+}
+
+// --subpixel_accuracy (mctf_subpel.hip): the a sub-pixel levels of me_for_image (motion_estimate.cpp:361-406) behind the whole-pixel
+// pyramid, whose level-0 vectors are in mvtmp[0].  Role planes at the up-sampled size: slot 3i PREV, 3i+1 predicted, 3i+2 NEXT of
+// B picture i; state0 = the level-0 state of the literal replay (same slots) or nullptr: the pictures themselves.
+static int me_subpel(qsvc_ctx* c, const LevelGeom& g, Level& lv, const uint8_t* frames, int L, const int16_t* state0) {
+  const int a = g.sub, planes = 3 * g.nB;
+  SpGeom sg;
+  sg.H = g.H; sg.W = g.W; sg.a = a; sg.Ha = g.H << a; sg.Wa = g.W << a; sg.b = g.S + g.bord; sg.ba = sg.b << a;
+  const long chunk = ((2L * (sg.Wa + 2 * sg.ba) + 8 + 15) & ~15L) | 1;  // glibc request2size | PREV_INUSE (texture.cpp:36-38)
+  sg.c0 = (int)(int16_t)(chunk & 0xFFFF); sg.c1 = (int)(int16_t)((chunk >> 16) & 0xFFFF);
+  const size_t N = (size_t)sg.Ha * sg.Wa, bytes = (size_t)planes * N * sizeof(int16_t);
+  int r;
+  if ((r = c->sp[0].ensure(c, bytes))) return r;
+  if ((r = c->sp[1].ensure(c, bytes))) return r;
+  int16_t* A = (int16_t*)c->sp[0].p; int16_t* T = (int16_t*)c->sp[1].p;
+  Prof pf;
+  pf.begin(c, "me_subpel");
+  HIPCHK(c, hipMemsetAsync(A, 0, bytes, c->st));  // the planes' interior is zeroed before every read (motion_estimate.cpp:723-741,803-807)
+  launch_sp_load(c->st, frames, g.F, sg, A, state0, 0, 3, 0, 2, g.nB, 1);
+  launch_sp_load(c->st, frames, g.F, sg, A, state0, 1, 3, 1, 2, g.nB, 0);
+  launch_sp_load(c->st, frames, g.F, sg, A, state0, 2, 3, 2, 2, g.nB, 1);
+  int bound = (2 << L) - 1;
+  const int lim = g.S << a;
+  for (int s = 1; s <= a; s++) {
+    launch_rp_dwt(c->st, A, T, N, planes, sg.Wa, g.H << s, g.W << s, 1);  // motion_estimate.cpp:368-370
+    const int16_t* in = (const int16_t*)c->mvtmp[(s - 1) & 1].p;
+    int16_t* out = s == a ? (int16_t*)lv.mv_raw.p : (int16_t*)c->mvtmp[s & 1].p;
+    launch_sp_search(c->st, sg, frames, g.F, A, g.nB, g.BY, g.BX, g.bs << s, g.bord >> s, lim, in, out);
+    bound = imin(2 * bound, lim) + 1;
+  }
+  pf.end(c);
+  lv.mv_bound = bound;
+  lv.hist_zeroed = false;
+  HIPCHK(c, hipGetLastError());
   return QSVC_OK;
 }
 
@@ -312,7 +348,7 @@ static int me_replay(qsvc_ctx* c, const LevelGeom& g, Level& lv, const uint8_t* 
     }
     MeArgs a;
     a.g = g; a.frames = frames; a.snap = A; a.snap_pic_stride = N; a.pic_mul = 3;
-    a.mv_prev = prev; a.mv_out = l == 0 ? (int16_t*)lv.mv_raw.p : (int16_t*)c->mvtmp[l & 1].p;
+    a.mv_prev = prev; a.mv_out = l == 0 && !g.sub ? (int16_t*)lv.mv_raw.p : (int16_t*)c->mvtmp[l & 1].p;
     a.l = l; a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l);
     a.zero_words = nullptr; a.zero_count = 0;
     pf.begin(c, l == 0 ? "me_search_l0" : "me_search_coarse");
@@ -341,6 +377,14 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   const bool replay = (g.H % (1 << L)) || (g.W % (1 << L));
   if (replay && ((g.H >> (L - 1)) < 2 || (g.W >> (L - 1)) < 2))
     return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d too small for %d pyramid levels (search_range %d)", g.W, g.H, L, S);
+  if (g.sub) {  // mctf_subpel.hip
+    const int b = S + g.bord;
+    if (S < 2) return c->fail(QSVC_ERR_UNSUPPORTED, "subpixel_accuracy with search_range 1: the reference's motion_estimate reads outside its planes and crashes");
+    if ((S << g.sub) > 126) return c->fail(QSVC_ERR_UNSUPPORTED, "search_range %d << subpixel_accuracy %d: vectors leave the 256-bin motion histogram of decorrelate.cpp:805-812", S, g.sub);
+    if ((g.W << g.sub) > 16384 || (g.H << g.sub) > 16384) return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d << %d exceeds the reference's line buffer (16384)", g.W, g.H, g.sub);
+    if (((g.H - b) << g.sub) < g.H + b)  // the band of the small picture's border would reach the planes' unshifted rows
+      return c->fail(QSVC_ERR_UNSUPPORTED, "search_range %d + border_size %d too large for a %d-row picture with subpixel_accuracy %d", S, g.bord, g.H, g.sub);
+  }
   if (desp(g.BY, L) * bs + S + g.bord > 32767) return c->fail(QSVC_ERR_UNSUPPORTED, "picture too large");
   Level& lv = c->lv[t];
   size_t fld = (size_t)g.BY * g.BX, mvbytes = (size_t)g.nB * 4 * fld * sizeof(int16_t);
@@ -350,7 +394,10 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   if (g.nB == 0) return QSVC_OK;
   const uint8_t* frames = (const uint8_t*)c->lv[t - 1].low.p;
   size_t N = (size_t)g.H * g.W;
-  if (replay) return me_replay(c, g, lv, frames, L);
+  if (replay) {
+    if ((r = me_replay(c, g, lv, frames, L))) return r;
+    return g.sub ? me_subpel(c, g, lv, frames, L, (const int16_t*)c->rp[0].p) : QSVC_OK;
+  }
   if ((int)c->snap.size() < L + 1) c->snap.resize(L + 1);
   Prof pf;
   pf.begin(c, "me_pyramid");
@@ -361,7 +408,7 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
     else launch_pyr_level_s16(c->st, (const int16_t*)c->snap[l - 1].p, (int16_t*)c->snap[l].p, g.W, g.H, P, l, R, C);
   }
   pf.end(c);
-  if (L >= 1) {
+  if (L >= 1 || g.sub) {
     if ((r = c->mvtmp[0].ensure(c, mvbytes))) return r;
     if ((r = c->mvtmp[1].ensure(c, mvbytes))) return r;
   }
@@ -370,7 +417,7 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
   for (int l = L; l >= 0; l--) {
     MeArgs a;
     a.g = g; a.frames = frames; a.snap = l ? c->snap[l].p : nullptr; a.snap_pic_stride = N;
-    a.mv_prev = prev; a.mv_out = l == 0 ? (int16_t*)lv.mv_raw.p : (int16_t*)c->mvtmp[l & 1].p;
+    a.mv_prev = prev; a.mv_out = l == 0 && !g.sub ? (int16_t*)lv.mv_raw.p : (int16_t*)c->mvtmp[l & 1].p;  // (sub-pixel levels follow)
     a.l = l; a.nby = desp(g.BY, l); a.nbx = desp(g.BX, l);
     a.zero_words = nullptr; a.zero_count = 0;
     if (l == 0 && me_piece_applies(a)) {  // the level-0 launch also zeroes the level's histograms for the predict kernel behind it
@@ -385,7 +432,7 @@ int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
     if (l == 0) lv.hist_zeroed = a.zero_words != nullptr && getenv("QSVC_ME_PIECE") == nullptr;
   }
   HIPCHK(c, hipGetLastError());
-  return QSVC_OK;
+  return g.sub ? me_subpel(c, g, lv, frames, L, nullptr) : QSVC_OK;
 }
 
 // chroma x2 planes of the even pictures frames[mul*k], k <= nB (mctf_kernels.hip: k_chroma_up)
@@ -409,6 +456,36 @@ static int predict_overlapped(qsvc_ctx* c, const LevelGeom& g, const PredArgs& a
   if (!launch_predict_overlap(c->st, a, (int16_t*)c->ovl[0].p, (int16_t*)c->ovl[1].p))
     return c->fail(QSVC_ERR_UNSUPPORTED, "block_overlaping %d with block size %d on a %dx%d picture is outside this path (power of two dividing "
                    "the block size, block + 2 x overlap <= %d, picture tiled by the block grid)", g.ov, g.bs, g.W, g.H, 96);
+  return QSVC_OK;
+}
+
+// --subpixel_accuracy in decorrelate / correlate (mctf_subpel.hip): references interpolated a times, predict() at the up-sampled
+// resolution, the prediction brought down through the low-low bands of a analysis levels, then residue / histograms as usual.
+static int predict_subpel(qsvc_ctx* c, const LevelGeom& g, const PredArgs& a) {
+  const int s = g.sub, Ha = g.H << s, Wa = g.W << s;
+  if (g.H % g.bs || g.W % g.bs)
+    return c->fail(QSVC_ERR_UNSUPPORTED, "subpixel_accuracy on a %dx%d picture the block grid (%d) does not tile: the stale margins of the reference's "
+                   "up-sampled prediction planes (Q7) are not reproduced on this path", g.W, g.H, g.bs);
+  if ((Wa > 16384 || Ha > 16384)) return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d << %d exceeds the reference's line buffer (16384)", g.W, g.H, s);
+  LevelGeom ge = g;
+  ge.W = Wa; ge.H = Ha; ge.bs = g.bs << s; ge.S = g.S << s; ge.ov = g.ov << s; ge.sub = 0;
+  const size_t upb = (size_t)(g.nB + 1) * 3 * Ha * Wa, pb = (size_t)g.nB * 3 * Ha * Wa * sizeof(int16_t);
+  int r;
+  if ((r = c->sp[0].ensure(c, upb))) return r;
+  if ((r = c->sp[1].ensure(c, upb))) return r;
+  if ((r = c->ovl[0].ensure(c, pb))) return r;
+  if ((r = c->ovl[1].ensure(c, pb))) return r;
+  const uint8_t* up = launch_sp_refs(c->st, a.frames, g, 2, g.nB + 1, s, (uint8_t*)c->sp[0].p, (uint8_t*)c->sp[1].p);
+  int16_t* p0 = (int16_t*)c->ovl[0].p; int16_t* p1 = (int16_t*)c->ovl[1].p;
+  if (ge.ov >= 2) {  // predict(block_overlaping << a, block_size << a, ...) (decorrelate.cpp:828-839)
+    PredArgs ae = a;
+    ae.g = ge; ae.up = up; ae.cup = nullptr; ae.margin = nullptr;
+    if (!launch_ovl_blocks(c->st, ae, p0, p1))
+      return c->fail(QSVC_ERR_UNSUPPORTED, "block_overlaping %d with block size %d at subpixel_accuracy %d is outside this path (block + 2 x overlap, "
+                     "both up-sampled, <= %d)", g.ov, g.bs, s, 96);
+  } else launch_sp_predict(c->st, ge, up, a.mv, p0);
+  const int16_t* res = launch_sp_down(c->st, p0, p1, g.nB * 3, g.H, g.W, s);
+  launch_pred_finish(c->st, a, res, 0);
   return QSVC_OK;
 }
 
@@ -528,7 +605,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   a.g = g; a.frames = (const uint8_t*)c->lv[t - 1].low.p; a.mv = (const int16_t*)lv.mv_raw.p;
   a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = (unsigned*)lv.hist.p;
   a.margin = nullptr; a.odd_out = nullptr; a.types = nullptr; a.cup = nullptr;
-  a.mv_copy = nullptr; a.hist_is_zero = lv.hist_zeroed ? 1 : 0;
+  a.mv_copy = nullptr; a.hist_is_zero = lv.hist_zeroed ? 1 : 0; a.up = nullptr;
   lv.hist_zeroed = false;
   lv.ragged = (g.H % bs || g.W % bs);
   if (lv.ragged) {  // Q7: the chroma margins carry state from picture to picture
@@ -537,10 +614,12 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   }
   Prof pf;
   pf.begin(c, "predict");
-  const bool fast = !lv.ragged && g.ov < 2 && pred_fast_path(a);
+  const bool fast = !lv.ragged && g.ov < 2 && !g.sub && pred_fast_path(a);
   if (fast) a.mv_copy = (int16_t*)lv.mv_filt.p;   // the fused launch also writes motion_filtered_t = motion_t
-  if (!lv.ragged && !fast && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
-  if (g.ov >= 2) {
+  if (!lv.ragged && !fast && !g.sub && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
+  if (g.sub) {
+    if ((r = predict_subpel(c, g, a))) return r;
+  } else if (g.ov >= 2) {
     if ((r = predict_overlapped(c, g, a))) return r;
   } else launch_predict(c->st, a);
   pf.end(c);
@@ -672,7 +751,7 @@ static int synth_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g, bo
   if (P < 1) return c->fail(QSVC_ERR_INVALID, "pictures %d", P);
   if (c->H < bs || c->W < bs) return c->fail(QSVC_ERR_INVALID, "picture %dx%d smaller than block_size %d", c->W, c->H, bs);
   g->W = c->W; g->H = c->H; g->bs = bs; g->BY = c->H / bs; g->BX = c->W / bs; g->S = S; g->P = P; g->nB = P / 2; g->F = c->F;
-  g->ov = c->opt_ov; g->bord = 0;
+  g->ov = c->opt_ov; g->bord = 0; g->sub = c->opt_sub;
   Level& lv = c->lv[t];
   if (need_low && lv.low_n < g->nB + 1) return c->fail(QSVC_ERR_STATE, "low_%d holds %d pictures, %d needed", t, lv.low_n, g->nB + 1);
   if (lv.high_n < g->nB || lv.mv_filt_n < g->nB || (int)lv.types.size() < g->nB || (g->nB && lv.mv_bs != bs))
@@ -741,7 +820,7 @@ int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   a.g = g; a.frames = (const uint8_t*)out.low.p; a.mv = (const int16_t*)lv.mv_filt.p;
   a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = nullptr;
   a.margin = nullptr; a.odd_out = (uint8_t*)out.low.p; a.types = (const uint8_t*)c->tmp16[0].p; a.cup = nullptr;
-  a.mv_copy = nullptr; a.hist_is_zero = 0;
+  a.mv_copy = nullptr; a.hist_is_zero = 0; a.up = nullptr;
   if (g.H % bs || g.W % bs) {  // Q7 applies to the decoder's prediction planes as well
     if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
     a.margin = (int16_t*)c->margin.p;
@@ -749,8 +828,10 @@ int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   Prof pf;
   pf.begin(c, "correlate");
   c->cup_src = nullptr;  // un_update has just rewritten the even pictures
-  if (!a.margin && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
-  if (g.ov >= 2) {
+  if (!a.margin && !g.sub && (r = make_cup(c, g, a.frames, 2, &a.cup))) return r;
+  if (g.sub) {
+    if ((r = predict_subpel(c, g, a))) return r;
+  } else if (g.ov >= 2) {
     if ((r = predict_overlapped(c, g, a))) return r;
   } else launch_predict(c->st, a);
   pf.end(c);

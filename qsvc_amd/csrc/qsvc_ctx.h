@@ -91,9 +91,11 @@ struct qsvc_ctx {
   int W = 0, H = 0;
   size_t F = 0;
   int keep_pred = 0;
-  int opt_ov = 0, opt_bord = 0;  // --block_overlaping, --border_size (qsvc_set_mctf_options)
+  int opt_ov = 0, opt_bord = 0, opt_sub = 0;  // --block_overlaping, --border_size, --subpixel_accuracy (qsvc_set_mctf_options)
   std::vector<Level> lv;
   std::vector<DevBuf> snap;  // ME pyramid snapshots per DWT level
+  DevBuf sp[2];              // --subpixel_accuracy (mctf_subpel.hip): the search's role planes at (H << a) x (W << a) + scratch; the
+                             // up-sampled references of the prediction + scratch
   DevBuf rp[2];              // Q5 geometries (mctf_replay.hip): [3 nB][H][W] int16 role planes of the literal replay + scratch
   DevBuf margin;             // Q7 chroma margin state of the level being decorrelated
   DevBuf ovl[2];             // --block_overlaping: prediction planes in the Mallat layout, [nB][3][H][W] int16 each

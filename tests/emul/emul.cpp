@@ -15,7 +15,7 @@ static LevelGeom make_geom(int P, int W, int H, int bs, int S) {
   LevelGeom g;
   g.W = W; g.H = H; g.bs = bs; g.BY = H / bs; g.BX = W / bs; g.S = S; g.P = P; g.nB = P / 2;
   g.F = (size_t)W * H + 2 * (size_t)(W / 2) * (H / 2);
-  g.ov = 0; g.bord = 0;
+  g.ov = 0; g.bord = 0; g.sub = 0;
   return g;
 }
 static int ilog2i(int s) { int l = 0; while ((1 << (l + 1)) <= s) l++; return l; }

@@ -23,7 +23,7 @@ from qsvc_amd.synth import make_clip  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-# name, kind, seed, W, H, TRLs, block_size, search_range, block_overlaping, border_size, full_dump[, subpixel_accuracy]
+# name, kind, seed, W, H, TRLs, block_size, search_range, block_overlaping, border_size, full_dump[, subpixel_accuracy[, pictures]]
 CASES = [
     ("ov2_tiny", "pan_noise", 3, 128, 96, 3, 16, 4, 2, 0, True),
     ("ov4_tiny_edge", "edge", 47, 96, 64, 3, 16, 4, 4, 0, True),
@@ -44,6 +44,7 @@ CASES = [
     ("sub1_binary", "binary", 48, 64, 64, 2, 16, 4, 0, 0, False, 1),          # every picture 'I'
     ("sub1_q5_350x286", "pan_noise", 43, 350, 286, 3, 32, 8, 0, 0, False, 1), # odd pyramid sizes (Q5) under the sub-pixel search
     ("sub2_sat_360x200", "saturating", 45, 360, 200, 4, 8, 4, 0, 0, False, 2),  # 'I' pictures among 'B' ones
+    ("sub1_q5_360x200_s32", "edge", 49, 360, 200, 2, 8, 32, 0, 0, False, 1, 5),  # Q5 (200 % 16 = 8) on a tiled grid; 5 pictures, one level
 ]
 
 
@@ -59,7 +60,7 @@ def main():
         sub = case[11] if len(case) > 11 else 0
         if only and name not in only:
             continue
-        frames = 2 ** (TRLs - 1) + 1
+        frames = case[12] if len(case) > 12 else 2 ** (TRLs - 1) + 1
         clip = make_clip(kind, frames, W, H, seed)
         levels = O.ref_analyze(clip, W, H, TRLs, bs, S, block_overlaping=ov, border_size=bord, subpixel_accuracy=sub)
         out = dict(meta=np.array([frames, W, H, TRLs, bs, S, seed, ov, bord] + ([sub] if sub else []), dtype=np.int64), kind=np.array(kind),

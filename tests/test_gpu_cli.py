@@ -216,9 +216,9 @@ def test_motion_expand_tools_from_files(oracle, tmp_path):
 
 def test_unsupported_requests_exit_nonzero(tmp_path):
     make_clip("pan", 5, 64, 64, 1).tofile(tmp_path / "low_0")
-    r = subprocess.run([MCTF, "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=3", "--subpixel_accuracy=2"],
+    r = subprocess.run([MCTF, "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=3", "--subpixel_accuracy=4"],
                        cwd=tmp_path, capture_output=True)
-    assert r.returncode != 0
+    assert r.returncode == 255
     r = subprocess.run([MCTF, "compress", "--pixels_in_x=64", "--pixels_in_y=64", "--TRLs=3", "--block_overlaping=3"],
                        cwd=tmp_path, capture_output=True)  # not a power of two: the library refuses
     assert r.returncode == 255
@@ -255,6 +255,40 @@ def test_compress_and_synthesize_with_overlap_and_border(oracle, tmp_path):
         lv = want[t - 1]
         low = oracle.synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], W, H, bs, 4 * 2 ** (t - 1), block_overlaping=2)["low"]
     np.testing.assert_array_equal(rd(tmp_path, "low_0"), low.reshape(-1))
-    # the one deferred option left is refused with the drivers' exit status
-    r = subprocess.run([MCTF, "analyze", f"--pixels_in_x={W}", f"--pixels_in_y={H}", "--subpixel_accuracy=1"], cwd=tmp_path, capture_output=True, text=True)
+    # what the library refuses ends the tool with the drivers' exit status
+    r = subprocess.run([MCTF, "analyze", f"--pixels_in_x={W}", f"--pixels_in_y={H}", "--subpixel_accuracy=5"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 255 and "subpixel_accuracy" in r.stderr
+
+
+def test_compress_and_expand_with_subpixel_accuracy(oracle, tmp_path):
+    """`mcj2k compress --subpixel_accuracy=2` (105 of the 217 call sites in trunk/tests use 2 or 3) against the restatement (pinned by
+    the compiled reference tools, tests/golden/n4_sub*.npz), then `mcj2k expand --subpixel_accuracy=2,2,2` from the code-stream alone."""
+    import glob, shutil
+    W, H, TRLs, GOPs, bs, sub = 128, 96, 3, 1, 16, 2
+    P = GOPs * 2 ** (TRLs - 1) + 1
+    clip = make_clip("pan_noise", P, W, H, 7)
+    enc = tmp_path / "enc"; dec = tmp_path / "dec"
+    enc.mkdir(); dec.mkdir()
+    clip.tofile(enc / "low_0")
+    MCJ2K = os.path.join(ROOT, "bin", "mcj2k")
+    geo = [f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLs}", f"--GOPs={GOPs}", f"--block_size={bs}", f"--block_size_min={bs}"]
+    r = subprocess.run([MCJ2K, "compress", *geo, "--SRLs=4", "--lossless=1", f"--subpixel_accuracy={sub}"], cwd=enc, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = oracle.analyze(clip, W, H, TRLs, bs, 4, subpixel_accuracy=sub)
+    plain = oracle.analyze(clip, W, H, TRLs, bs, 4)
+    assert not np.array_equal(want[0]["motion"], plain[0]["motion"])
+    for t, lv in enumerate(want, 1):
+        np.testing.assert_array_equal(rd(enc, f"motion_{t}", np.int16), lv["motion"].reshape(-1), err_msg=f"motion_{t}")
+        assert rd(enc, f"frame_types_{t}").tobytes() == lv["frame_types"]
+        np.testing.assert_array_equal(rd(enc, f"high_{t}"), lv["high"].reshape(-1), err_msg=f"high_{t}")
+        np.testing.assert_array_equal(rd(enc, f"low_{t}"), lv["low"].reshape(-1), err_msg=f"low_{t}")
+    for pat in ("*.j2c", "*.mjc", "*type*"):
+        for f in glob.glob(str(enc / pat)):
+            shutil.copy(f, dec)
+    r = subprocess.run([MCJ2K, "expand", *geo, "--SRLs=4", f"--subpixel_accuracy={sub},{sub},{sub}"], cwd=dec, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    low = want[-1]["low"]
+    for t in range(TRLs - 1, 0, -1):
+        lv = want[t - 1]
+        low = oracle.synthesize_step(low, lv["high"], lv["motion_filtered"], lv["frame_types"], W, H, bs, 4 * 2 ** (t - 1), subpixel_accuracy=sub)["low"]
+        np.testing.assert_array_equal(rd(dec, f"low_{t - 1}"), low.reshape(-1), err_msg=f"low_{t - 1}")

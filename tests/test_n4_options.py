@@ -1,5 +1,6 @@
 """SURVEY.md 8f N4 -- the reference's optional MCTF flags, pinned by goldens the compiled reference tools produced
-(tests/golden/n4_*.npz): --block_overlaping (decorrelate.cpp:84-172) and --border_size (motion_estimate.cpp:213-217,714).
+(tests/golden/n4_*.npz): --block_overlaping (decorrelate.cpp:84-172), --border_size (motion_estimate.cpp:213-217,714) and
+--subpixel_accuracy (motion_estimate.cpp:361-412, decorrelate.cpp:656-686,828-861).
 CPU: the restatement; GPU: the HIP path through the C ABI (forward levels and the inverse chain)."""
 import numpy as np
 import pytest
@@ -26,8 +27,12 @@ def test_restatement_matches_reference_goldens(oracle, name):
         assert sha(low) == str(z[f"synth_low_{t - 1}_sha"]), f"synth_low_{t - 1}"
 
 
+# sub-pixel accuracy on a picture the block grid does not tile (Q7 at the up-sampled size) is refused by the GPU path
+GPU_REFUSED = {"sub3_q7_200x120", "sub1_q5_350x286"}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", n4_cases())
+@pytest.mark.parametrize("name", [n for n in n4_cases() if n not in GPU_REFUSED])
 def test_hip_matches_reference_goldens(name):
     from qsvc_amd import hip
     z, m = load_n4(name)
@@ -36,7 +41,7 @@ def test_hip_matches_reference_goldens(name):
     e = hip.Engine(0)
     try:
         e.seq_config(W, H, keep_prediction=True)
-        e.set_mctf_options(block_overlaping=m["ov"], border_size=m["bord"])
+        e.set_mctf_options(block_overlaping=m["ov"], border_size=m["bord"], subpixel_accuracy=m["sub"])
         e.put_frames(hip.LOW, 0, clip)
         P, S, levels = m["frames"], m["S"], []
         for t in range(1, m["TRLs"]):
@@ -63,18 +68,36 @@ def test_unsupported_options_are_refused():
     try:
         e.seq_config(128, 96)
         with pytest.raises(hip.QsvcError) as ei:
-            e.set_mctf_options(subpixel_accuracy=1)
+            e.set_mctf_options(subpixel_accuracy=4)
         assert ei.value.code == -2
         with pytest.raises(hip.QsvcError):
             e.set_mctf_options(block_overlaping=3)
+        # sub-pixel accuracy: search range 1 (the reference's own motion_estimate crashes there), vectors that leave the 256-bin
+        # motion histogram, and a picture the block grid does not tile (its stale up-sampled prediction margins are not reproduced)
+        from qsvc_amd.synth import make_clip
+        e.set_mctf_options(subpixel_accuracy=2)
+        e.put_frames(hip.LOW, 0, make_clip("pan", 3, 128, 96, 1))
+        for S in (1, 32):
+            with pytest.raises(hip.QsvcError) as ei:
+                e.motion_estimate(1, 3, 16, S)
+            assert ei.value.code == -2
+        z, m = load_n4("sub3_q7_200x120")
+        e.seq_config(m["W"], m["H"])
+        e.set_mctf_options(subpixel_accuracy=m["sub"])
+        e.put_frames(hip.LOW, 0, golden_input(z, m))
+        e.motion_estimate(1, m["frames"], m["bs"], m["S"])
+        np.testing.assert_array_equal(e.get_motion(hip.MOTION_RAW, 1, m["frames"] // 2, m["bs"]), z["motion_1"])   # the search is fine
+        with pytest.raises(hip.QsvcError) as ei:
+            e.decorrelate(1, m["frames"], m["bs"], m["S"])
+        assert ei.value.code == -2
     finally:
         e.close()
 
 
 def test_subpixel_probe_record():
-    """--subpixel_accuracy > 0 stays refused.  The committed record of what the reference's own tools do with it
-    (tests/golden/make_subpel_probe.py -> subpel_probe.json): repeatable under default malloc, but motion_t itself changes with the
-    heap's fill pattern (MALLOC_PERTURB_) on every clip -- the search reads plane borders nothing ever wrote."""
+    """Why --subpixel_accuracy needs a model of the reference's heap.  The committed record of what the reference's own
+    tools do with it (tests/golden/make_subpel_probe.py -> subpel_probe.json): repeatable under default malloc, but motion_t itself
+    changes with the heap's fill pattern (MALLOC_PERTURB_) on every clip -- the search reads plane borders nothing ever wrote."""
     import json, os
     from helpers import GOLDEN
     rec = json.load(open(os.path.join(GOLDEN, "subpel_probe.json")))
