@@ -158,6 +158,8 @@ def main():
                     help="pictures of the step's sequence the single-core CPU baseline codes (2^j + 1; default: the whole sequence at "
                          "1080p, 5 at 4K).  The baseline is a reported figure, not part of the timed region; `sample` says what ran")
     ap.add_argument("--no-decode", action="store_true", help="skip the non-headline decode extra")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config4 block (one 4K 33-picture 9/7 sequence, BASELINE's \"HBM roofline run\") of the default line")
+    ap.add_argument("--no-cli", action="store_true", help="skip cli_wall_s (bin/mcj2k compress from low_0 on disk to the .j2c files)")
     ap.add_argument("--no-iso", action="store_true", help="skip the single-sequence pass (profiling runs: exactly warmup + steps encodes per session)")
     ap.add_argument("--clip", default="pan_noise")
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
@@ -223,26 +225,32 @@ def main():
     dev = os.environ.get("QSVC_BENCH_DEVICE")  # test hook: several ranks on one GPU (forces the host-staged exchange)
     devno = int(dev) if dev is not None else (local if world > 1 else 0)
     engs = [hip.Engine(devno) for _ in range(S)]
+    # The motion-field coding (compress.py:197-212) runs on the sequence's own context, between the analysis and the textures, as in the
+    # reference.  QSVC_BENCH_MOTION=beside is the experiment of round 4: a second context per sequence codes the motion beside the texture
+    # coding (measured: 4 450 instead of 6 830 fps with 12 sequences in flight, 14.4 instead of 8.4 ms for one sequence alone -- the two
+    # contexts' streams get in each other's way more than the 1.7 ms serial chain they could hide)
+    mv_engs = [hip.Engine(devno) for _ in range(S)] if os.environ.get("QSVC_BENCH_MOTION", "inline") == "beside" else [None] * S
     for e in engs:
         e.set_tier2_threads(t2_timed)  # an explicit per-context setting (include/qsvc_hip.h), not an environment variable read mid-run
     eng = engs[0]
-    real_exchange, exchange_kind = [None] * S, "none"
+    transport, exchange_kind = None, "none"
     if world > 1:
         import torch
-        # RCCL over xGMI, one communicator per session; the ids travel through gloo.  Every rank takes the same branch
-        # at every step, so a failure anywhere degrades ALL ranks to the host-staged transport (a transport fallback,
-        # never a compute fallback).
+        # RCCL over xGMI: ONE communicator per rank (held by session 0's context), whatever the number of sequences in flight -- their
+        # halo records of a level travel as one message per neighbour (qsvc_halo_exchange_batch).  The id travels through gloo.  Every
+        # rank takes the same branch at every step, so a failure anywhere degrades ALL ranks to the host-staged transport (a
+        # transport fallback, never a compute fallback).
         uids = [None]
         if rank == 0 and dev is None and os.environ.get("QSVC_EXCHANGE", "rccl") == "rccl":
             try:
-                uids = [[hip.Engine.comm_unique_id() for _ in range(S)]]
+                uids = [hip.Engine.comm_unique_id()]
             except Exception as ex:
                 log(f"[rank 0] RCCL unavailable ({ex})")
         dist.broadcast_object_list(uids, src=0)
         ok = 0
         if uids[0] is not None:
             try:
-                real_exchange = [sharding.RcclExchange(engs[k], rank, world, uids[0][k]) for k in range(S)]
+                transport = sharding.RcclExchange(engs[0], rank, world, uids[0])
                 ok = 1
             except Exception as ex:
                 log(f"[rank {rank}] qsvc_comm_init failed ({ex})")
@@ -251,42 +259,15 @@ def main():
         if flag.item() == 1:
             exchange_kind = "rccl"
         else:
-            real_exchange = [sharding.HostExchange(dist, rank, world) for _ in range(S)]
+            transport = sharding.HostExchange(dist, rank, world)
             exchange_kind = "gloo-host"
 
     prm = CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=TRLS, GOPs=GOPS, block_size=BS, block_size_min=BS,
                          search_range=S0, SRLs=SRLS, lossless=bool(args.reversible), reversible=bool(args.reversible), nLayers=1)
 
-    class Lockstep:
-        """All sessions of this rank reach the level's exchange point together; ONE thread then runs the sessions'
-        exchanges one after the other, so every rank issues its collectives in the same order.  A session that dies
-        aborts the barrier (threading.BrokenBarrierError in the others) instead of leaving them waiting."""
-        def __init__(self):
-            self.args = [None] * S
-            self.bar = threading.Barrier(S, action=self._run, timeout=300)
-            self.err = None
-
-        def _run(self):
-            try:
-                for k in range(S):
-                    e, t, bs = self.args[k]
-                    real_exchange[k].exchange(e, t, bs)
-            except Exception as ex:  # noqa: BLE001
-                self.err = ex
-
-        def proxy(self, k):
-            outer = self
-
-            class P:
-                def exchange(self, e, t, bs):
-                    outer.args[k] = (e, t, bs)
-                    outer.bar.wait()
-                    if outer.err is not None:
-                        raise outer.err
-            return P()
-
-    lock = Lockstep() if world > 1 else None
-    comps = [Compressor(engs[k], copy.deepcopy(prm), lock.proxy(k) if lock else None) for k in range(S)]
+    # all sequences of this rank reach a level's exchange point together; the last one runs ONE batched exchange for all of them
+    lock = sharding.BatchExchange(transport, engs) if world > 1 else None
+    comps = [Compressor(engs[k], copy.deepcopy(prm), lock.member(k) if lock else None, mv_engs[k]) for k in range(S)]
     comp = comps[0]
     P = comp.pictures
     # weak scaling: rank r holds pictures [16r, 16r+16] of one long synthetic sequence (boundary picture shared)
@@ -320,16 +301,24 @@ def main():
     low_first = 0 if rank == 0 else 1  # the shared boundary picture of low_T is coded by the left shard
     nbytes_of = [0] * S
 
-    phase = {"analyze_calls_return": 0.0, "texture_call": 0.0, "n": 0}  # wall clock of session 0's two calls (diagnostic)
+    phase = {"analyze_calls_return": 0.0, "motion_call": 0.0, "texture_call": 0.0, "n": 0}  # wall clock of session 0's calls (diagnostic)
+
+    mv_bytes_of = [0] * S
 
     def step(k):
         t_a = time.perf_counter()
         comps[k].analyze()
         t_b = time.perf_counter()
+        # compress.py:197-212: the motion fields are coded between the analysis and the texture coding (decorrelators on the host, the
+        # 16-bit component planes of all levels in one lossless JPEG 2000 batch on the GPU)
+        fut = comps[k].motion_async()
+        t_c = time.perf_counter()
         out = comps[k].texture(low_first, copy=False)  # code-streams stay in the engine's host buffer (no Python copies)
+        _, mcs = fut.result()
         if k == 0:
-            phase["analyze_calls_return"] += t_b - t_a; phase["texture_call"] += time.perf_counter() - t_b; phase["n"] += 1
+            phase["analyze_calls_return"] += t_b - t_a; phase["motion_call"] += t_c - t_b; phase["texture_call"] += time.perf_counter() - t_c; phase["n"] += 1
         nbytes_of[k] = sum(len(c) for v in out.values() for c in v)
+        mv_bytes_of[k] = sum(len(c) for v in mcs.values() for c in v)
 
     failures = []
 
@@ -343,7 +332,7 @@ def main():
             except BaseException as ex:  # noqa: BLE001
                 failures.append((k, repr(ex)))
                 if lock is not None:
-                    lock.bar.abort()
+                    lock.abort()
         if S == 1:
             work(0)
         else:
@@ -411,7 +400,7 @@ def main():
     for e in engs:
         e.set_profiling(True)
     barrier()
-    phase.update(analyze_calls_return=0.0, texture_call=0.0, n=0)
+    phase.update(analyze_calls_return=0.0, motion_call=0.0, texture_call=0.0, n=0)
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
@@ -458,16 +447,28 @@ def main():
         # context that holds nothing but the streams, the filtered motion and the frame types.  Wall clock from streams in host
         # memory to low_0 in HBM; the decoded planes make the host round trip the C ABI's decode entry point implies.
         try:
+            from qsvc_amd import motion as motion_chain
             e0 = engs[0]
             comp.analyze()
+            _, mcs = comp.motion()
+            mcs = {t: [bytes(c) for c in v] for t, v in mcs.items()}
             out = comp.texture(0, copy=True)
-            side = {t: (e0.get_motion(hip.MOTION_FILTERED, t, Pt // 2, bst), bytes(e0.get_frame_types(t, Pt // 2))) for (t, Pt, St, bst) in comp.levels}
+            types = {t: bytes(e0.get_frame_types(t, Pt // 2)) for (t, Pt, St, bst) in comp.levels}
             items = [(hip.HIGH, t, Pt // 2) for (t, Pt, St, bst) in comp.levels] + [(hip.LOW, comp.levels[-1][0], comp.levels[-1][1] // 2 + 1)]
             streams = [cs for (kind, t, n) in items for cs in out[(kind, t)]]
             dec = hip.Engine(devno)
             dec.seq_config(W, H)
 
             def decode_once():
+                # motion_expand.py: the residues of every level from their code-streams (one batch), then the two correlators
+                mplanes = dec.j2k_decode_planes([cs for (t, Pt, St, bst) in comp.levels for cs in mcs[t]])
+                res, k = {}, 0
+                for (t, Pt, St, bst) in comp.levels:
+                    nf, BY, BX = Pt // 2, H // bst, W // bst
+                    comps4 = np.stack(mplanes[k:k + 4 * nf]).reshape(nf, 4, BY, BX).transpose(1, 0, 2, 3)
+                    res[t] = motion_chain.mux_components(np.ascontiguousarray(comps4))
+                    k += 4 * nf
+                fields = motion_chain.field_chain(res, TRLS)
                 planes = dec.j2k_decode_planes(streams)
                 k = 0
                 for (kind, t, n) in items:
@@ -477,8 +478,8 @@ def main():
                         k += 3
                     dec.put_frames(kind, t, fr)
                 for (t, Pt, St, bst) in comp.levels:
-                    dec.put_motion(hip.MOTION_FILTERED, t, side[t][0], bst)
-                    dec.put_frame_types(t, side[t][1])
+                    dec.put_motion(hip.MOTION_FILTERED, t, fields[t], bst)
+                    dec.put_frame_types(t, types[t])
                 for (t, Pt, St, bst) in reversed(comp.levels):
                     dec.synthesize_step(t, Pt, bst, St)
                 dec.sync()
@@ -496,10 +497,61 @@ def main():
             #  v + r * update_factor and is not an exact inverse, update.cpp:93-115 -- hence a PSNR, not an equality)
             decode_extra = {"ms_per_sequence": round(dms, 3), "frames_per_s": round(P / (dms * 1e-3), 1), "pictures": P,
                             "psnr_vs_input_db": round(99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse), 2),
-                            "what": "JPEG 2000 decode of all subband pictures (one batch) + inverse MCTF to low_0; one sequence, streams in host "
-                                    "memory -> pictures in HBM; first correct form of the decoder (not tuned)"}
+                            "what": "what `mcj2k expand` does: the motion residues from their code-streams + the two correlators, JPEG 2000 decode "
+                                    "of all subband pictures (one batch), inverse MCTF to low_0; one sequence, streams in host memory -> pictures in HBM"}
         except Exception as ex:  # an extra: never fail the headline on it
             decode_extra = {"error": repr(ex)}
+
+    # ---- extras of the default line (rank 0, one GPU, config 3): the drop-in executable including disk I/O, and BASELINE's configs[3] ----
+    cli_wall, config4 = None, None
+    if rank == 0 and world == 1 and args.config == 3 and not args.no_cli:
+        # SURVEY.md 8d(1) "including disk I/O": `bin/mcj2k compress` on this very configuration, from low_0 on disk to the code-stream
+        # files, as a fresh process each time (interpreter start, library load and GPU initialisation included, as for the reference's
+        # tools).  First run = cold; then the default form (every intermediate the reference's stages leave behind is written:
+        # even_t, odd_t, high_t, low_t, motion_t, prediction_even_t) and the lean form (--keep_intermediates=0: only the code-stream).
+        import shutil, subprocess, tempfile
+        try:
+            d = tempfile.mkdtemp(prefix="qsvc_cli_", dir="/tmp")
+            variant(seq_local, 0).tofile(os.path.join(d, "low_0"))
+            cmd = [os.path.join(ROOT, "bin", "mcj2k"), "compress", f"--pixels_in_x={W}", f"--pixels_in_y={H}", f"--TRLs={TRLS}", f"--GOPs={GOPS}",
+                   f"--block_size={BS}", f"--block_size_min={BS}", f"--SRLs={SRLS}", f"--search_range={S0}",
+                   "--lossless=1" if args.reversible else "--nLayers=1"]
+            walls = []
+            for extra in ([], [], ["--keep_intermediates=0"]):
+                for f in os.listdir(d):
+                    if f != "low_0":
+                        os.remove(os.path.join(d, f))
+                t1 = time.perf_counter()
+                rr = subprocess.run(cmd + extra, cwd=d, capture_output=True, text=True, timeout=600)
+                walls.append(time.perf_counter() - t1)
+                if rr.returncode != 0:
+                    raise RuntimeError(rr.stderr[-300:])
+            nfiles = len([f for f in os.listdir(d) if f.endswith(".j2c")])
+            shutil.rmtree(d, ignore_errors=True)
+            cli_wall = {"cold_s": round(walls[0], 3), "warm_s": round(walls[1], 3), "warm_code_stream_only_s": round(walls[2], 3), "pictures": P,
+                        "frames_per_s_warm": round(P / walls[1], 2), "j2c_files": nfiles, "command": " ".join(["mcj2k"] + cmd[1:]),
+                        "what": "wall clock of one fresh `mcj2k compress` process: low_0 read from disk, MCTF + motion coding + texture coding on the "
+                                "GPU, every output file written; cold = first run on this box; code_stream_only = --keep_intermediates=0"}
+        except Exception as ex:  # an extra: never fail the headline on it
+            cli_wall = {"error": repr(ex)}
+    if rank == 0 and world == 1 and args.config == 3 and not args.no_config4:
+        # BASELINE.json configs[3] ("4K 32-frame GOP, 9/7 irreversible, 4 temporal + 5 spatial levels, HBM roofline run"): ONE 33-picture
+        # sequence alone on the chip, 1 warm-up + 3 timed encodes, with its isolated streaming-kernel table -- in a child process (the
+        # globals of this one describe config 3), after this one has released its contexts
+        import subprocess
+        for e in engs + [m for m in mv_engs if m is not None]:
+            e.close()
+        engs, mv_engs = [], []
+        try:
+            rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "4", "--sessions", "1", "--steps", "3", "--warmup", "1",
+                                 "--no-cpu-baseline", "--no-decode", "--no-cli", "--no-config4"], capture_output=True, text=True, timeout=900)
+            c4 = json.loads(rr.stdout.strip().splitlines()[-1])
+            config4 = {k: c4[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "codeblocks_per_s", "roofline",
+                                          "roofline_streaming", "kernels") if k in c4}
+            config4["workload"] = c4["config"]["workload"]
+            config4["sequences_in_flight"] = 1
+        except Exception as ex:
+            config4 = {"error": repr(ex)}
 
     if rank == 0:
         pics_total = (G * world + 1) * S   # unique pictures per step: S independent sequences of G*N+1 pictures
@@ -531,27 +583,39 @@ def main():
         except Exception:
             pass
 
+        # kernels whose long streams are read 16 bytes per lane: on gfx950 FETCH_SIZE reports HALF of such a stream
+        # (MI355X_MICROARCH.md, HBM counters); the MQ front reads its decisions as uint4, the context modelling its magnitude rows and
+        # the gather its segments the same way.  Their own data confirm it: k_t1_cm2 writes 278 MB of decisions per sequence and the MQ
+        # kernel's raw fetch is 146 MB.
+        WIDE16 = ("k_t1_mq_pipe", "k_t1_mq<", "k_t1_cm2", "k_gather")
+
         def traffic_of(prefixes):
-            """HBM bytes per step (= one encode of one sequence) of a kernel group: FETCH_SIZE + WRITE_SIZE of every kernel whose
-            name starts with one of `prefixes`, summed over the launches of one encode (tools/pmc_summary.py: hbm_bytes_per_step_raw).
-            RAW sums: none of these kernels reads 16 bytes per lane in long streams (the one pattern MI355X_MICROARCH.md says
-            FETCH_SIZE halves); calibration on a kernel with exactly known byte counts is described in DESIGN.md 6."""
+            """HBM bytes per step (= one encode of one sequence) of a kernel group: FETCH_SIZE + WRITE_SIZE of every kernel whose name
+            starts with one of `prefixes`, summed over the launches of one encode (tools/pmc_summary.py), with the fetch DOUBLED for the
+            kernels of WIDE16 and raw for the others (1-, 4- and 8-byte accesses: calibrated on a kernel with exactly known byte counts,
+            DESIGN.md 6)."""
             tot, seen = 0, False
             for kn, e in pmc.items():
                 if any(kn.startswith(px) for px in prefixes) and "hbm_bytes_per_step_raw" in e:
                     seen = True
                     tot += e["hbm_bytes_per_step_raw"]
+                    if kn.startswith(WIDE16):
+                        tot += e["fetch_bytes_per_launch_raw"] * e["launches_profiled"] / max(e.get("encodes_profiled", 5), 1)
             return int(tot) if seen else None
 
         dom = "j2k_t1_mq"
         a = alg[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e9 if dom in per and per[dom]["ms_per_step"] > 0 else 0.0
         mq_traffic = traffic_of([mq_symbol]) or traffic_of(["k_t1_mq_pipe<64, 4, 196, 144>"])
+        cm_traffic = traffic_of(["k_t1_cm2"])
         roof = {"kernel": dom, "kernel_symbol": mq_symbol, "bound": "hbm", "achieved": round(a, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(a / HBM_PEAK_GBS, 6),
                 "traffic": mq_traffic,
-                "traffic_source": ("profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE per launch, separate passes, one sequence in flight: the "
-                                   "pipeline in its default form, the same loads and stores as the small-LDS form)") if mq_traffic is not None
+                "traffic_source": ("profiles/" + PMC_FILE + " (2 x FETCH_SIZE + WRITE_SIZE per launch: the kernel reads its decisions 16 bytes per "
+                                   "lane, the pattern FETCH_SIZE halves on gfx950; separate passes, one sequence in flight)") if mq_traffic is not None
                                   else "missing (kernel symbol not in profiles/" + PMC_FILE + ")",
+                "tier1_traffic": (mq_traffic + cm_traffic) if (mq_traffic is not None and cm_traffic is not None) else None,
+                "tier1_traffic_note": "context modelling (k_t1_cm2) + MQ coder together, fetch doubled for both: the one-byte-per-decision "
+                                      "round trip through HBM on top of the algorithmic bytes",
                 "launch_ms": per.get(dom, {}).get("ms_per_step"), "algorithmic_bytes_per_launch": int(alg[dom]),
                 "algorithmic_bytes": f"SURVEY.md 8d: {ncb_step} code-blocks x 4096 coefficients x {coef_bytes} B + emitted code bytes, one launch per step",
                 "note": "the launch with the largest share of the step; EBCOT Tier-1 is serial-dependency bound, not HBM bound (SURVEY.md H4/8d): "
@@ -574,7 +638,7 @@ def main():
                                 "algorithmic_bytes_per_step": int(alg[k]), "achieved_GBs": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4),
                                 "traffic": traffic_of(prefixes)}
             streaming["note"] = ("isolated = one sequence in flight, HIP events on the context's stream around each kernel group; traffic = HBM bytes "
-                                 "per step from profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE, raw; null = not in that file); ME is ALU-bound "
+                                 "per step from profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE, raw: 1/4/8-byte accesses; null = not in that file); ME is ALU-bound "
                                  "by design (SURVEY.md 8d), its fraction is quoted for completeness")
         t1ms = sum(per.get(k, {}).get("ms_per_step", 0) for k in ("j2k_t1_cm", "j2k_t1_mq"))
         line = {
@@ -591,11 +655,16 @@ def main():
                        "pictures_per_step_total": pics_total, "sequences_in_flight_per_gpu": S,
                        "parallelism": f"gop-shard x{world}", "halo_exchange": exchange_kind,
                        "rccl_ranks": world if exchange_kind == "rccl" else 0, "shard_check": shard_check,
+                       "rccl_communicators_per_rank": 1 if exchange_kind == "rccl" else 0,
+                       "halo_messages_per_level_per_neighbour": 1 if world > 1 else 0,
+                       "host_threads_per_rank": {"session": S, "motion_coding": S if mv_engs and mv_engs[0] is not None else 0, "tier2_workers": S * t2_timed},
+                       "contexts_per_sequence": 2 if mv_engs and mv_engs[0] is not None else 1,
                        "host_cores_pinned": args.host_cores or None,
                        "tier2_threads_per_context": t2_timed, "host_cpus": len(os.sched_getaffinity(0))},
             "codeblocks_per_s": round(ncb_step * world * S * args.steps / dt, 1),
             "ebcot_codeblocks_per_s_kernel": round(ncb_step / (t1ms * 1e-3), 1) if t1ms else None,
-            "codestream_bytes_per_step": int(nbytes), "codestream_bytes_per_step_all_sessions": int(sum(nbytes_of)), "mq_symbols_per_step": int(stats["symbols"]),
+            "codestream_bytes_per_step": int(nbytes), "codestream_bytes_per_step_all_sessions": int(sum(nbytes_of)),
+            "motion_codestream_bytes_per_step": int(mv_bytes_of[0]), "mq_symbols_per_step": int(stats["symbols"]),
             "kernels": per, "host_stages": host, "session0_calls_ms": phase_timed, "roofline": roof, "roofline_streaming": streaming,
         }
         if serial_ms is not None:
@@ -604,6 +673,10 @@ def main():
                                        "kernels_ms_isolated": {k: round(v[0], 4) for k, v in iso.items()}}
         if decode_extra is not None:
             line["decode"] = decode_extra
+        if cli_wall is not None:
+            line["cli_wall_s"] = cli_wall
+        if config4 is not None:
+            line["config4"] = config4
         line["kernels_note"] = ("kernels{} are HIP-event durations on session 0's stream inside the timed region; with several sessions in "
                                 "flight kernels of different sessions overlap, so they do not sum to ms_per_step; host_stages{} are wall-clock "
                                 "milliseconds of the CPU stages of session 0 (rate allocation, Tier-2)")
@@ -616,7 +689,7 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
-    for e in engs:
+    for e in engs + [m for m in mv_engs if m is not None]:
         e.close()
     if dist is not None:
         dist.barrier()

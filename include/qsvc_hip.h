@@ -133,6 +133,17 @@ int qsvc_comm_destroy(qsvc_ctx* ctx);
 /* ncclGroupStart; send/recv the halo records of level t with ranks r-1 and r+1; ncclGroupEnd; then
  * import what arrived.  Call between qsvc_decorrelate and qsvc_update. */
 int qsvc_halo_exchange(qsvc_ctx* ctx, int t);
+/* The same for the n contexts ONE rank keeps in flight on one GPU (n independent sequences, one context each; same picture size
+ * and block size): their records travel as ONE message of n records per neighbour.  ctxs[0] owns the batch buffers and, for the
+ * RCCL transport, the rank's only communicator (qsvc_comm_init on ctxs[0] alone): a rank needs one communicator however many
+ * sequences it codes at once.  Streams are ordered with events: every context packs on its own stream, the message leaves on
+ * ctxs[0]'s stream after all of them, and every context's update waits for the arrival.
+ * Host-staged: export side s of all n contexts into dst (qsvc_halo_batch_bytes bytes), import what the neighbour's export of the
+ * other side produced (NULL: no neighbour on that side). */
+size_t qsvc_halo_batch_bytes(qsvc_ctx* const* ctxs, int n, int t);
+int qsvc_halo_batch_export_host(qsvc_ctx* const* ctxs, int n, int t, int side, void* dst_host);
+int qsvc_halo_batch_import_host(qsvc_ctx* const* ctxs, int n, int t, int side, const void* src_host);
+int qsvc_halo_exchange_batch(qsvc_ctx* const* ctxs, int n, int t);
 
 /* ---- truncating 5/3 (unit-testable; used by the ME pyramid and the chroma x2 / /2 steps) ---- */
 /* replaces dwt2d<short,_5_3>::analyze / ::synthesize (dwt2d.cpp:76-175, 5_3.cpp:39-115) on a HOST
@@ -172,6 +183,16 @@ int qsvc_j2k_encode_plane(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, con
  * (motion_compress_j2k.py:131-142).  prm->reversible must be 1 and prm->levels 0.  offs[nplanes+1]. */
 int qsvc_j2k_encode_planes_s16(qsvc_ctx* ctx, const int16_t* planes, int nplanes, int H, int W, const qsvc_j2k_params* prm,
                                uint8_t* out, size_t cap, size_t* offs);
+/* replaces the motion-field coding chain of `mctf compress` (compress.py:197-212 -> motion_compress.py:146-186: one
+ * interlevel_motion_decorrelate process per level, bidirectional_motion_decorrelate on the coarsest, then motion_compress_j2k.py:98-142:
+ * demux / split and one kdu_compress per component plane) for the levels ts[0] < ts[1] < ... whose motion_filtered_t is resident,
+ * fields[k] fields each, one block size: residues on the host (the fields are kilobytes), every component plane of every level coded
+ * lossless in one batch.  out: the 4 * sum(fields) code-streams back to back in (level, field, component) order,
+ * offs[4 * sum(fields) + 1]; residues (optional): the motion_residue_t files' contents, levels back to back.
+ * filtered_host (optional): the fields themselves (levels back to back, the motion_filtered_t files' contents) instead of the
+ * context's resident ones -- a second context can then code the motion of a sequence while the first codes its textures. */
+int qsvc_motion_encode(qsvc_ctx* ctx, int nlevels, const int* ts, const int* fields, int block_size, const int16_t* filtered_host,
+                       int16_t* residues, uint8_t* out, size_t cap, size_t* offs);
 /* Unit-testable transform: level shift + `levels` of forward DWT of a host 8-bit plane, Mallat layout.
  * out receives H*W int32 (reversible 5/3) or H*W float32 (irreversible 9/7, before quantisation). */
 int qsvc_j2k_dwt(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, int reversible, int levels, void* out);

@@ -308,6 +308,12 @@ static int upload_if_changed(qsvc_ctx* c, void* dev, const void* src, size_t byt
 }
 
 void j2k_release(qsvc_ctx* c) {
+  if (c->j2k_mv) {  // the motion planes' state first (same teardown)
+    J2kState* keep = c->j2k;
+    c->j2k = c->j2k_mv; c->j2k_mv = nullptr;
+    j2k_release(c);
+    c->j2k = keep;
+  }
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->llA, &s->llB, &s->sbtab_d, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->outbuf, &s->res_d, &s->plen_d,
@@ -551,7 +557,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     launch_t1_nbps(c->st, (const CbDesc*)S.cbs_d.p, ncb, (int*)S.nbps_d.p, (int*)S.err_d.p);
     pf.end(c);
   } else {  // Clevels = 0 (motion-field planes): level shift, then quantise + pack per code-block
-    pf.begin(c, "j2k_t1_pack");
+    pf.begin(c, src[0].s16 ? "mv_t1_pack" : "j2k_t1_pack");
     launch_level_shift(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, S.coefA.p, rev);
     launch_t1_pack_blk(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (unsigned long long*)S.mags.p,
                        (int*)S.nbps_d.p, (int*)S.err_d.p, rev);
@@ -660,7 +666,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
       if ((r = S.t1tabs_d.ensure(c, T1_TABLES_BYTES))) return r;
       launch_t1_tables(c->st, (uint8_t*)S.t1tabs_d.p);
     }
-    pf.begin(c, "j2k_t1_cm");
+    pf.begin(c, src[0].s16 ? "mv_t1_cm" : "j2k_t1_cm");
     for (int k = 0; k < nparts; k++) {
       if (njobs && cut[k + 1] > cut[k])  // one context-modelling wave per block, its bit-planes one after the other (plane p = job joboff[block] + p)
         launch_t1_cm2(c->st, (const CbDesc*)S.cbs_d.p, ncb, nbp, (const int*)S.joboff_d.p, (const int*)S.order_d.p + cut[k],
@@ -674,7 +680,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
       }
     }
     pf.end(c);
-    pf.begin(c, "j2k_t1_mq");  // (with parts: what of the MQ stage is left after the last part's context modelling)
+    pf.begin(c, src[0].s16 ? "mv_t1_mq" : "j2k_t1_mq");  // (motion planes: their own segment names)  // (with parts: what of the MQ stage is left after the last part's context modelling)
     mq_part(c->st, nparts - 1);
     for (int k = 0; k + 1 < nparts; k++) HIPCHK(c, hipStreamWaitEvent(c->st, S.mq_done[k], 0));
     pf.end(c);
@@ -689,7 +695,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     {
       const auto w0 = std::chrono::steady_clock::now();
       HIPCHK(c, hipStreamSynchronize(c->st));
-      c->host_time("host_wait_tier1", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+      c->host_time(src[0].s16 ? "host_mv_wait_tier1" : "host_wait_tier1", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
     }
     HIPCHK(c, hipGetLastError());
     if (err & 2) return c->fail(QSVC_ERR_HIP, "internal: the MQ coder's wave pair lost step (a wait gave up)");
@@ -719,7 +725,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     if (hipHostMalloc((void**)&S.gath_h, want, hipHostMallocDefault) != hipSuccess) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%zu)", want);
     S.gath_h_cap = want;
   }
-  pf.begin(c, "j2k_gather");
+  pf.begin(c, src[0].s16 ? "mv_gather" : "j2k_gather");
   HIPCHK(c, hipMemcpyAsync(S.offs_d.p, goffs.data(), (size_t)ncb * 8, hipMemcpyHostToDevice, c->st));
   HIPCHK(c, hipMemcpyAsync(S.lens_d.p, glens.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
   launch_gather(c->st, (const uint8_t*)S.outbuf.p, J2K_OUTCAP, (const unsigned long long*)S.offs_d.p, (const int*)S.lens_d.p, ncb,
@@ -781,6 +787,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     // environment is not consulted while other contexts' threads may be changing it), else 8; never more than planes
     if (!c->t2_default) { const char* e = getenv("QSVC_T2_THREADS"); int v = e ? atoi(e) : 8; c->t2_default = v < 1 ? 1 : (v > 64 ? 64 : v); }
     int t2_want = c->t2_threads > 0 ? c->t2_threads : c->t2_default;
+    if (src[0].s16 && t2_want > 2) t2_want = 2;  // motion planes: kilobytes per stream, their state keeps at most one worker thread
     if (t2_want > np) t2_want = np;
     if (t2_want < 1) t2_want = 1;
     if (S.pool && S.pool->nworkers != t2_want - 1) { delete S.pool; S.pool = nullptr; }  // rebuilt only when the count changes
@@ -819,7 +826,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     HIPCHK(c, hipGetLastError());
     for (int p = 0; p < np; p++) if (rc2[p] != rc[p]) return c->fail(QSVC_ERR_HIP, "internal: Tier-2 length of plane %d changed between the passes", p);
     t2_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2b_begin).count();
-    c->host_time("host_tier2", t2_ms);
+    c->host_time(src[0].s16 ? "host_mv_tier2" : "host_tier2", t2_ms);
   }
   return QSVC_OK;
 }
@@ -924,6 +931,12 @@ int qsvc_j2k_encode_planes_s16(qsvc_ctx* c, const int16_t* planes, int nplanes, 
                                uint8_t* out, size_t cap, size_t* offs) {
   if (!c || !planes || !prm || !out || !offs || nplanes < 1 || W < 1 || H < 1 || W > 16384 || H > 16384) return QSVC_ERR_INVALID;
   (void)hipSetDevice(c->dev);
+  // the motion planes have their own encoder state: a texture batch before and after finds its tables, job lists and buffers as it left them
+  struct Swap {
+    qsvc_ctx* c;
+    explicit Swap(qsvc_ctx* c_) : c(c_) { std::swap(c->j2k, c->j2k_mv); }
+    ~Swap() { std::swap(c->j2k, c->j2k_mv); }
+  } swap_state(c);
   if (!c->j2k) c->j2k = new J2kState();
   size_t bytes = (size_t)nplanes * W * H * 2;
   int r = c->j2k->up_d.ensure(c, bytes);

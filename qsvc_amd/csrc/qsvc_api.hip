@@ -111,7 +111,8 @@ void qsvc_destroy(qsvc_ctx* c) {
   free_seq(c);
   for (auto& b : c->snap) b.release();
   c->mvtmp[0].release(); c->mvtmp[1].release(); c->rp[0].release(); c->rp[1].release(); c->sp[0].release(); c->sp[1].release();
-  for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); }
+  for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); c->halo_btx[s_].release(); c->halo_brx[s_].release(); }
+  if (c->halo_ev) (void)hipEventDestroy(c->halo_ev);
   c->margin.release(); c->cup.release(); c->ovl[0].release(); c->ovl[1].release();
   if (c->comm) qsvc_comm_destroy(c);
   c->scal.release(); c->allB.release(); c->tmp16[0].release(); c->tmp16[1].release(); c->hhist.release();
@@ -858,7 +859,8 @@ static int halo_ragged(qsvc_ctx* c, int t) {
   return c->lv[t].ragged ? c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d is not a multiple of the block size: its prediction margins depend "
                                    "on every earlier picture of the level, the sequence cannot be split across GPUs", c->W, c->H) : QSVC_OK;
 }
-static int halo_pack(qsvc_ctx* c, int t, int side) {
+// dst: where the record goes (device), or nullptr: the context's own send buffer of that side
+static int halo_pack(qsvc_ctx* c, int t, int side, uint8_t* dst = nullptr) {
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   if (int rr = halo_ragged(c, t)) return rr;
   Level& lv = c->lv[t];
@@ -866,9 +868,11 @@ static int halo_pack(qsvc_ctx* c, int t, int side) {
   if (nB < 1 || lv.mv_filt_n < nB || (int)lv.types.size() < nB) return c->fail(QSVC_ERR_STATE, "nothing to export for t=%d", t);
   int i = side == 0 ? 0 : nB - 1;
   size_t fld = (size_t)(c->H / lv.mv_bs) * (c->W / lv.mv_bs), mvb = 4 * fld * sizeof(int16_t);
-  int r = c->halo_tx[side].ensure(c, c->F + mvb + 16);
-  if (r) return r;
-  uint8_t* d = (uint8_t*)c->halo_tx[side].p;
+  if (!dst) {
+    int r = c->halo_tx[side].ensure(c, c->F + mvb + 16);
+    if (r) return r;
+  }
+  uint8_t* d = dst ? dst : (uint8_t*)c->halo_tx[side].p;
   HIPCHK(c, hipMemcpyAsync(d, (uint8_t*)lv.high.p + (size_t)i * c->F, c->F, hipMemcpyDeviceToDevice, c->st));
   HIPCHK(c, hipMemcpyAsync(d + c->F, (uint8_t*)lv.mv_filt.p + (size_t)i * mvb, mvb, hipMemcpyDeviceToDevice, c->st));
   memset(c->halo_tb[side], 0, 16);
@@ -980,6 +984,178 @@ int qsvc_halo_exchange(qsvc_ctx* c, int t) {
   lv.halo[0] = left ? c->halo_rx[0].p : nullptr;
   lv.halo[1] = right ? c->halo_rx[1].p : nullptr;
   return QSVC_OK;
+}
+
+// ---- batched exchange: the records of n contexts of ONE rank (its sequences in flight) as one message per neighbour ----------
+// ctxs[0] owns the batch buffers (and, for the RCCL transport, the rank's only communicator).  Every context packs its record on its
+// own stream into its slot of the batch; the owner's stream waits for all of them before the message leaves, and every context's
+// stream waits for the arrival before its update reads the slot it was given.  All contexts: same device, geometry and block size.
+static int batch_check(qsvc_ctx* const* cs, int n, int t, size_t* rec) {
+  if (!cs || n < 1 || !cs[0]) return QSVC_ERR_INVALID;
+  qsvc_ctx* o = cs[0];
+  if (t < 1 || t > QSVC_MAX_T) return o->fail(QSVC_ERR_INVALID, "temporal subband %d out of range", t);
+  if (!o->lv[t].mv_bs) return o->fail(QSVC_ERR_STATE, "halo exchange before decorrelate of t=%d", t);
+  *rec = qsvc_halo_bytes(o, o->lv[t].mv_bs);
+  for (int k = 0; k < n; k++) {
+    qsvc_ctx* c = cs[k];
+    if (!c) return o->fail(QSVC_ERR_INVALID, "null context in the batch");
+    if (c->dev != o->dev || c->W != o->W || c->H != o->H || c->lv[t].mv_bs != o->lv[t].mv_bs)
+      return o->fail(QSVC_ERR_INVALID, "contexts of one halo batch must share the device, the picture size and the block size (context %d differs)", k);
+    if (!c->halo_ev && hipEventCreateWithFlags(&c->halo_ev, hipEventDisableTiming) != hipSuccess) return o->fail(QSVC_ERR_HIP, "hipEventCreate");
+  }
+  return QSVC_OK;
+}
+// every context's record of `side` into the owner's send batch; on return the owner's stream is ordered behind all of them
+static int batch_pack(qsvc_ctx* const* cs, int n, int t, int side, size_t rec) {
+  qsvc_ctx* o = cs[0];
+  int r = o->halo_btx[side].ensure(o, (size_t)n * rec);
+  if (r) return r;
+  for (int k = 0; k < n; k++) {
+    if ((r = halo_pack(cs[k], t, side, (uint8_t*)o->halo_btx[side].p + (size_t)k * rec))) { if (k) o->err = cs[k]->err; return r; }
+    HIPCHK(o, hipEventRecord(cs[k]->halo_ev, cs[k]->st));
+    if (k) HIPCHK(o, hipStreamWaitEvent(o->st, cs[k]->halo_ev, 0));
+  }
+  return QSVC_OK;
+}
+// the owner's receive batch of `side` has been written on the owner's stream: every context takes its slot (or none: no neighbour)
+static int batch_take(qsvc_ctx* const* cs, int n, int t, int side, size_t rec, bool present) {
+  qsvc_ctx* o = cs[0];
+  if (present) HIPCHK(o, hipEventRecord(o->halo_ev, o->st));
+  for (int k = 0; k < n; k++) {
+    cs[k]->lv[t].halo[side] = present ? (uint8_t*)o->halo_brx[side].p + (size_t)k * rec : nullptr;
+    if (present && k) HIPCHK(o, hipStreamWaitEvent(cs[k]->st, o->halo_ev, 0));
+  }
+  return QSVC_OK;
+}
+size_t qsvc_halo_batch_bytes(qsvc_ctx* const* ctxs, int n, int t) {
+  size_t rec = 0;
+  return batch_check(ctxs, n, t, &rec) ? 0 : (size_t)n * rec;
+}
+int qsvc_halo_batch_export_host(qsvc_ctx* const* ctxs, int n, int t, int side, void* dst) {
+  size_t rec = 0;
+  int r = batch_check(ctxs, n, t, &rec);
+  if (r) return r;
+  qsvc_ctx* o = ctxs[0];
+  if (!dst || (side != 0 && side != 1)) return o->fail(QSVC_ERR_INVALID, "bad halo batch export arguments");
+  (void)hipSetDevice(o->dev);
+  if ((r = batch_pack(ctxs, n, t, side, rec))) return r;
+  HIPCHK(o, hipMemcpyAsync(dst, o->halo_btx[side].p, (size_t)n * rec, hipMemcpyDeviceToHost, o->st));
+  HIPCHK(o, hipStreamSynchronize(o->st));
+  return QSVC_OK;
+}
+int qsvc_halo_batch_import_host(qsvc_ctx* const* ctxs, int n, int t, int side, const void* src) {
+  size_t rec = 0;
+  int r = batch_check(ctxs, n, t, &rec);
+  if (r) return r;
+  qsvc_ctx* o = ctxs[0];
+  if (side != 0 && side != 1) return o->fail(QSVC_ERR_INVALID, "bad halo side %d", side);
+  (void)hipSetDevice(o->dev);
+  for (int k = 0; k < n; k++) { int rr_ = qsvc_resolve(ctxs[k]); if (rr_) return rr_; }
+  if (src) {
+    if ((r = o->halo_brx[side].ensure(o, (size_t)n * rec))) return r;
+    // (the slots may still be read by the previous level's update of any context: their streams are joined first)
+    for (int k = 1; k < n; k++) { HIPCHK(o, hipEventRecord(ctxs[k]->halo_ev, ctxs[k]->st)); HIPCHK(o, hipStreamWaitEvent(o->st, ctxs[k]->halo_ev, 0)); }
+    HIPCHK(o, hipMemcpyAsync(o->halo_brx[side].p, src, (size_t)n * rec, hipMemcpyHostToDevice, o->st));
+    HIPCHK(o, hipStreamSynchronize(o->st));  // the caller's buffer is free on return
+  }
+  return batch_take(ctxs, n, t, side, rec, src != nullptr);
+}
+int qsvc_halo_exchange_batch(qsvc_ctx* const* ctxs, int n, int t) {
+  size_t rec = 0;
+  int r = batch_check(ctxs, n, t, &rec);
+  if (r) return r;
+  qsvc_ctx* o = ctxs[0];
+  if (!o->comm) return o->fail(QSVC_ERR_STATE, "qsvc_comm_init not called on the batch's first context");
+  (void)hipSetDevice(o->dev);
+  const bool nb[2] = {o->rank > 0, o->rank + 1 < o->nranks};
+  for (int s = 0; s < 2; s++)
+    if (nb[s]) {
+      if ((r = o->halo_brx[s].ensure(o, (size_t)n * rec))) return r;
+      if ((r = batch_pack(ctxs, n, t, s, rec))) return r;
+    }
+  const int ncclUint8 = 1;
+  int e = g_rccl.GroupStart();
+  for (int s = 0; s < 2 && !e; s++)
+    if (nb[s]) {
+      const int peer = s == 0 ? o->rank - 1 : o->rank + 1;
+      e = g_rccl.Send(o->halo_btx[s].p, (size_t)n * rec, ncclUint8, peer, o->comm, o->st);
+      if (!e) e = g_rccl.Recv(o->halo_brx[s].p, (size_t)n * rec, ncclUint8, peer, o->comm, o->st);
+    }
+  int e2 = g_rccl.GroupEnd();
+  if (e || e2) return o->fail(QSVC_ERR_HIP, "RCCL halo exchange (batch of %d): %s", n, g_rccl.GetErrorString(e ? e : e2));
+  for (int s = 0; s < 2; s++)
+    if ((r = batch_take(ctxs, n, t, s, rec, nb[s]))) return r;
+  return QSVC_OK;
+}
+
+// ---- motion-field coding chain (compress.py:197-212 -> motion_compress.py:146-186 -> motion_compress_j2k.py:98-142) ---------
+// One call for what the reference spreads over TRLs - 1 decorrelator processes, a demux / split pipeline and one kdu_compress per
+// component plane: the resident motion_filtered_t of the levels ts[0] < ts[1] < ... come to the host (kilobytes), every level but the
+// last is predicted from the level above (residue = field - reference / 2 with C division, two fields per reference field, the
+// last reference kept when the file ends: interlevel_motion_decorrelate.cpp:32-70,249-283), the last level is decorrelated
+// bidirectionally (NEXT -= PREV, bidirectional_motion_decorrelate.cpp:25-52), the planar residue file is cut as the reference's
+// `demux 8 2c 2 | split` cuts it (component c of a field = every 4th int16, phase c: motion_compress_j2k.py:103-107), and all
+// component planes of all levels are coded lossless in ONE batch.  Streams in (level, field, component) order.
+int qsvc_motion_encode(qsvc_ctx* c, int nlevels, const int* ts, const int* fields, int block_size, const int16_t* filtered_host,
+                       int16_t* residues, uint8_t* out, size_t cap, size_t* offs) {
+  if (!c || !ts || !fields || !out || !offs || nlevels < 1 || block_size < 1) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
+  (void)hipSetDevice(c->dev);
+  if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+  const int BY = c->H / block_size, BX = c->W / block_size;
+  const size_t fld = (size_t)BY * BX, per = 4 * fld;
+  size_t total = 0;
+  for (int k = 0; k < nlevels; k++) {
+    const int t = ts[k];
+    if (t < 1 || t > QSVC_MAX_T || fields[k] < 0 || (k && ts[k] <= ts[k - 1])) return c->fail(QSVC_ERR_INVALID, "bad level list");
+    const Level& lv = c->lv[t];
+    if (!filtered_host && (lv.mv_filt_n < fields[k] || (fields[k] && lv.mv_bs != block_size)))
+      return c->fail(QSVC_ERR_STATE, "motion_filtered_%d holds %d fields at block size %d (asked for %d at %d)", t, lv.mv_filt_n, lv.mv_bs, fields[k], block_size);
+    total += (size_t)fields[k];
+  }
+  if (!total) { offs[0] = 0; return QSVC_OK; }
+  std::vector<int16_t> filt(total * per), planes(total * per);
+  size_t o = 0;
+  if (filtered_host) memcpy(filt.data(), filtered_host, total * per * sizeof(int16_t));
+  else {
+    for (int k = 0; k < nlevels; k++) {
+      if (fields[k]) HIPCHK(c, hipMemcpyAsync(filt.data() + o, c->lv[ts[k]].mv_filt.p, (size_t)fields[k] * per * sizeof(int16_t), hipMemcpyDeviceToHost, c->st));
+      o += (size_t)fields[k] * per;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+  }
+  // residues, in place of the fields (a level's reference is the NEXT level's field, still unmodified: levels in ascending order)
+  o = 0;
+  for (int k = 0; k < nlevels; k++) {
+    int16_t* f = filt.data() + o;
+    const size_t on = o + (size_t)fields[k] * per;
+    if (k + 1 < nlevels) {
+      const int16_t* ref = filt.data() + on;
+      const int nref = fields[k + 1];
+      for (int i = 0; i < fields[k]; i++) {
+        const int r = i / 2 < nref ? i / 2 : nref - 1;  // past the end of the reference file the tool keeps the last field it read
+        int16_t* d = f + (size_t)i * per;
+        if (r >= 0) { const int16_t* q = ref + (size_t)r * per; for (size_t j = 0; j < per; j++) d[j] = (int16_t)(d[j] - q[j] / 2); }
+      }
+    } else {
+      for (int i = 0; i < fields[k]; i++) {
+        int16_t* d = f + (size_t)i * per;
+        for (size_t j = 0; j < 2 * fld; j++) d[2 * fld + j] = (int16_t)(d[2 * fld + j] - d[j]);  // NEXT-X -= PREV-X, NEXT-Y -= PREV-Y
+      }
+    }
+    o = on;
+  }
+  if (residues) memcpy(residues, filt.data(), total * per * sizeof(int16_t));
+  for (size_t i = 0; i < total; i++) {  // the byte cut of the planar file: component c = every 4th int16 of the field
+    const int16_t* s = filt.data() + i * per;
+    int16_t* d = planes.data() + i * per;
+    for (int comp = 0; comp < 4; comp++)
+      for (size_t j = 0; j < fld; j++) d[(size_t)comp * fld + j] = s[4 * j + comp];
+  }
+  qsvc_j2k_params prm;
+  memset(&prm, 0, sizeof prm);
+  prm.reversible = 1; prm.levels = 0; prm.layers = 1; prm.cblk_w = 64; prm.cblk_h = 64; prm.use_sop = 1; prm.base_step = 1.0f / 256;
+  return qsvc_j2k_encode_planes_s16(c, planes.data(), (int)(total * 4), BY, BX, &prm, out, cap, offs);
 }
 
 // ---- truncating 5/3 on a host plane ---------------------------------------------------------------

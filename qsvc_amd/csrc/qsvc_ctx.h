@@ -104,6 +104,8 @@ struct qsvc_ctx {
   DevBuf mvtmp[2], scal, tmp16[2];
   DevBuf allB;   // QSVC_ALLB_MAX bytes of 'B': frame_types_t of a level without 'I' pictures, already on the device
   DevBuf halo_tx[2], halo_rx[2];  // boundary records: [0] left neighbour, [1] right neighbour
+  DevBuf halo_btx[2], halo_brx[2];  // batched exchange (qsvc_halo_batch_*): n records back to back, owned by the batch's first context
+  hipEvent_t halo_ev = nullptr;   // this context's record is packed / the batch's records have arrived
   uint8_t halo_tb[2][16];
   void* comm = nullptr;            // ncclComm_t (RCCL), line topology
   int rank = 0, nranks = 1;
@@ -120,6 +122,8 @@ struct qsvc_ctx {
   std::vector<HostSeg> hsegs;
   void host_time(const char* name, double ms);
   J2kState* j2k = nullptr;
+  J2kState* j2k_mv = nullptr;    // a second encoder state for the motion-field planes (qsvc_j2k_encode_planes_s16): `mctf compress` codes them
+                                 // between the analysis and the textures of every sequence, and the texture state's resident tables stay valid
   J2kDecState* j2kdec = nullptr;
   int fail(int code, const char* fmt, ...);
   int hipfail(hipError_t e, const char* what);

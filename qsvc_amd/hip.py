@@ -21,8 +21,9 @@ SYMBOLS = [
     "qsvc_set_mctf_options", "qsvc_put_frames", "qsvc_get_frames", "qsvc_put_motion", "qsvc_get_motion", "qsvc_put_frame_types",
     "qsvc_get_frame_types", "qsvc_get_histograms", "qsvc_motion_estimate", "qsvc_decorrelate", "qsvc_update",
     "qsvc_analyze_step", "qsvc_un_update", "qsvc_correlate", "qsvc_synthesize_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
-    "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_dwt53_trunc",
-    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_stats", "qsvc_set_tier2_threads", "qsvc_set_profiling", "qsvc_get_timings",
+    "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_halo_batch_bytes", "qsvc_halo_batch_export_host", "qsvc_halo_batch_import_host",
+    "qsvc_halo_exchange_batch", "qsvc_dwt53_trunc",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_motion_encode", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_stats", "qsvc_set_tier2_threads", "qsvc_set_profiling", "qsvc_get_timings",
 ]
 
 
@@ -77,12 +78,17 @@ def load_library() -> C.CDLL:
     L.qsvc_comm_init.argtypes = [vp, i, i, vp, C.c_size_t]
     L.qsvc_comm_destroy.argtypes = [vp]
     L.qsvc_halo_exchange.argtypes = [vp, i]
+    L.qsvc_halo_batch_bytes.argtypes = [C.POINTER(vp), i, i]; L.qsvc_halo_batch_bytes.restype = C.c_size_t
+    L.qsvc_halo_batch_export_host.argtypes = [C.POINTER(vp), i, i, i, vp]
+    L.qsvc_halo_batch_import_host.argtypes = [C.POINTER(vp), i, i, i, vp]
+    L.qsvc_halo_exchange_batch.argtypes = [C.POINTER(vp), i, i]
     L.qsvc_dwt53_trunc.argtypes = [vp, i16p, i, i, i, i, i]
     L.qsvc_j2k_encode_frames.argtypes = [vp, i, i, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_encode_multi.argtypes = [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                         C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_encode_plane.argtypes = [vp, u8p, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_encode_planes_s16.argtypes = [vp, i16p, i, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.qsvc_motion_encode.argtypes = [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_int), i, vp, vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_dwt.argtypes = [vp, u8p, i, i, i, i, vp]
     L.qsvc_j2k_decode_planes.argtypes = [vp, i, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i, vp, C.c_size_t, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -230,6 +236,34 @@ class Engine:
     def halo_exchange(self, t):
         self._chk(self.L.qsvc_halo_exchange(self.h, t))
 
+    # ---- the records of several contexts of one rank as one message per neighbour (engines[0] owns buffers and communicator)
+    @staticmethod
+    def _handles(engines):
+        return (C.c_void_p * len(engines))(*[e.h for e in engines])
+
+    @staticmethod
+    def halo_batch_export(engines, t, side) -> np.ndarray:
+        e0, hs = engines[0], Engine._handles(engines)
+        n = e0.L.qsvc_halo_batch_bytes(hs, len(engines), t)
+        buf = np.empty(n, dtype=np.uint8)
+        e0._chk(e0.L.qsvc_halo_batch_export_host(hs, len(engines), t, side, buf.ctypes.data))
+        return buf
+
+    @staticmethod
+    def halo_batch_import(engines, t, side, data):
+        e0, hs = engines[0], Engine._handles(engines)
+        if data is None:
+            e0._chk(e0.L.qsvc_halo_batch_import_host(hs, len(engines), t, side, None))
+            return
+        a = np.ascontiguousarray(data, dtype=np.uint8)
+        assert a.size == e0.L.qsvc_halo_batch_bytes(hs, len(engines), t)
+        e0._chk(e0.L.qsvc_halo_batch_import_host(hs, len(engines), t, side, a.ctypes.data))
+
+    @staticmethod
+    def halo_exchange_batch(engines, t):
+        e0 = engines[0]
+        e0._chk(e0.L.qsvc_halo_exchange_batch(Engine._handles(engines), len(engines), t))
+
     # ---- transforms
     def dwt53_trunc(self, plane: np.ndarray, levels: int, inverse=False) -> np.ndarray:
         p = np.ascontiguousarray(plane, dtype=np.int16).copy()
@@ -294,6 +328,37 @@ class Engine:
         self._chk(self.L.qsvc_j2k_encode_planes_s16(self.h, p.ctypes.data, n, H, W, C.byref(params), out.ctypes.data, cap, offs))
         o = list(offs)
         return [out[o[k]:o[k + 1]].tobytes() for k in range(n)]
+
+    def motion_encode(self, levels, block_size, want_residues=False, copy=True, filtered=None):
+        """levels: [(t, fields)] in ascending t -> ({t: [code-stream per (field, component)]}, {t: motion_residue_t} or None): the whole
+        motion-field coding chain of `mctf compress` in one call (qsvc_motion_encode).  filtered: {t: motion_filtered_t} from the host
+        instead of this context's resident fields."""
+        levels = [(t, f) for (t, f) in levels]
+        n = len(levels)
+        BY, BX = self.H // block_size, self.W // block_size
+        total = sum(f for _, f in levels)
+        ts, fs = (C.c_int * n)(*[t for t, _ in levels]), (C.c_int * n)(*[f for _, f in levels])
+        cap = total * 4 * (BY * BX * 4 + 4096) + 4096
+        if getattr(self, "_mv_out", None) is None or self._mv_out.size < cap:
+            self._mv_out = np.empty(cap, dtype=np.uint8)
+        out = self._mv_out
+        offs = (C.c_size_t * (4 * total + 1))()
+        res = np.empty((total, 4, BY, BX), dtype=np.int16) if want_residues else None
+        fh = None
+        if filtered is not None:
+            fh = np.ascontiguousarray(np.concatenate([np.asarray(filtered[t], dtype=np.int16).reshape(f, 4, BY, BX) for t, f in levels]))
+        self._chk(self.L.qsvc_motion_encode(self.h, n, ts, fs, block_size, fh.ctypes.data if fh is not None else None,
+                                            res.ctypes.data if res is not None else None, out.ctypes.data, out.size, offs))
+        o = list(offs)
+        mv = memoryview(out)
+        streams, residues, k, r = {}, ({} if want_residues else None), 0, 0
+        for t, f in levels:
+            streams[t] = [out[o[k + j]:o[k + j + 1]].tobytes() if copy else mv[o[k + j]:o[k + j + 1]] for j in range(4 * f)]
+            k += 4 * f
+            if want_residues:
+                residues[t] = res[r:r + f]
+                r += f
+        return streams, residues
 
     def j2k_dwt(self, plane: np.ndarray, reversible: bool, levels: int) -> np.ndarray:
         p = np.ascontiguousarray(plane, dtype=np.uint8)

@@ -45,8 +45,12 @@ class CompressParams:  # defaults of compress.py:57-106
 
 
 class Compressor:
-    def __init__(self, engine, params: CompressParams, exchange=None):
+    def __init__(self, engine, params: CompressParams, exchange=None, motion_engine=None):
         self.e = engine
+        # a second context of the same GPU for the motion-field coding: its (short, serial) Tier-1 chain then runs beside the texture
+        # coding of the same sequence instead of in front of it (motion_async)
+        self.me = motion_engine
+        self._pool = None
         self.p = params.resolve()
         self.exchange = exchange
         self.levels = schedule.level_schedule(self.p.GOPs, self.p.TRLs, self.p.block_size, self.p.block_size_min, self.p.search_range)
@@ -92,7 +96,43 @@ class Compressor:
         streams = self.e.j2k_encode_multi(items, copy=copy)  # one batch: every subband picture of the sequence
         return {(it[0], it[1]): s for it, s in zip(items, streams)}
 
-    def compress(self):
+    # compress.py:197-212 -> motion_compress.py:146-186 -> motion_compress_j2k.py:98-142
+    def motion(self, want_residues=False, copy=True):
+        """The motion-field coding chain on the device-resident filtered fields, one native call (qsvc_motion_encode): inter-level /
+        bidirectional decorrelation on the host side of the library (the fields are kilobytes), the reference's demux cut, and the
+        lossless coding of every 16-bit component plane of every level in ONE batch on the GPU.
+        -> ({t: motion_residue_t} or None, {t: [code-stream per (field, component)]})."""
+        if not self.levels:
+            return ({} if want_residues else None), {}
+        if self.p.block_size > self.p.block_size_min and len(self.levels) > 1:
+            raise NotImplementedError("motion_compress with a shrinking block size (motion_compress.py:159-166 quirk) is not reproduced")
+        streams, res = self.e.motion_encode([(t, P // 2) for (t, P, S, bs) in self.levels], self.p.block_size, want_residues, copy)
+        return res, streams
+
+    def motion_async(self):
+        """compress.py:197-212 codes the motion between the analysis and the textures; the two are independent.  With a motion engine:
+        the filtered fields come to the host (kilobytes) and a worker thread codes them on the second context while the caller goes on
+        to texture(); returns a future of motion()'s result.  Without one: motion() now, wrapped in a finished future."""
+        from concurrent.futures import Future, ThreadPoolExecutor
+        if self.me is None or not self.levels:
+            f = Future()
+            f.set_result(self.motion(copy=False))
+            return f
+        from .hip import MOTION_FILTERED
+        lv = [(t, P // 2) for (t, P, S, bs) in self.levels]
+        filt = {t: self.e.get_motion(MOTION_FILTERED, t, n, self.p.block_size) for (t, n) in lv}
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=1)
+            self.me.seq_config(self.p.pixels_in_x, self.p.pixels_in_y)
+
+        def work():
+            streams, _ = self.me.motion_encode(lv, self.p.block_size, False, False, filtered=filt)
+            return None, streams
+        return self._pool.submit(work)
+
+    def compress(self, with_motion=False):
         if self.p.TRLs > 1:
             self.analyze()
+            if with_motion:
+                self.motion()
         return self.texture()

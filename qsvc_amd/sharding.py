@@ -10,6 +10,8 @@ data-path communication (the JPEG 2000 stage is embarrassingly parallel).
 Two transports for the halo records:
   RcclExchange ...... device-to-device over xGMI through the C ABI (qsvc_comm_init / qsvc_halo_exchange)
   HostExchange ...... host-staged over any torch.distributed backend (gloo on CPU-only test machines)
+A rank that keeps several sequences in flight on its GPU (one engine each) sends their records as ONE message per neighbour:
+exchange_batch(engines, t, block_size) -- one communicator per rank (held by engines[0]) however many sequences it codes at once.
 """
 from __future__ import annotations
 
@@ -28,6 +30,9 @@ class RcclExchange:
 
     def exchange(self, engine, t, block_size):
         engine.halo_exchange(t)
+
+    def exchange_batch(self, engines, t, block_size):
+        type(engines[0]).halo_exchange_batch(engines, t)
 
 
 class HostExchange:
@@ -53,3 +58,60 @@ class HostExchange:
                 w.wait()
         for side, buf in rx.items():
             engine.halo_import(t, side, buf.numpy())
+
+    def exchange_batch(self, engines, t, block_size):
+        """The records of all the rank's engines as one message per neighbour (the layout the RCCL batch sends)."""
+        import torch
+        E = type(engines[0])
+        ops, rx = [], {}
+        for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
+            if peer < 0 or peer >= self.world:
+                E.halo_batch_import(engines, t, side, None)
+                continue
+            tx = torch.from_numpy(np.ascontiguousarray(E.halo_batch_export(engines, t, side)))
+            rx[side] = torch.empty(tx.numel(), dtype=torch.uint8)
+            ops.append(self.dist.P2POp(self.dist.isend, tx, peer))
+            ops.append(self.dist.P2POp(self.dist.irecv, rx[side], peer))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        for side, buf in rx.items():
+            E.halo_batch_import(engines, t, side, buf.numpy())
+
+
+class BatchExchange:
+    """The sequences one rank keeps in flight (one engine and host thread each) reach a level's exchange point together; the LAST
+    one to arrive runs ONE batched exchange for all of them (transport.exchange_batch: one message per neighbour), so every rank
+    issues exactly one exchange per level whatever its number of sequences, in the same order on every rank.  A sequence that fails
+    breaks the barrier for the others instead of leaving them waiting."""
+
+    def __init__(self, transport, engines, timeout=300):
+        import threading
+        self.transport, self.engines = transport, list(engines)
+        self.args = [None] * len(self.engines)
+        self.error = None
+        self.bar = threading.Barrier(len(self.engines), action=self._run, timeout=timeout)
+
+    def _run(self):
+        try:
+            ts = {a[0] for a in self.args}
+            bss = {a[1] for a in self.args}
+            if len(ts) != 1 or len(bss) != 1:
+                raise RuntimeError(f"sequences of one rank reached different exchange points: levels {ts}, block sizes {bss}")
+            self.transport.exchange_batch(self.engines, ts.pop(), bss.pop())
+        except Exception as ex:  # noqa: BLE001
+            self.error = ex
+
+    def abort(self):
+        self.bar.abort()
+
+    def member(self, k):
+        outer = self
+
+        class Member:
+            def exchange(self, engine, t, block_size):
+                outer.args[k] = (t, block_size)
+                outer.bar.wait()
+                if outer.error is not None:
+                    raise outer.error
+        return Member()

@@ -52,6 +52,22 @@ class FakeEngine:
     def halo_import(self, t, side, rec):
         self.halo[t][side] = None if rec is None else np.ascontiguousarray(rec, dtype=np.uint8).copy()
 
+    # the batch entry points of hip.Engine (records of several engines back to back)
+    @staticmethod
+    def halo_batch_export(engines, t, side):
+        bs = engines[0].H // engines[0].mv_filt[t].shape[2]
+        return np.concatenate([e.halo_export(t, side, bs) for e in engines])
+
+    @staticmethod
+    def halo_batch_import(engines, t, side, data):
+        if data is None:
+            for e in engines:
+                e.halo_import(t, side, None)
+            return
+        parts = np.split(np.ascontiguousarray(data, dtype=np.uint8), len(engines))
+        for e, rec in zip(engines, parts):
+            e.halo_import(t, side, rec)
+
     def update(self, t, P, bs, uf=0.25):
         def h(side):
             rec = self.halo[t][side]

@@ -279,3 +279,24 @@ def test_dwt_entry_point_between_two_encodes_of_one_geometry(eng):
     np.testing.assert_array_equal(eng.j2k_dwt(other, True, 2), J.coefficients(other, True, 2))
     b = eng.j2k_encode_plane(pl, p)
     assert a == b == J.encode_plane(pl, reversible=True, levels=3)
+
+
+def test_native_motion_coding_chain_equals_the_host_modules(eng):
+    """qsvc_motion_encode (the whole motion-field coding chain of `mctf compress` in one call) == qsvc_amd/motion.py, which is pinned by
+    the reference's own decorrelators (tests/test_motion_host.py), + the restatement's lossless coder on every component plane."""
+    from qsvc_amd import hip, motion
+    from qsvc_amd.pipeline import CompressParams, Compressor
+    W, H, bs, TRLs = 128, 96, 16, 4
+    comp = Compressor(eng, CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=TRLs, GOPs=1, block_size=bs, block_size_min=bs, SRLs=3, lossless=True))
+    comp.configure(); comp.load(make_clip("edge", comp.pictures, W, H, 12))
+    comp.analyze()
+    res, streams = comp.motion(want_residues=True)
+    filt = {t: eng.get_motion(hip.MOTION_FILTERED, t, P // 2, bs) for (t, P, S, b) in comp.levels}
+    assert any(np.abs(f).max() > 0 for f in filt.values())
+    want = motion.residue_chain(filt, TRLs, bs, bs)
+    for t in want:
+        np.testing.assert_array_equal(res[t], want[t], err_msg=f"motion_residue_{t}")
+        comps = motion.demux_components(want[t])
+        for n in range(want[t].shape[0]):
+            for c in range(4):
+                assert streams[t][4 * n + c] == J.encode_plane_s16(comps[c, n]), (t, n, c)
