@@ -298,90 +298,6 @@ __device__ __forceinline__ int d_anysig(const uint8_t* fl, int y, int x) {
   return (DFL(y, x - 1) | DFL(y, x + 1) | DFL(y - 1, x) | DFL(y + 1, x) | DFL(y - 1, x - 1) | DFL(y - 1, x + 1) | DFL(y + 1, x - 1) | DFL(y + 1, x + 1)) & DF_SIG;
 }
 
-// flags: [ncb][66*66] u8 (zeroed), lastp: [ncb][64*64] u8, coef: the planes (int32 magnitudes while decoding, zeroed)
-__global__ void __launch_bounds__(64) k_t1_decode(const DecCb* cbs, int ncb, const uint8_t* segs, uint8_t* flags, uint8_t* lastp_all, void* coefv) {
-  __shared__ uint8_t s_ctx[19 * 64];
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= ncb) return;
-  const DecCb cb = cbs[b];
-  uint8_t* fl = flags + (size_t)b * 66 * 66;
-  uint8_t* lastp = lastp_all + (size_t)b * 64 * 64;
-  int32_t* mag = (int32_t*)coefv + cb.plane_off + (size_t)cb.y0 * cb.W + cb.x0;  // row stride cb.W
-  const int w = cb.w, h = cb.h, orient = cb.orient, W = cb.W;
-  MqDec m;
-  m.init(segs + cb.seg, cb.len, s_ctx + threadIdx.x);
-  int np = 0;
-#define DEC_SIGN(y, x) do { int xb_, cx_ = d_sc(fl, (y), (x), &xb_); int s_ = m.decode(cx_) ^ xb_; DFL((y), (x)) |= (uint8_t)(DF_SIG | (s_ ? DF_NEG : 0)); } while (0)
-  for (int p = cb.nbps - 1; p >= 0 && np < cb.npasses; p--) {
-    if (p != cb.nbps - 1) {
-      for (int y0 = 0; y0 < h; y0 += 4)
-        for (int x = 0; x < w; x++)
-          for (int y = y0; y < y0 + 4 && y < h; y++) {
-            const uint8_t f = DFL(y, x);
-            if ((f & DF_SIG) || !d_anysig(fl, y, x)) continue;
-            if (m.decode(d_zc(fl, y, x, orient))) { mag[(size_t)y * W + x] |= 1 << p; DEC_SIGN(y, x); }
-            lastp[y * 64 + x] = (uint8_t)p;
-            DFL(y, x) |= DF_VISIT;
-          }
-      if (++np >= cb.npasses) break;
-      for (int y0 = 0; y0 < h; y0 += 4)
-        for (int x = 0; x < w; x++)
-          for (int y = y0; y < y0 + 4 && y < h; y++) {
-            const uint8_t f = DFL(y, x);
-            if (!(f & DF_SIG) || (f & DF_VISIT)) continue;
-            const int cx = (f & DF_REFINED) ? 16 : (d_anysig(fl, y, x) ? 15 : 14);
-            if (m.decode(cx)) mag[(size_t)y * W + x] |= 1 << p;
-            lastp[y * 64 + x] = (uint8_t)p;
-            DFL(y, x) |= DF_REFINED;
-          }
-      if (++np >= cb.npasses) break;
-    }
-    for (int y0 = 0; y0 < h; y0 += 4)
-      for (int x = 0; x < w; x++) {
-        int y = y0;
-        if (y0 + 3 < h) {
-          bool run = true;
-          for (int k = 0; k < 4; k++)
-            if ((DFL(y0 + k, x) & (DF_SIG | DF_VISIT)) || d_anysig(fl, y0 + k, x)) { run = false; break; }
-          if (run) {
-            if (!m.decode(17)) { for (int k = 0; k < 4; k++) lastp[(y0 + k) * 64 + x] = (uint8_t)p; continue; }
-            int first = m.decode(18) << 1;
-            first |= m.decode(18);
-            for (int k = 0; k < first; k++) lastp[(y0 + k) * 64 + x] = (uint8_t)p;
-            y = y0 + first;
-            mag[(size_t)y * W + x] |= 1 << p; lastp[y * 64 + x] = (uint8_t)p;
-            DEC_SIGN(y, x);
-            y++;
-          }
-        }
-        for (; y < y0 + 4 && y < h; y++) {
-          const uint8_t f = DFL(y, x);
-          if (f & (DF_SIG | DF_VISIT)) continue;
-          if (m.decode(d_zc(fl, y, x, orient))) { mag[(size_t)y * W + x] |= 1 << p; DEC_SIGN(y, x); }
-          lastp[y * 64 + x] = (uint8_t)p;
-        }
-      }
-    np++;
-    for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++) DFL(y, x) &= (uint8_t)~DF_VISIT;
-  }
-#undef DEC_SIGN
-  // dequantise in place (E.1.1.2, r = 1/2 for the bit-planes that were not decoded; r = 0 for a fully decoded reversible sample)
-  for (int y = 0; y < h; y++)
-    for (int x = 0; x < w; x++) {
-      const int mg = mag[(size_t)y * W + x];
-      if (!mg) continue;
-      const int pl = lastp[y * 64 + x], neg = DFL(y, x) & DF_NEG;
-      if (cb.rev) {
-        const int v = mg + (pl > 0 ? (1 << (pl - 1)) : 0);
-        mag[(size_t)y * W + x] = neg ? -v : v;
-      } else {
-        const float v = __fmul_rn(__fadd_rn((float)mg, pl > 0 ? (float)(1 << (pl - 1)) : 0.5f), cb.delta);
-        ((float*)mag)[(size_t)y * W + x] = neg ? -v : v;
-      }
-    }
-}
-
 // Round 3 form of the block decoder.  The decoding direction is serial per block and its control flow is data dependent at every
 // sample (which pass a sample belongs to, run mode, renormalisation shifts), so lanes that decode different blocks in one wave
 // each pay for every other lane's path: with 64 blocks per wave the wave executed the union of 64 control flows (measured:
@@ -608,22 +524,14 @@ extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* 
   if (ncb) {
     if ((r = S.cbs_d.ensure(c, (size_t)ncb * sizeof(DecCb)))) return r;
     if ((r = S.segs_d.ensure(c, segs.size() + 16))) return r;
-    if ((r = S.flags_d.ensure(c, (size_t)ncb * 66 * 66))) return r;
     if ((r = S.lastp_d.ensure(c, (size_t)ncb * 64 * 64))) return r;
     HIPCHK(c, hipMemcpyAsync(S.cbs_d.p, cbs.data(), (size_t)ncb * sizeof(DecCb), hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(S.segs_d.p, segs.data(), segs.size(), hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemsetAsync(S.lastp_d.p, 0, (size_t)ncb * 64 * 64, c->st));
     pf.begin(c, "j2k_t1_decode");
-    static const bool lds_env = [] { const char* e = getenv("QSVC_DEC_LDS"); return !(e && e[0] == '0'); }();
-    if (lds_env) {
-      hipLaunchKernelGGL(k_t1_decode_lds, dim3((ncb + DEC_LANES - 1) / DEC_LANES), dim3(64), 0, c->st, (const DecCb*)S.cbs_d.p, ncb,
-                         (const uint8_t*)S.segs_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p, 0, DEC_LANES);
-      hipLaunchKernelGGL(k_dec_dequant, dim3(ncb), dim3(256), 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.lastp_d.p, S.coefA.p);
-    } else {
-      HIPCHK(c, hipMemsetAsync(S.flags_d.p, 0, (size_t)ncb * 66 * 66, c->st));
-      hipLaunchKernelGGL(k_t1_decode, dim3((ncb + 63) / 64), dim3(64), 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.segs_d.p,
-                         (uint8_t*)S.flags_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p);
-    }
+    hipLaunchKernelGGL(k_t1_decode_lds, dim3((ncb + DEC_LANES - 1) / DEC_LANES), dim3(64), 0, c->st, (const DecCb*)S.cbs_d.p, ncb,
+                       (const uint8_t*)S.segs_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p, 0, DEC_LANES);
+    hipLaunchKernelGGL(k_dec_dequant, dim3(ncb), dim3(256), 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.lastp_d.p, S.coefA.p);
     pf.end(c);
   }
   // inverse DWT, levels L .. 1: horizontal (A -> B) then vertical (B -> A); samples outside the level's region are not touched,

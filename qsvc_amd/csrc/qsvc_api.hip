@@ -363,15 +363,14 @@ static int me_replay(qsvc_ctx* c, const LevelGeom& g, Level& lv, const uint8_t* 
   return QSVC_OK;
 }
 
-int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
-  if (!c) return QSVC_ERR_INVALID;
+static int motion_estimate_impl(qsvc_ctx* c, int t, int P, int bs, int S) {
   (void)hipSetDevice(c->dev);
   LevelGeom g;
   int r = level_geom(c, t, P, bs, S, &g);
   if (r) return r;
   int lg = ilog2_exact(S);
   if (lg < 0 || S > 128) return c->fail(QSVC_ERR_UNSUPPORTED, "search_range %d is not a power of two <= 128", S);
-  if (!c->pending.empty() && !c->resolving) c->calls.push_back({0, t, P, bs, S, 0, 0.0f});
+  if (!c->pending.empty() && !c->resolving) c->spec_call = true;
   int L = lg - 1 < 0 ? 0 : lg - 1;  // motion_estimate.cpp:277 (search ranges 1 and 2: dwt_levels <= 0, one search on the pictures)
   // the level-l search state equals the l-level analysis only while every intermediate size is even; otherwise (Q5) the
   // reference's own analyse / synthesise walk is replayed literally (me_replay below)
@@ -581,11 +580,17 @@ int qsvc_resolve(qsvc_ctx* c) {
     }
   }
   c->resolving = false;
+  if (r && redo_level) {
+    // a replay failed: what the levels from redo_level up hold was computed from the speculative state -- nothing may read it
+    for (int t = redo_level; t <= QSVC_MAX_T; t++) {
+      Level& lv = c->lv[t];
+      lv.high_n = 0; lv.low_n = 0; lv.mv_filt_n = 0; lv.types.clear(); lv.types_d_ok = false; lv.types_allB = false;
+    }
+  }
   return r;
 }
 
-int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
-  if (!c) return QSVC_ERR_INVALID;
+static int decorrelate_impl(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   (void)hipSetDevice(c->dev);
   LevelGeom g;
   int r = level_geom(c, t, P, bs, S, &g);
@@ -593,7 +598,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   if (S < 1 || S > 128) return c->fail(QSVC_ERR_INVALID, "search_range %d", S);
   Level& lv = c->lv[t];
   if (lv.mv_raw_n < g.nB || lv.mv_bs != bs) return c->fail(QSVC_ERR_STATE, "motion_%d missing (run motion_estimate first)", t);
-  if (!c->pending.empty() && !c->resolving) c->calls.push_back({1, t, P, bs, S, always_B, 0.0f});
+  if (!c->pending.empty() && !c->resolving) c->spec_call = true;
   size_t fld = (size_t)g.BY * g.BX, mvbytes = (size_t)g.nB * 4 * fld * sizeof(int16_t);
   if ((r = lv.high.ensure(c, (size_t)(g.nB ? g.nB : 1) * g.F))) return r;
   if ((r = lv.mv_filt.ensure(c, mvbytes ? mvbytes : 16))) return r;
@@ -634,7 +639,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
     if (!lv.hhist.ensure(hbytes)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%zu)", hbytes);
     HIPCHK(c, hipMemcpyAsync(lv.hhist.p, lv.hist.p, hbytes, hipMemcpyDeviceToHost, c->st));
     lv.pending = true; lv.dec_nB = g.nB; lv.dec_BY = g.BY; lv.dec_BX = g.BX;
-    if (c->pending.empty()) c->calls.push_back({1, t, P, bs, S, always_B, 0.0f});  // (otherwise logged on entry)
+    c->spec_call = true;  // the first pending decision: the replay starts behind this call
     c->pending.push_back(t);
   } else if (!always_B) {
     // host-side I/B rule (decorrelate.cpp:964-979) on the three device histograms
@@ -673,8 +678,7 @@ int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   return QSVC_OK;
 }
 
-int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
-  if (!c) return QSVC_ERR_INVALID;
+static int update_impl(qsvc_ctx* c, int t, int P, int bs, float uf) {
   (void)hipSetDevice(c->dev);
   LevelGeom g;
   int r = level_geom(c, t, P, bs, 0, &g);
@@ -693,7 +697,7 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
     if ((r = qsvc_resolve(c))) return r;
   }
   if (!c->pending.empty() && !c->resolving) {
-    c->calls.push_back({2, t, P, bs, 0, 0, uf});
+    c->spec_call = true;
     if (c->calls.size() > 4096 && (r = qsvc_resolve(c))) return r;
   }
   const bool resident = lv.mv_bound >= 0 && lv.types_d_ok && !have_halo;
@@ -734,6 +738,30 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   HIPCHK(c, hipGetLastError());
   if (!resident) HIPCHK(c, hipStreamSynchronize(c->st));  // lv.types / halo buffers may be changed by the caller next
   return QSVC_OK;
+}
+
+// A stage call made while I/B decisions are pending is logged for replay (qsvc_resolve) -- AFTER it has queued its work
+// successfully: a call that was refused (geometry, state, memory) must not come back as an error of an unrelated entry point.
+static int logged(qsvc_ctx* c, int r, const StageCall& call) {
+  const bool spec = c->spec_call;
+  c->spec_call = false;
+  if (!r && spec && !c->resolving && !c->pending.empty()) c->calls.push_back(call);
+  return r;
+}
+int qsvc_motion_estimate(qsvc_ctx* c, int t, int P, int bs, int S) {
+  if (!c) return QSVC_ERR_INVALID;
+  c->spec_call = false;
+  return logged(c, motion_estimate_impl(c, t, P, bs, S), {0, t, P, bs, S, 0, 0.0f});
+}
+int qsvc_decorrelate(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
+  if (!c) return QSVC_ERR_INVALID;
+  c->spec_call = false;
+  return logged(c, decorrelate_impl(c, t, P, bs, S, always_B), {1, t, P, bs, S, always_B, 0.0f});
+}
+int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
+  if (!c) return QSVC_ERR_INVALID;
+  c->spec_call = false;
+  return logged(c, update_impl(c, t, P, bs, uf), {2, t, P, bs, 0, 0, uf});
 }
 
 int qsvc_analyze_step(qsvc_ctx* c, int t, int P, int bs, int S, int always_B, float uf) {

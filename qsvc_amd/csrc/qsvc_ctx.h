@@ -112,6 +112,7 @@ struct qsvc_ctx {
   PinBuf hhist;                  // the B pictures' histograms on the host: [nB][3][256] u32 (immediate decisions)
   bool defer_ok = true;          // decorrelate may defer its I/B decisions (off while a replay runs; QSVC_DEFER_IB=0 turns it off)
   bool resolving = false;
+  bool spec_call = false;        // the stage call in progress queued work on a speculative ('B') state: logged for replay once it has succeeded
   std::vector<int> pending;      // levels with pending decisions, in the order decorrelate was called
   std::vector<StageCall> calls;  // stage calls since the first pending decision
   std::string err;

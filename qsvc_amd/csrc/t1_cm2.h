@@ -15,7 +15,7 @@
 // independently (cm2_column) and a prefix sum of the per-column counts puts them in scan order.  No flag words in memory,
 // no neighbour updates, no atomics: the state is one 32-bit word per stripe column, built from the magnitudes.
 //
-// The per-column code is the column body of t1_pass (t1_core.h) on a locally assembled flag word, so both forms produce
+// The per-column code is the column body of t1_pass (tests/emul/t1_legacy.h) on a locally assembled flag word, so both forms produce
 // the same decisions (tests/emul checks all of them against the restatement's Tier-1).
 #pragma once
 #include "t1_core.h"

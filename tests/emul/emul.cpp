@@ -215,6 +215,7 @@ int emul_border_luma(const uint8_t* luma, int H, int W, int b, int16_t* out /*(H
 
 // ---- EBCOT Tier-1: one block through the lane code with lane stride 1 -------------------------
 #include "../../qsvc_amd/csrc/t1_core.h"
+#include "t1_legacy.h"
 #include "../../qsvc_amd/csrc/t1_cm2.h"
 extern "C" int emul_t1_block(const int32_t* vals, int w, int h, int orient, uint8_t* out, int* npasses, int* nbps,
                              int* pass_len, long long* pass_dist) {

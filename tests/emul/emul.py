@@ -17,7 +17,7 @@ def lib():
     if _LIB is None:
         so = os.path.join(_HERE, "libqsvc_emul.so")
         srcs = [os.path.join(_HERE, "emul.cpp")] + [os.path.join(_HERE, "..", "..", "qsvc_amd", "csrc", f)
-                                                    for f in ("mctf_core.h", "mctf_threads.h", "t1_core.h", "t1_cm2.h")]
+                                                    for f in ("mctf_core.h", "mctf_threads.h", "t1_core.h", "t1_cm2.h")] + [os.path.join(_HERE, "t1_legacy.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so,
                                    os.path.join(_HERE, "emul.cpp")])
