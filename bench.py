@@ -225,11 +225,12 @@ def main():
     dev = os.environ.get("QSVC_BENCH_DEVICE")  # test hook: several ranks on one GPU (forces the host-staged exchange)
     devno = int(dev) if dev is not None else (local if world > 1 else 0)
     engs = [hip.Engine(devno) for _ in range(S)]
-    # The motion-field coding (compress.py:197-212) runs on the sequence's own context, between the analysis and the textures, as in the
-    # reference.  QSVC_BENCH_MOTION=beside is the experiment of round 4: a second context per sequence codes the motion beside the texture
+    # The motion-field coding (compress.py:197-212) runs on the sequence's own context, in the textures' batch (qsvc_compress_code).
+    # QSVC_BENCH_MOTION=beside is an experiment of round 4: a second context per sequence codes the motion beside the texture
     # coding (measured: 4 450 instead of 6 830 fps with 12 sequences in flight, 14.4 instead of 8.4 ms for one sequence alone -- the two
     # contexts' streams get in each other's way more than the 1.7 ms serial chain they could hide)
-    mv_engs = [hip.Engine(devno) for _ in range(S)] if os.environ.get("QSVC_BENCH_MOTION", "inline") == "beside" else [None] * S
+    motion_mode = os.environ.get("QSVC_BENCH_MOTION", "batch")
+    mv_engs = [hip.Engine(devno) for _ in range(S)] if motion_mode == "beside" else [None] * S
     for e in engs:
         e.set_tier2_threads(t2_timed)  # an explicit per-context setting (include/qsvc_hip.h), not an environment variable read mid-run
     eng = engs[0]
@@ -309,12 +310,23 @@ def main():
         t_a = time.perf_counter()
         comps[k].analyze()
         t_b = time.perf_counter()
-        # compress.py:197-212: the motion fields are coded between the analysis and the texture coding (decorrelators on the host, the
-        # 16-bit component planes of all levels in one lossless JPEG 2000 batch on the GPU)
-        fut = comps[k].motion_async()
-        t_c = time.perf_counter()
-        out = comps[k].texture(low_first, copy=False)  # code-streams stay in the engine's host buffer (no Python copies)
-        _, mcs = fut.result()
+        # compress.py:197-228: the motion fields are coded between the analysis and the textures (decorrelators on the host side of the
+        # library, the 16-bit component planes of all levels lossless) -- here in the same batch as the textures
+        if motion_mode == "off":    # diagnosis only: the round-3 step without the motion coding (its line is marked)
+            t_c = t_b
+            out, mcs = comps[k].texture(low_first, copy=False), {}
+        elif motion_mode == "inline":   # two calls, the motion planes' Tier-1 chain in front of the textures'
+            _, mcs = comps[k].motion(copy=True)
+            t_c = time.perf_counter()
+            out = comps[k].texture(low_first, copy=False)
+        elif mv_engs[k] is None:   # the motion fields' component planes ride in the textures' batch (qsvc_compress_code): ONE call
+            t_c = t_b
+            out, mcs = comps[k].code(low_first, copy=False)  # code-streams stay in the engine's host buffer (no Python copies)
+        else:
+            fut = comps[k].motion_async()
+            t_c = time.perf_counter()
+            out = comps[k].texture(low_first, copy=False)
+            _, mcs = fut.result()
         if k == 0:
             phase["analyze_calls_return"] += t_b - t_a; phase["motion_call"] += t_c - t_b; phase["texture_call"] += time.perf_counter() - t_c; phase["n"] += 1
         nbytes_of[k] = sum(len(c) for v in out.values() for c in v)
@@ -659,6 +671,8 @@ def main():
                        "halo_messages_per_level_per_neighbour": 1 if world > 1 else 0,
                        "host_threads_per_rank": {"session": S, "motion_coding": S if mv_engs and mv_engs[0] is not None else 0, "tier2_workers": S * t2_timed},
                        "contexts_per_sequence": 2 if mv_engs and mv_engs[0] is not None else 1,
+                       "motion_field_coding": {"batch": "in the textures' batch (qsvc_compress_code)", "inline": "its own batch before the textures",
+                                               "beside": "on a second context", "off": "NOT CODED (diagnosis run, not a valid step)"}.get(motion_mode, motion_mode),
                        "host_cores_pinned": args.host_cores or None,
                        "tier2_threads_per_context": t2_timed, "host_cpus": len(os.sched_getaffinity(0))},
             "codeblocks_per_s": round(ncb_step * world * S * args.steps / dt, 1),

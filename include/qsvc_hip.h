@@ -193,6 +193,14 @@ int qsvc_j2k_encode_planes_s16(qsvc_ctx* ctx, const int16_t* planes, int nplanes
  * context's resident ones -- a second context can then code the motion of a sequence while the first codes its textures. */
 int qsvc_motion_encode(qsvc_ctx* ctx, int nlevels, const int* ts, const int* fields, int block_size, const int16_t* filtered_host,
                        int16_t* residues, uint8_t* out, size_t cap, size_t* offs);
+/* The two together -- everything `mctf compress` does behind the analysis (compress.py:197-228: motion_compress, then
+ * texture_compress) -- in ONE batch on the GPU: the subband pictures of the sequences (arguments as qsvc_j2k_encode_multi) and the
+ * motion fields' component planes (arguments as qsvc_motion_encode, resident fields) share the Tier-1 launches.  out: first the
+ * 3 * sum(counts) texture streams, then the 4 * sum(mfields) motion streams; offs has one entry more than streams.  The motion
+ * planes use the textures' code-block size (64 x 64 by default, Kakadu's default for both). */
+int qsvc_compress_code(qsvc_ctx* ctx, int nseq, const int* kinds, const int* ts, const int* firsts, const int* counts,
+                       const qsvc_j2k_params* prms, int nlevels, const int* mts, const int* mfields, int block_size, int16_t* residues,
+                       uint8_t* out, size_t cap, size_t* offs);
 /* Unit-testable transform: level shift + `levels` of forward DWT of a host 8-bit plane, Mallat layout.
  * out receives H*W int32 (reversible 5/3) or H*W float32 (irreversible 9/7, before quantisation). */
 int qsvc_j2k_dwt(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, int reversible, int levels, void* out);

@@ -262,7 +262,8 @@ struct Pinned {
 
 struct J2kState {
   T2Pool* pool = nullptr;
-  DevBuf coefA, llA, llB, sbtab_d, planes_d, cbs_d, nbps_d, mags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d;
+  std::function<int()> after_resolve;   // one-shot: queued work that needs the final I/B decisions (the motion planes of qsvc_compress_code)
+  DevBuf coefA, llA, llB, sbtab_d, planes_d, cbs_d, nbps_d, mags, outbuf, res_d, plen_d, pdist_d, offs_d, lens_d, gath_d, err_d, up_d, mvup_d;
   DevBuf joboff_d, order_d, segs_d, cnt_d, dist_d;  // Tier-1: first job of each block, MQ slot table, decision segments
   DevBuf tilemap_d;                                 // the DWT levels' workgroup lists (dwt_build_tilemap)
   std::vector<uint32_t> tilemap; std::vector<int> tile_first; std::vector<int> tile_key;   // ... and the geometry they were built for
@@ -317,7 +318,7 @@ void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->llA, &s->llB, &s->sbtab_d, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d, &s->nbeff_d, &s->njobs_d, &s->t1tabs_d, &s->tilemap_d};
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->mvup_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d, &s->nbeff_d, &s->njobs_d, &s->t1tabs_d, &s->tilemap_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   for (auto& e : s->copied) if (e) (void)hipEventDestroy(e);
@@ -434,11 +435,21 @@ struct PlaneSrc { const uint8_t* src; int stride, W, H; const qsvc_j2k_params* p
 static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8_t* out, size_t cap, size_t* offs) {
   if (!c->j2k) c->j2k = new J2kState();
   J2kState& S = *c->j2k;
+  // A batch is a run of picture planes (8-bit, one transform, step, level count and code-block size) optionally FOLLOWED by a run of
+  // 16-bit signed planes coded reversibly without any decomposition (the motion-field components of `mctf compress`): the second
+  // group goes through level shift + pack instead of the DWT kernels and then shares the Tier-1 launches, the gather and the copy.
+  const int np_all = (int)src.size();
+  int npA = 0;
+  while (npA < np_all && !src[npA].s16) npA++;
+  for (int p = npA; p < np_all; p++)
+    if (!src[p].s16) return c->fail(QSVC_ERR_INVALID, "16-bit planes must follow the 8-bit planes of a batch");
   const qsvc_j2k_params* prm = src[0].prm;
   bool any_dist = false;
-  for (auto& p : src) {
-    if (p.prm->reversible != prm->reversible || p.prm->levels != prm->levels || p.prm->cblk_w != prm->cblk_w ||
-        p.prm->cblk_h != prm->cblk_h || p.prm->base_step != prm->base_step)
+  for (int q = 0; q < np_all; q++) {
+    const PlaneSrc& p = src[q];
+    const qsvc_j2k_params* g = q < npA ? prm : src[npA].prm;   // the group's first plane
+    if (p.prm->reversible != g->reversible || p.prm->levels != g->levels || p.prm->cblk_w != prm->cblk_w ||
+        p.prm->cblk_h != prm->cblk_h || p.prm->base_step != g->base_step)
       return c->fail(QSVC_ERR_INVALID, "planes of one batch must share transform, step and code-block parameters");
     if (p.prm->layers > 16) return c->fail(QSVC_ERR_INVALID, "at most 16 quality layers");
     if (p.prm->layers > 1 || p.prm->slopes[0] > 0) any_dist = true;
@@ -448,7 +459,6 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   if (prm->levels < 0 || prm->levels > J2K_MAXLEV) return c->fail(QSVC_ERR_INVALID, "Clevels %d", prm->levels);
   if (cbw > 64 || cbh > 64 || cbw < 4 || cbh < 4 || (cbw & (cbw - 1)) || (cbh & (cbh - 1)))
     return c->fail(QSVC_ERR_UNSUPPORTED, "code-block %dx%d (powers of two in 4..64)", cbw, cbh);
-  float base_step = prm->base_step > 0 ? prm->base_step : 1.0f / 256;
   const int np = (int)src.size();
   // distinct plane geometries of the batch
   std::vector<PlanePlan> plans;
@@ -457,27 +467,39 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     int k = -1;
     const int prec = src[p].s16 ? 16 : 8;
     for (size_t q = 0; q < plans.size(); q++) if (plans[q].W == src[p].W && plans[q].H == src[p].H && plans[q].prec == prec) { k = (int)q; break; }
-    if (k < 0) { plans.emplace_back(); build_plan(plans.back(), src[p].W, src[p].H, prm->levels, rev, base_step, cbw, cbh, prec); k = (int)plans.size() - 1; }
+    if (k < 0) {
+      plans.emplace_back();
+      build_plan(plans.back(), src[p].W, src[p].H, src[p].prm->levels, src[p].prm->reversible != 0, src[p].prm->base_step > 0 ? src[p].prm->base_step : 1.0f / 256, cbw, cbh, prec);
+      k = (int)plans.size() - 1;
+    }
     plan_of[p] = k;
   }
   for (int p = 0; p < np; p++)
-    if (src[p].s16 && (!rev || plans[plan_of[p]].L != 0))
+    if (src[p].s16 && (!src[p].prm->reversible || plans[plan_of[p]].L != 0))
       return c->fail(QSVC_ERR_UNSUPPORTED, "16-bit signed planes are coded reversibly with Clevels=0 only (motion fields)");
   int maxL = 0, maxW = 0, maxH = 0;
+  for (int p = 0; p < npA; p++) maxL = std::max(maxL, plans[plan_of[p]].L);
+  // the planes that go through level shift + pack: the 16-bit group, or everything when no plane has a decomposition level
+  const int npD = maxL > 0 ? npA : 0, npP = np - npD;   // DWT group [0, npD), pack group [npD, np)
+  const bool revP = npP && src[npD].s16 ? true : rev;
+  int maxWP = 0, maxHP = 0;
   S.planes.resize(np);
-  size_t total = 0;
+  size_t total = 0;   // samples of the pack group (the only planes that exist as a coefficient plane)
   std::vector<int> first_cb(np + 1);
   int ncb = 0;
   for (int p = 0; p < np; p++) {
-    S.planes[p].off = total; S.planes[p].src = src[p].src; S.planes[p].u8stride = src[p].stride; S.planes[p].W = src[p].W; S.planes[p].H = src[p].H; S.planes[p].s16 = src[p].s16;
-    total += (size_t)src[p].W * src[p].H;
-    maxW = std::max(maxW, src[p].W); maxH = std::max(maxH, src[p].H); maxL = std::max(maxL, plans[plan_of[p]].L);
+    S.planes[p].off = p < npD ? 0 : total; S.planes[p].src = src[p].src; S.planes[p].u8stride = src[p].stride; S.planes[p].W = src[p].W; S.planes[p].H = src[p].H; S.planes[p].s16 = src[p].s16;
+    if (p < npD) { maxW = std::max(maxW, src[p].W); maxH = std::max(maxH, src[p].H); }
+    else { total += (size_t)src[p].W * src[p].H; maxWP = std::max(maxWP, src[p].W); maxHP = std::max(maxHP, src[p].H); }
     first_cb[p] = ncb; ncb += plans[plan_of[p]].ncb;
   }
   first_cb[np] = ncb;
-  // all planes must share L for the batched DWT launches (same Clevels, sizes large enough)
-  for (int p = 0; p < np; p++)
+  const int ncbD = first_cb[npD], ncbP = ncb - ncbD;
+  // the planes of the DWT group must share L for the batched launches (same Clevels, sizes large enough)
+  for (int p = 0; p < npD; p++)
     if (plans[plan_of[p]].L != maxL) return c->fail(QSVC_ERR_UNSUPPORTED, "planes of one batch must allow the same number of DWT levels");
+  for (int p = npD; p < np; p++)
+    if (plans[plan_of[p]].L != 0) return c->fail(QSVC_ERR_UNSUPPORTED, "planes of one batch must allow the same number of DWT levels");
   S.cbs.resize(ncb);
   for (int p = 0; p < np; p++) {
     const PlanePlan& pl = plans[plan_of[p]];
@@ -505,13 +527,14 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     llB_n += ((size_t)((w2 + 3) & ~3) * h2 + 7) & ~(size_t)7;
     const PlanePlan& pl = plans[plan_of[p]];
     for (int k = 0; k < nsb; k++) {
+      if (k >= (int)pl.sb.size()) { S.sbtab[(size_t)p * nsb + k] = DwtSb{0, 0, 0, 0.0f}; continue; }   // (pack-group planes: LL only)
       const Subband& sb = pl.sb[k];
       S.sbtab[(size_t)p * nsb + k] = DwtSb{first_cb[p] + sb.first_cb, sb.gx, sb.Mb, sb.delta};
     }
   }
   const size_t ll_elem = rev ? 2 : 4;
-  if (maxL == 0) { if ((r = S.coefA.ensure(c, total * 4))) return r; }
-  else {
+  if (npP) { if ((r = S.coefA.ensure(c, total * 4))) return r; }
+  if (maxL > 0) {
     if ((r = S.llA.ensure(c, llA_n * ll_elem + 64))) return r;
     if ((r = S.llB.ensure(c, llB_n * ll_elem + 64))) return r;
     if ((r = S.sbtab_d.ensure(c, S.sbtab.size() * sizeof(DwtSb)))) return r;
@@ -532,19 +555,24 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   if ((r = upload_if_changed(c, S.cbs_d.p, S.cbs.data(), (size_t)ncb * sizeof(CbDesc), S.up_cbs, S.up_cbs_at))) return r;
   HIPCHK(c, hipMemsetAsync(S.err_d.p, 0, 16, c->st));
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }  // pending I/B decisions (qsvc_api.hip): the pictures must be final from here on
+  if (S.after_resolve) {
+    std::function<int()> f;
+    f.swap(S.after_resolve);
+    if ((r = f())) return r;
+  }
   Prof pf;
   if (maxL > 0) {
     // one kernel per level: tile in LDS, vertical + horizontal lifting, LL to the next level, the other subbands quantised and
     // packed straight into the Tier-1 magnitudes; the blocks' largest magnitudes are collected by atomicMax into nbps_d
     int minW = maxW, minH = maxH;
-    for (const PlaneDesc& q : S.planes) { if (q.W < minW) minW = q.W; if (q.H < minH) minH = q.H; }
+    for (int p = 0; p < npD; p++) { const PlaneDesc& q = S.planes[p]; if (q.W < minW) minW = q.W; if (q.H < minH) minH = q.H; }
     const uint32_t* tm = nullptr;
-    if (dwt_tilemap_fits(np, maxW, maxH)) {  // one workgroup per tile that exists (the planes of a batch differ in size)
+    if (dwt_tilemap_fits(npD, maxW, maxH)) {  // one workgroup per tile that exists (the planes of a batch differ in size)
       std::vector<int> key;
-      key.reserve(2 * np + 1);
+      key.reserve(2 * npD + 1);
       key.push_back(maxL);
-      for (const PlaneDesc& q : S.planes) { key.push_back(q.W); key.push_back(q.H); }
-      if (key != S.tile_key) { dwt_build_tilemap(S.planes.data(), np, maxL, S.tilemap, S.tile_first); S.tile_key.swap(key); }
+      for (int p = 0; p < npD; p++) { key.push_back(S.planes[p].W); key.push_back(S.planes[p].H); }
+      if (key != S.tile_key) { dwt_build_tilemap(S.planes.data(), npD, maxL, S.tilemap, S.tile_first); S.tile_key.swap(key); }
       if ((r = S.tilemap_d.ensure(c, S.tilemap.size() * 4 + 16))) return r;
       if ((r = upload_if_changed(c, S.tilemap_d.p, S.tilemap.data(), S.tilemap.size() * 4, S.up_tilemap, S.up_tilemap_at))) return r;
       tm = (const uint32_t*)S.tilemap_d.p;
@@ -552,15 +580,16 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     // (the segment begins where the device's work does: the host-side table checks above are not the transform's time)
     pf.begin(c, rev ? "j2k_dwt53" : "j2k_dwt97");
     HIPCHK(c, hipMemsetAsync(S.nbps_d.p, 0, (size_t)ncb * 4, c->st));
-    launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, minW, minH, (const DwtSb*)S.sbtab_d.p, maxL, rev, S.llA.p, S.llB.p,
+    launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, npD, maxW, maxH, minW, minH, (const DwtSb*)S.sbtab_d.p, maxL, rev, S.llA.p, S.llB.p,
                      (unsigned long long*)S.mags.p, (int*)S.nbps_d.p, nullptr, ilog2i(cbw), ilog2i(cbh), (int*)S.err_d.p, tm, S.tile_first.data());
-    launch_t1_nbps(c->st, (const CbDesc*)S.cbs_d.p, ncb, (int*)S.nbps_d.p, (int*)S.err_d.p);
+    launch_t1_nbps(c->st, (const CbDesc*)S.cbs_d.p, ncbD, (int*)S.nbps_d.p, (int*)S.err_d.p);
     pf.end(c);
-  } else {  // Clevels = 0 (motion-field planes): level shift, then quantise + pack per code-block
-    pf.begin(c, src[0].s16 ? "mv_t1_pack" : "j2k_t1_pack");
-    launch_level_shift(c->st, (const PlaneDesc*)S.planes_d.p, np, maxW, maxH, S.coefA.p, rev);
-    launch_t1_pack_blk(c->st, (const CbDesc*)S.cbs_d.p, ncb, (const PlaneDesc*)S.planes_d.p, S.coefA.p, (unsigned long long*)S.mags.p,
-                       (int*)S.nbps_d.p, (int*)S.err_d.p, rev);
+  }
+  if (npP) {  // Clevels = 0 (motion-field planes): level shift, then quantise + pack per code-block
+    pf.begin(c, src[npD].s16 ? "mv_t1_pack" : "j2k_t1_pack");
+    launch_level_shift(c->st, (const PlaneDesc*)S.planes_d.p + npD, npP, maxWP, maxHP, S.coefA.p, revP);
+    launch_t1_pack_blk(c->st, (const CbDesc*)S.cbs_d.p + ncbD, ncbP, (const PlaneDesc*)S.planes_d.p, S.coefA.p,
+                       (unsigned long long*)S.mags.p + (size_t)ncbD * (T1_MAGS_BYTES / 8), (int*)S.nbps_d.p + ncbD, (int*)S.err_d.p, revP);
     pf.end(c);
   }
   // Tier-1.  The job list (bit-planes per block -> first job of each block, MQ slot table) is built ON THE DEVICE when the segment
@@ -909,6 +938,71 @@ int qsvc_j2k_encode_multi(qsvc_ctx* c, int nseq, const int* kinds, const int* ts
   }
   if (src.empty()) { offs[0] = 0; return QSVC_OK; }
   return j2k_encode_planes(c, src, out, cap, offs);
+}
+
+// `mctf compress` behind the analysis in ONE batch: the temporal subbands' pictures (as qsvc_j2k_encode_multi) and the motion fields'
+// component planes (as qsvc_motion_encode) share the Tier-1 launches, the gather and the copy, so the (short) serial chain of
+// the motion planes' code-blocks runs beside the textures' instead of in front of them.
+int qsvc_compress_code(qsvc_ctx* c, int nseq, const int* kinds, const int* ts, const int* firsts, const int* counts, const qsvc_j2k_params* prms,
+                       int nlevels, const int* mts, const int* mfields, int block_size, int16_t* residues, uint8_t* out, size_t cap, size_t* offs) {
+  if (!c || !kinds || !ts || !firsts || !counts || !prms || !out || !offs || nseq < 1) return QSVC_ERR_INVALID;
+  (void)hipSetDevice(c->dev);
+  if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+  std::vector<PlaneSrc> src;
+  for (int i = 0; i < nseq; i++) {
+    int r = add_sequence(c, kinds[i], ts[i], firsts[i], counts[i], &prms[i], src);
+    if (r) return r;
+  }
+  std::vector<int16_t> planes;
+  qsvc_j2k_params mprm;
+  qsvc_motion_prm(&mprm);
+  if (!src.empty()) mprm.cblk_w = prms[0].cblk_w, mprm.cblk_h = prms[0].cblk_h;  // one code-block size per batch
+  if (nlevels > 0 && !residues) {
+    // the motion planes are made ON THE DEVICE from the resident fields (k_motion_planes), queued right after the pending I/B
+    // decisions are taken ('I' pictures zero their fields): no host round trip stands between the analysis and the batch
+    if (!mts || !mfields || nlevels > MV_MAXLEV || block_size < 1) return c->fail(QSVC_ERR_INVALID, "bad motion level list");
+    const int BY = c->H / block_size, BX = c->W / block_size;
+    const size_t fld = (size_t)BY * BX, per = 4 * fld;
+    MvLevels ml;
+    memset(&ml, 0, sizeof ml);
+    ml.nlevels = nlevels; ml.fld = (int)fld;
+    size_t total = 0;
+    for (int k = 0; k < nlevels; k++) {
+      const int t = mts[k];
+      if (t < 1 || t > QSVC_MAX_T || mfields[k] < 0 || (k && mts[k] <= mts[k - 1])) return c->fail(QSVC_ERR_INVALID, "bad level list");
+      const Level& lv = c->lv[t];
+      if (lv.mv_filt_n < mfields[k] || (mfields[k] && lv.mv_bs != block_size))
+        return c->fail(QSVC_ERR_STATE, "motion_filtered_%d holds %d fields at block size %d (asked for %d at %d)", t, lv.mv_filt_n, lv.mv_bs, mfields[k], block_size);
+      ml.filt[k] = (const int16_t*)lv.mv_filt.p; ml.fields[k] = mfields[k]; ml.first[k] = (int)total;
+      total += (size_t)mfields[k];
+    }
+    ml.first[nlevels] = (int)total;
+    if (total) {
+      if (!c->j2k) c->j2k = new J2kState();
+      int r = c->j2k->mvup_d.ensure(c, total * per * sizeof(int16_t));
+      if (r) return r;
+      int16_t* dst = (int16_t*)c->j2k->mvup_d.p;
+      hipStream_t st = c->st;
+      c->j2k->after_resolve = [ml, dst, total, per, st]() { launch_motion_planes(st, ml, dst, total * per); return (int)QSVC_OK; };
+      for (size_t p = 0; p < total * 4; p++) src.push_back({(const uint8_t*)dst + p * fld * 2, BX, BX, BY, &mprm, 1});
+    }
+  } else if (nlevels > 0) {  // the caller wants the residue files' contents: the host half of the chain (qsvc_motion_planes)
+    int BY = 0, BX = 0;
+    int r = qsvc_motion_planes(c, nlevels, mts, mfields, block_size, nullptr, residues, planes, &BY, &BX);
+    if (r) return r;
+    if (!planes.empty()) {
+      if (!c->j2k) c->j2k = new J2kState();
+      const size_t bytes = planes.size() * sizeof(int16_t), N = (size_t)BY * BX;
+      if ((r = c->j2k->mvup_d.ensure(c, bytes))) return r;
+      HIPCHK(c, hipMemcpyAsync(c->j2k->mvup_d.p, planes.data(), bytes, hipMemcpyHostToDevice, c->st));
+      HIPCHK(c, hipStreamSynchronize(c->st));  // (`planes` is pageable and local)
+      for (size_t p = 0; p < planes.size() / N; p++) src.push_back({(const uint8_t*)c->j2k->mvup_d.p + p * N * 2, BX, BX, BY, &mprm, 1});
+    }
+  }
+  if (src.empty()) { offs[0] = 0; return QSVC_OK; }
+  const int rr = j2k_encode_planes(c, src, out, cap, offs);
+  if (c->j2k) c->j2k->after_resolve = nullptr;   // (a refused batch must not leave its hook behind)
+  return rr;
 }
 
 int qsvc_j2k_encode_plane(qsvc_ctx* c, const uint8_t* plane, int H, int W, const qsvc_j2k_params* prm, uint8_t* out, size_t cap,

@@ -62,4 +62,14 @@ void launch_t1_cm2(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, 
 void launch_t1_tables(hipStream_t st, uint8_t* tabs);   // the table block of k_t1_cm2, once per context
 void launch_gather(hipStream_t st, const uint8_t* outbuf, int outcap, const unsigned long long* offs, const int* lens, int ncb,
                    uint8_t* dst);
+// the motion fields' component planes on the device (qsvc_compress_code): inter-level / bidirectional residues of the resident
+// motion_filtered_t + the reference's byte cut (component c of a field = every 4th int16), one thread per output sample
+#define MV_MAXLEV 16
+struct MvLevels {
+  const int16_t* filt[MV_MAXLEV];   // [fields][4][BY][BX] of level k (ascending temporal subbands)
+  int fields[MV_MAXLEV];
+  int first[MV_MAXLEV + 1];         // fields before level k
+  int nlevels, fld;                 // fld = BY * BX
+};
+void launch_motion_planes(hipStream_t st, const MvLevels& ml, int16_t* dst, size_t n);
 }  // namespace qsvc

@@ -34,6 +34,36 @@ void launch_level_shift(hipStream_t st, const PlaneDesc* d_planes, int nplanes, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Motion-field coding chain on the device (motion_compress.py:146-186, motion_compress_j2k.py:103-107): residue of every level but
+// the last against the level above (field - reference / 2, C division, two fields per reference field, the last reference kept:
+// interlevel_motion_decorrelate.cpp:32-70,249-283), NEXT -= PREV on the last (bidirectional_motion_decorrelate.cpp:25-52), and the
+// component planes as the reference's `demux 8 2c 2 | split` cuts the planar residue file: component c, sample j <- int16 4 j + c.
+__global__ void __launch_bounds__(256) k_motion_planes(MvLevels ml, int16_t* dst, size_t n) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const size_t per = 4 * (size_t)ml.fld;
+  const int fi = (int)(e / per);                 // field over all levels
+  const int w = (int)(e % per), comp = w / ml.fld, j = w % ml.fld;
+  int k = 0;
+  while (k + 1 < ml.nlevels && fi >= ml.first[k + 1]) k++;
+  const int i = fi - ml.first[k];
+  const int m = 4 * j + comp;                    // position in the planar field
+  const int16_t* f = ml.filt[k] + (size_t)i * per;
+  int v = f[m];
+  if (k + 1 < ml.nlevels) {
+    const int nref = ml.fields[k + 1];
+    const int r = i / 2 < nref ? i / 2 : nref - 1;
+    if (r >= 0) v -= ml.filt[k + 1][(size_t)r * per + m] / 2;
+  } else if (m >= 2 * ml.fld) {
+    v -= f[m - 2 * ml.fld];
+  }
+  dst[e] = (int16_t)v;
+}
+void launch_motion_planes(hipStream_t st, const MvLevels& ml, int16_t* dst, size_t n) {
+  if (n) hipLaunchKernelGGL(k_motion_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ml, dst, n);
+}
+
+// ---------------------------------------------------------------------------------------------
 // largest magnitude of every block (collected by the DWT kernel) -> number of magnitude bit-planes
 __global__ void __launch_bounds__(256) k_t1_nbps(const CbDesc* cbs, int ncb, int* nbps, int* err) {
   int b = blockIdx.x * 256 + threadIdx.x;

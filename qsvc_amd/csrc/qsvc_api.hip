@@ -1124,13 +1124,15 @@ int qsvc_halo_exchange_batch(qsvc_ctx* const* ctxs, int n, int t) {
 // bidirectionally (NEXT -= PREV, bidirectional_motion_decorrelate.cpp:25-52), the planar residue file is cut as the reference's
 // `demux 8 2c 2 | split` cuts it (component c of a field = every 4th int16, phase c: motion_compress_j2k.py:103-107), and all
 // component planes of all levels are coded lossless in ONE batch.  Streams in (level, field, component) order.
-int qsvc_motion_encode(qsvc_ctx* c, int nlevels, const int* ts, const int* fields, int block_size, const int16_t* filtered_host,
-                       int16_t* residues, uint8_t* out, size_t cap, size_t* offs) {
-  if (!c || !ts || !fields || !out || !offs || nlevels < 1 || block_size < 1) return QSVC_ERR_INVALID;
+// the host half of the chain: the component planes of all levels (4 * sum(fields) planes of BY x BX int16, back to back)
+int qsvc_motion_planes(qsvc_ctx* c, int nlevels, const int* ts, const int* fields, int block_size, const int16_t* filtered_host,
+                       int16_t* residues, std::vector<int16_t>& planes, int* BYo, int* BXo) {
+  if (!c || !ts || !fields || nlevels < 1 || block_size < 1) return QSVC_ERR_INVALID;
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   (void)hipSetDevice(c->dev);
   if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
   const int BY = c->H / block_size, BX = c->W / block_size;
+  *BYo = BY; *BXo = BX;
   const size_t fld = (size_t)BY * BX, per = 4 * fld;
   size_t total = 0;
   for (int k = 0; k < nlevels; k++) {
@@ -1141,8 +1143,9 @@ int qsvc_motion_encode(qsvc_ctx* c, int nlevels, const int* ts, const int* field
       return c->fail(QSVC_ERR_STATE, "motion_filtered_%d holds %d fields at block size %d (asked for %d at %d)", t, lv.mv_filt_n, lv.mv_bs, fields[k], block_size);
     total += (size_t)fields[k];
   }
-  if (!total) { offs[0] = 0; return QSVC_OK; }
-  std::vector<int16_t> filt(total * per), planes(total * per);
+  planes.assign(total * per, 0);
+  if (!total) return QSVC_OK;
+  std::vector<int16_t> filt(total * per);
   size_t o = 0;
   if (filtered_host) memcpy(filt.data(), filtered_host, total * per * sizeof(int16_t));
   else {
@@ -1180,10 +1183,23 @@ int qsvc_motion_encode(qsvc_ctx* c, int nlevels, const int* ts, const int* field
     for (int comp = 0; comp < 4; comp++)
       for (size_t j = 0; j < fld; j++) d[(size_t)comp * fld + j] = s[4 * j + comp];
   }
+  return QSVC_OK;
+}
+void qsvc_motion_prm(qsvc_j2k_params* prm) {  // motion_compress_j2k.py:131-142: Creversible=yes Clevels=0 Cuse_sop=yes, one layer
+  memset(prm, 0, sizeof *prm);
+  prm->reversible = 1; prm->levels = 0; prm->layers = 1; prm->cblk_w = 64; prm->cblk_h = 64; prm->use_sop = 1; prm->base_step = 1.0f / 256;
+}
+int qsvc_motion_encode(qsvc_ctx* c, int nlevels, const int* ts, const int* fields, int block_size, const int16_t* filtered_host,
+                       int16_t* residues, uint8_t* out, size_t cap, size_t* offs) {
+  if (!c || !out || !offs) return QSVC_ERR_INVALID;
+  std::vector<int16_t> planes;
+  int BY = 0, BX = 0;
+  int r = qsvc_motion_planes(c, nlevels, ts, fields, block_size, filtered_host, residues, planes, &BY, &BX);
+  if (r) return r;
+  if (planes.empty()) { offs[0] = 0; return QSVC_OK; }
   qsvc_j2k_params prm;
-  memset(&prm, 0, sizeof prm);
-  prm.reversible = 1; prm.levels = 0; prm.layers = 1; prm.cblk_w = 64; prm.cblk_h = 64; prm.use_sop = 1; prm.base_step = 1.0f / 256;
-  return qsvc_j2k_encode_planes_s16(c, planes.data(), (int)(total * 4), BY, BX, &prm, out, cap, offs);
+  qsvc_motion_prm(&prm);
+  return qsvc_j2k_encode_planes_s16(c, planes.data(), (int)(planes.size() / ((size_t)BY * BX)), BY, BX, &prm, out, cap, offs);
 }
 
 // ---- truncating 5/3 on a host plane ---------------------------------------------------------------

@@ -133,5 +133,9 @@ struct qsvc_ctx {
 // Take every pending I/B decision (one stream synchronisation); if a picture turns out 'I', redo what was computed from the
 // speculative 'B'.  Every entry point that reads or replaces level state calls this first; returns QSVC_OK or an error.
 extern "C" int qsvc_resolve(qsvc_ctx* c);  // internal (not in include/qsvc_hip.h)
+// internal: the host half of the motion-field coding chain (qsvc_api.hip) for the entry points that code the planes (j2k_api.hip)
+extern "C" int qsvc_motion_planes(qsvc_ctx* c, int nlevels, const int* ts, const int* fields, int block_size, const int16_t* filtered_host,
+                                  int16_t* residues, std::vector<int16_t>& planes, int* BY, int* BX);
+extern "C" void qsvc_motion_prm(qsvc_j2k_params* prm);
 void j2k_release(qsvc_ctx* c);
 void j2k_decode_release(qsvc_ctx* c);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "qsvc_analyze_step", "qsvc_un_update", "qsvc_correlate", "qsvc_synthesize_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_halo_batch_bytes", "qsvc_halo_batch_export_host", "qsvc_halo_batch_import_host",
     "qsvc_halo_exchange_batch", "qsvc_dwt53_trunc",
-    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_motion_encode", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_stats", "qsvc_set_tier2_threads", "qsvc_set_profiling", "qsvc_get_timings",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_motion_encode", "qsvc_compress_code", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_stats", "qsvc_set_tier2_threads", "qsvc_set_profiling", "qsvc_get_timings",
 ]
 
 
@@ -89,6 +89,8 @@ def load_library() -> C.CDLL:
     L.qsvc_j2k_encode_plane.argtypes = [vp, u8p, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_encode_planes_s16.argtypes = [vp, i16p, i, i, i, C.POINTER(J2kParams), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_motion_encode.argtypes = [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_int), i, vp, vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    IP = C.POINTER(C.c_int)
+    L.qsvc_compress_code.argtypes = [vp, i, IP, IP, IP, IP, C.POINTER(J2kParams), i, IP, IP, i, vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.qsvc_j2k_dwt.argtypes = [vp, u8p, i, i, i, i, vp]
     L.qsvc_j2k_decode_planes.argtypes = [vp, i, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i, vp, C.c_size_t, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -328,6 +330,37 @@ class Engine:
         self._chk(self.L.qsvc_j2k_encode_planes_s16(self.h, p.ctypes.data, n, H, W, C.byref(params), out.ctypes.data, cap, offs))
         o = list(offs)
         return [out[o[k]:o[k + 1]].tobytes() for k in range(n)]
+
+    def compress_code(self, items, levels, block_size, copy=True):
+        """items: [(kind, t, first, count, J2kParams)] as j2k_encode_multi; levels: [(t, fields)] as motion_encode ->
+        (texture streams per item, {t: motion streams}): textures and motion fields of a sequence in one batch (qsvc_compress_code)."""
+        items = [it for it in items if it[3] > 0]
+        n, nl = len(items), len(levels)
+        IA = C.c_int * max(n, 1)
+        kinds, ts = IA(*[it[0] for it in items]), IA(*[it[1] for it in items])
+        firsts, counts = IA(*[it[2] for it in items]), IA(*[it[3] for it in items])
+        prms = (J2kParams * max(n, 1))(*[it[4] for it in items])
+        MA = C.c_int * max(nl, 1)
+        mts, mfs = MA(*[t for t, _ in levels]), MA(*[f for _, f in levels])
+        total, mtotal = sum(it[3] for it in items), sum(f for _, f in levels)
+        BY, BX = self.H // block_size, self.W // block_size
+        cap = total * self.F * 2 + mtotal * 4 * (BY * BX * 4 + 4096) + (1 << 20)
+        if getattr(self, "_j2k_out", None) is None or self._j2k_out.size < cap:
+            self._j2k_out = np.empty(cap, dtype=np.uint8)
+        out = self._j2k_out
+        offs = (C.c_size_t * (3 * total + 4 * mtotal + 1))()
+        self._chk(self.L.qsvc_compress_code(self.h, n, kinds, ts, firsts, counts, prms, nl, mts, mfs, block_size, None, out.ctypes.data, out.size, offs))
+        o, mv = list(offs), memoryview(out)
+        cut = (lambda a, b: out[a:b].tobytes()) if copy else (lambda a, b: mv[a:b])
+        tex, k = [], 0
+        for it in items:
+            tex.append([cut(o[k + j], o[k + j + 1]) for j in range(3 * it[3])])
+            k += 3 * it[3]
+        mot = {}
+        for t, f in levels:
+            mot[t] = [cut(o[k + j], o[k + j + 1]) for j in range(4 * f)]
+            k += 4 * f
+        return tex, mot
 
     def motion_encode(self, levels, block_size, want_residues=False, copy=True, filtered=None):
         """levels: [(t, fields)] in ascending t -> ({t: [code-stream per (field, component)]}, {t: motion_residue_t} or None): the whole

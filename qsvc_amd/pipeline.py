@@ -109,6 +109,15 @@ class Compressor:
         streams, res = self.e.motion_encode([(t, P // 2) for (t, P, S, bs) in self.levels], self.p.block_size, want_residues, copy)
         return res, streams
 
+    def code(self, low_first=0, copy=True):
+        """compress.py:197-228 behind the analysis, in ONE batch (qsvc_compress_code): the motion fields' component planes ride in the
+        textures' Tier-1 launches.  -> ({(kind, t): texture streams}, {t: motion streams})."""
+        items = [it for it in self.texture_items(low_first) if it[3] > 0]
+        if self.p.block_size > self.p.block_size_min and len(self.levels) > 1:
+            raise NotImplementedError("motion_compress with a shrinking block size (motion_compress.py:159-166 quirk) is not reproduced")
+        tex, mot = self.e.compress_code(items, [(t, P // 2) for (t, P, S, bs) in self.levels], self.p.block_size, copy)
+        return {(it[0], it[1]): s for it, s in zip(items, tex)}, mot
+
     def motion_async(self):
         """compress.py:197-212 codes the motion between the analysis and the textures; the two are independent.  With a motion engine:
         the filtered fields come to the host (kilobytes) and a worker thread codes them on the second context while the caller goes on

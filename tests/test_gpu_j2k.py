@@ -300,3 +300,24 @@ def test_native_motion_coding_chain_equals_the_host_modules(eng):
         for n in range(want[t].shape[0]):
             for c in range(4):
                 assert streams[t][4 * n + c] == J.encode_plane_s16(comps[c, n]), (t, n, c)
+
+
+@pytest.mark.parametrize("lossless", [True, False])
+def test_textures_and_motion_in_one_batch_equal_the_separate_calls(eng, lossless):
+    """qsvc_compress_code: the motion fields' 16-bit component planes ride in the textures' batch (level shift + pack beside the DWT
+    kernels, then the same Tier-1 launches); every stream equals what qsvc_j2k_encode_multi and qsvc_motion_encode give on their own."""
+    from qsvc_amd.pipeline import CompressParams, Compressor
+    W, H, bs, TRLs = 192, 128, 16, 4
+    comp = Compressor(eng, CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=TRLs, GOPs=1, block_size=bs, block_size_min=bs, SRLs=4, lossless=lossless,
+                                          nLayers=3))
+    comp.configure(); comp.load(make_clip("edge", comp.pictures, W, H, 13))
+    comp.analyze()
+    _, mot = comp.motion()
+    tex = comp.texture()
+    tex2, mot2 = comp.code()
+    assert sorted(tex) == sorted(tex2) and sorted(mot) == sorted(mot2)
+    for k in tex:
+        assert tex[k] == tex2[k], k
+    for t in mot:
+        assert mot[t] == mot2[t], t
+    assert comp.texture() == tex   # and the texture batch alone again afterwards (the encoder's resident tables follow the batch's shape)
