@@ -35,6 +35,8 @@ void launch_sp_search(hipStream_t st, const SpGeom& g, const uint8_t* frames, si
                       int lim, const int16_t* mv_in, int16_t* mv_out);
 uint8_t* launch_sp_refs(hipStream_t st, const uint8_t* frames, const LevelGeom& g, int mul, int count, int a, uint8_t* up, uint8_t* tmp);
 void launch_sp_predict(hipStream_t st, const LevelGeom& ge, const uint8_t* up, const int16_t* mv, int16_t* ppl);
+void launch_sp_predict_one(hipStream_t st, const LevelGeom& ge, const uint8_t* up, const int16_t* mv, int i, int16_t* pp, int16_t* tmp, int H, int W, int a,
+                           int16_t* out);
 int16_t* launch_sp_down(hipStream_t st, int16_t* ppl, int16_t* tmp, int count, int H, int W, int a);
 void launch_pred_margin(hipStream_t st, const PredArgs& a);  // mctf_margin.hip (Q7)
 void launch_update(hipStream_t st, const UpdArgs& a);

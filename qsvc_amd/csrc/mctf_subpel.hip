@@ -156,8 +156,11 @@ uint8_t* launch_sp_refs(hipStream_t st, const uint8_t* frames, const LevelGeom& 
 }
 // predict() without overlap at the up-sampled resolution (decorrelate.cpp:93-108,153-167): ge = the up-sampled geometry
 // (H << a, W << a, bs << a, S << a, ov << a); up = [nB+1][3][ge.H][ge.W]; ppl = [nB][3][ge.H][ge.W] int16
-__global__ void __launch_bounds__(256) k_sp_predict(LevelGeom ge, const uint8_t* up, const int16_t* mv, int16_t* ppl) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z / 3, c = blockIdx.z % 3;
+// one: only B picture `one` (>= 0), into the three planes at ppl, and what predict() does not write (rows / columns beyond the block
+// grid, Q7) is LEFT AS IT IS -- the persistent prediction planes of a ragged picture (launch_sp_predict_one); one < 0: all pictures,
+// plane (i, c) at ppl + (3 i + c) planes.
+__global__ void __launch_bounds__(256) k_sp_predict(LevelGeom ge, const uint8_t* up, const int16_t* mv, int16_t* ppl, int one) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, i = one >= 0 ? one : blockIdx.z / 3, c = blockIdx.z % 3;
   if (x >= ge.W || y >= ge.H) return;
   const size_t plane = (size_t)ge.H * ge.W, fld = (size_t)ge.BY * ge.BX;
   const int by = y / ge.bs, bx = x / ge.bs;
@@ -168,11 +171,33 @@ __global__ void __launch_bounds__(256) k_sp_predict(LevelGeom ge, const uint8_t*
     const uint8_t* r0 = up + ((size_t)i * 3 + c) * plane;
     const uint8_t* r1 = up + ((size_t)(i + 1) * 3 + c) * plane;
     p = (luma_b(r0, bg, y + m[fld], x + m[0]) + luma_b(r1, bg, y + m[3 * fld], x + m[2 * fld])) >> 1;
-  }
-  ppl[((size_t)i * 3 + c) * plane + (size_t)y * ge.W + x] = (int16_t)p;
+  } else if (one >= 0) return;
+  ppl[((size_t)(one >= 0 ? 0 : i) * 3 + c) * plane + (size_t)y * ge.W + x] = (int16_t)p;
 }
 void launch_sp_predict(hipStream_t st, const LevelGeom& ge, const uint8_t* up, const int16_t* mv, int16_t* ppl) {
-  hipLaunchKernelGGL(k_sp_predict, dim3((ge.W + 63) / 64, (ge.H + 3) / 4, ge.nB * 3), dim3(64, 4), 0, st, ge, up, mv, ppl);
+  hipLaunchKernelGGL(k_sp_predict, dim3((ge.W + 63) / 64, (ge.H + 3) / 4, ge.nB * 3), dim3(64, 4), 0, st, ge, up, mv, ppl, -1);
+}
+// Ragged pictures (Q7 at the up-sampled size): the reference's three prediction planes are allocated once per level and never
+// cleared; predict() writes the block grid's area, the whole plane is clipped, analysed IN PLACE (a levels, chroma one more), and
+// what lies beyond the block grid keeps that state for the next picture.  Literal, one B picture after the other:
+//   pp   [3][Ha][Wa] int16, zero before the level's first picture (a fresh heap), carried from picture to picture
+//   out  [3][H][W] compact: the planes' top-left H x W after the a levels (chroma before its extra level: launch_pred_finish takes it)
+__global__ void __launch_bounds__(256) k_sp_clip(int16_t* p, size_t n) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) { const int v = p[k]; p[k] = (int16_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+}
+__global__ void __launch_bounds__(256) k_sp_extract(const int16_t* pp, int16_t* out, int H, int W, int Ha, int Wa) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, c = blockIdx.z;
+  if (x < W && y < H) out[((size_t)c * H + y) * W + x] = pp[((size_t)c * Ha + y) * Wa + x];
+}
+void launch_sp_predict_one(hipStream_t st, const LevelGeom& ge, const uint8_t* up, const int16_t* mv, int i, int16_t* pp, int16_t* tmp, int H, int W,
+                           int a, int16_t* out) {
+  const size_t N = (size_t)ge.H * ge.W;
+  hipLaunchKernelGGL(k_sp_predict, dim3((ge.W + 63) / 64, (ge.H + 3) / 4, 3), dim3(64, 4), 0, st, ge, up, mv, pp, i);
+  hipLaunchKernelGGL(k_sp_clip, dim3((unsigned)((3 * N + 255) / 256)), dim3(256), 0, st, pp, 3 * N);                        // decorrelate.cpp:841-848
+  for (int k = 0; k < a; k++) launch_rp_dwt(st, pp, tmp, N, 3, ge.W, ge.H >> k, ge.W >> k, 0);                                // :852-857
+  hipLaunchKernelGGL(k_sp_extract, dim3((W + 63) / 64, (H + 3) / 4, 3), dim3(64, 4), 0, st, pp, out, H, W, ge.H, ge.W);
+  launch_rp_dwt(st, pp + N, tmp + N, N, 2, ge.W, H, W, 0);                                                                   // :860-861 (the state the next picture finds)
 }
 // the low-low band of one analysis level (decorrelate.cpp:852-857) of `count` compact ny x nx planes -> compact (ny/2) x (nx/2)
 // planes; clip: the planes are clipped to 0..255 first (decorrelate.cpp:841-848, before the first level only)

@@ -463,9 +463,10 @@ static int predict_overlapped(qsvc_ctx* c, const LevelGeom& g, const PredArgs& a
 // resolution, the prediction brought down through the low-low bands of a analysis levels, then residue / histograms as usual.
 static int predict_subpel(qsvc_ctx* c, const LevelGeom& g, const PredArgs& a) {
   const int s = g.sub, Ha = g.H << s, Wa = g.W << s;
-  if (g.H % g.bs || g.W % g.bs)
-    return c->fail(QSVC_ERR_UNSUPPORTED, "subpixel_accuracy on a %dx%d picture the block grid (%d) does not tile: the stale margins of the reference's "
-                   "up-sampled prediction planes (Q7) are not reproduced on this path", g.W, g.H, g.bs);
+  const bool ragged = g.H % g.bs || g.W % g.bs;
+  if (ragged && g.ov >= 1)
+    return c->fail(QSVC_ERR_UNSUPPORTED, "subpixel_accuracy with block_overlaping on a %dx%d picture the block grid (%d) does not tile is not "
+                   "implemented on this path", g.W, g.H, g.bs);
   if ((Wa > 16384 || Ha > 16384)) return c->fail(QSVC_ERR_UNSUPPORTED, "picture %dx%d << %d exceeds the reference's line buffer (16384)", g.W, g.H, s);
   LevelGeom ge = g;
   ge.W = Wa; ge.H = Ha; ge.bs = g.bs << s; ge.S = g.S << s; ge.ov = g.ov << s; ge.sub = 0;
@@ -477,6 +478,19 @@ static int predict_subpel(qsvc_ctx* c, const LevelGeom& g, const PredArgs& a) {
   if ((r = c->ovl[1].ensure(c, pb))) return r;
   const uint8_t* up = launch_sp_refs(c->st, a.frames, g, 2, g.nB + 1, s, (uint8_t*)c->sp[0].p, (uint8_t*)c->sp[1].p);
   int16_t* p0 = (int16_t*)c->ovl[0].p; int16_t* p1 = (int16_t*)c->ovl[1].p;
+  if (ragged) {
+    // Q7 at the up-sampled size: the prediction planes carry state from picture to picture, so the level is walked literally, one B
+    // picture after the other, on three persistent planes (mctf_subpel.hip: launch_sp_predict_one)
+    const size_t N = (size_t)Ha * Wa, n1 = (size_t)g.H * g.W;
+    if ((r = c->margin.ensure(c, (3 * N + (size_t)g.nB * 3 * n1) * sizeof(int16_t)))) return r;
+    int16_t* pp = (int16_t*)c->margin.p; int16_t* outp = pp + 3 * N;
+    HIPCHK(c, hipMemsetAsync(pp, 0, 3 * N * sizeof(int16_t), c->st));
+    for (int i = 0; i < g.nB; i++) launch_sp_predict_one(c->st, ge, up, a.mv, i, pp, p0, g.H, g.W, s, outp + (size_t)i * 3 * n1);
+    PredArgs af = a;
+    af.margin = nullptr;
+    launch_pred_finish(c->st, af, outp, 0);
+    return QSVC_OK;
+  }
   if (ge.ov >= 2) {  // predict(block_overlaping << a, block_size << a, ...) (decorrelate.cpp:828-839)
     PredArgs ae = a;
     ae.g = ge; ae.up = up; ae.cup = nullptr; ae.margin = nullptr;
@@ -614,7 +628,7 @@ static int decorrelate_impl(qsvc_ctx* c, int t, int P, int bs, int S, int always
   a.mv_copy = nullptr; a.hist_is_zero = lv.hist_zeroed ? 1 : 0; a.up = nullptr;
   lv.hist_zeroed = false;
   lv.ragged = (g.H % bs || g.W % bs);
-  if (lv.ragged) {  // Q7: the chroma margins carry state from picture to picture
+  if (lv.ragged && !g.sub) {  // Q7: the chroma margins carry state from picture to picture
     if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
     a.margin = (int16_t*)c->margin.p;
   }
@@ -850,7 +864,7 @@ int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   a.high = (uint8_t*)lv.high.p; a.pred_dump = c->keep_pred ? (uint8_t*)lv.pred.p : nullptr; a.hist = nullptr;
   a.margin = nullptr; a.odd_out = (uint8_t*)out.low.p; a.types = (const uint8_t*)c->tmp16[0].p; a.cup = nullptr;
   a.mv_copy = nullptr; a.hist_is_zero = 0; a.up = nullptr;
-  if (g.H % bs || g.W % bs) {  // Q7 applies to the decoder's prediction planes as well
+  if ((g.H % bs || g.W % bs) && !g.sub) {  // Q7 applies to the decoder's prediction planes as well
     if ((r = c->margin.ensure(c, (size_t)g.nB * 2 * margin_geom(g).count() * sizeof(int16_t)))) return r;
     a.margin = (int16_t*)c->margin.p;
   }

@@ -27,8 +27,7 @@ def test_restatement_matches_reference_goldens(oracle, name):
         assert sha(low) == str(z[f"synth_low_{t - 1}_sha"]), f"synth_low_{t - 1}"
 
 
-# sub-pixel accuracy on a picture the block grid does not tile (Q7 at the up-sampled size) is refused by the GPU path
-GPU_REFUSED = {"sub3_q7_200x120", "sub1_q5_350x286"}
+GPU_REFUSED = set()   # (every golden chain runs on the GPU path, incl. sub-pixel accuracy on pictures the block grid does not tile)
 
 
 @pytest.mark.gpu
@@ -72,8 +71,8 @@ def test_unsupported_options_are_refused():
         assert ei.value.code == -2
         with pytest.raises(hip.QsvcError):
             e.set_mctf_options(block_overlaping=3)
-        # sub-pixel accuracy: search range 1 (the reference's own motion_estimate crashes there), vectors that leave the 256-bin
-        # motion histogram, and a picture the block grid does not tile (its stale up-sampled prediction margins are not reproduced)
+        # sub-pixel accuracy: search range 1 (the reference's own motion_estimate crashes there) and vectors that leave the 256-bin
+        # motion histogram
         from qsvc_amd.synth import make_clip
         e.set_mctf_options(subpixel_accuracy=2)
         e.put_frames(hip.LOW, 0, make_clip("pan", 3, 128, 96, 1))
@@ -81,15 +80,6 @@ def test_unsupported_options_are_refused():
             with pytest.raises(hip.QsvcError) as ei:
                 e.motion_estimate(1, 3, 16, S)
             assert ei.value.code == -2
-        z, m = load_n4("sub3_q7_200x120")
-        e.seq_config(m["W"], m["H"])
-        e.set_mctf_options(subpixel_accuracy=m["sub"])
-        e.put_frames(hip.LOW, 0, golden_input(z, m))
-        e.motion_estimate(1, m["frames"], m["bs"], m["S"])
-        np.testing.assert_array_equal(e.get_motion(hip.MOTION_RAW, 1, m["frames"] // 2, m["bs"]), z["motion_1"])   # the search is fine
-        with pytest.raises(hip.QsvcError) as ei:
-            e.decorrelate(1, m["frames"], m["bs"], m["S"])
-        assert ei.value.code == -2
     finally:
         e.close()
 
@@ -106,3 +96,38 @@ def test_subpixel_probe_record():
         assert r["exit_codes"] == [0, 0, 0, 0] and r["repeat_identical"]
         assert "motion_1" in r["files_depending_on_heap_fill"]
         assert r["malloc_perturb_165"]["motion_1"] != r["default_malloc"]["motion_1"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,seed,frames,W,H,TRLs,bs,S,sub", [("pan_noise", 71, 9, 200, 120, 3, 32, 4, 1), ("edge", 72, 5, 120, 68, 2, 16, 4, 2),
+                                                                ("saturating", 73, 9, 72, 56, 3, 16, 2, 1)])
+def test_hip_subpixel_on_ragged_pictures_equals_restatement(oracle, kind, seed, frames, W, H, TRLs, bs, S, sub):
+    """Sub-pixel accuracy on pictures the block grid does not tile (the reference's default block size at 1080p is such a case):
+    the up-sampled prediction planes carry their in-place analysis state from picture to picture (Q7), several B pictures deep,
+    forward and back."""
+    from qsvc_amd import hip
+    from qsvc_amd.synth import make_clip
+    clip = make_clip(kind, frames, W, H, seed)
+    want = oracle.analyze(clip, W, H, TRLs, bs, S, subpixel_accuracy=sub)
+    e = hip.Engine(0)
+    try:
+        e.seq_config(W, H, keep_prediction=True)
+        e.set_mctf_options(subpixel_accuracy=sub)
+        e.put_frames(hip.LOW, 0, clip)
+        P, St = frames, S
+        for t, w in enumerate(want, 1):
+            e.analyze_step(t, P, bs, St)
+            nB = P // 2
+            np.testing.assert_array_equal(e.get_motion(hip.MOTION_RAW, t, nB, bs), w["motion"], err_msg=f"motion_{t}")
+            assert e.get_frame_types(t, nB) == w["frame_types"]
+            np.testing.assert_array_equal(e.get_frames(hip.HIGH, t, 0, nB), w["high"], err_msg=f"high_{t}")
+            np.testing.assert_array_equal(e.get_frames(hip.LOW, t, 0, nB + 1), w["low"], err_msg=f"low_{t}")
+            P, St = (P + 1) // 2, min(2 * St, 128)
+        low = want[-1]["low"]
+        for t in range(len(want), 0, -1):
+            w, Pt = want[t - 1], want[t - 1]["pictures"]
+            low = oracle.synthesize_step(low, w["high"], w["motion_filtered"], w["frame_types"], W, H, bs, w["search_range"], subpixel_accuracy=sub)["low"]
+            e.synthesize_step(t, 2 * (Pt // 2) + 1, bs, w["search_range"])
+            np.testing.assert_array_equal(e.get_frames(hip.LOW, t - 1, 0, 2 * (Pt // 2) + 1), low, err_msg=f"synth_low_{t - 1}")
+    finally:
+        e.close()
