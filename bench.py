@@ -33,12 +33,12 @@ sys.path.insert(0, ROOT)
 # BASELINE.json configs[2] (the judged default) and configs[3] ("4K 32-frame GOP, 9/7 irreversible, 4 temporal + 5 spatial levels"):
 # geometry, TRLs, GOPs, block size, first search range, SRLs, pictures per GPU window, default transform, sessions in flight, PMC file
 CONFIGS = {
-    3: dict(W=1920, H=1080, TRLS=4, GOPS=2, BS=8, S0=4, SRLS=5, G=16, reversible=1, sessions=12, pmc="r03_pmc_hbm.json", name="1080p"),
-    4: dict(W=3840, H=2160, TRLS=5, GOPS=2, BS=16, S0=4, SRLS=6, G=32, reversible=0, sessions=4, pmc="r03_cfg4_pmc_hbm.json", name="4K"),
+    3: dict(W=1920, H=1080, TRLS=4, GOPS=2, BS=8, S0=4, SRLS=5, G=16, reversible=1, sessions=12, pmc="r04_pmc_hbm.json", name="1080p"),
+    4: dict(W=3840, H=2160, TRLS=5, GOPS=2, BS=16, S0=4, SRLS=6, G=32, reversible=0, sessions=4, pmc="r04_cfg4_pmc_hbm.json", name="4K"),
 }
 W, H, TRLS, GOPS, BS, S0, SRLS = 1920, 1080, 4, 2, 8, 4, 5   # overwritten from CONFIGS[--config] in main()
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = "r03_pmc_hbm.json"  # tools/refresh_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, one sequence in flight
+PMC_FILE = "r04_pmc_hbm.json"  # tools/refresh_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, one sequence in flight
 
 
 def codeblocks_per_frame(w, h, levels, cb=64):

@@ -5,7 +5,7 @@
 // Everything works on RUNS OF 8 SAMPLES of one row that share one MC block, as packed bytes / packed 16-bit pairs:
 //   * a displaced reference run is one unaligned 8-byte load; per-byte (a + b) >> 1 without carries between bytes;
 //   * the residue clamp(odd - pred, -128, 127) + 128 on 16-bit pairs (v_pk_sub_i16, v_pk_max/min_i16);
-//   * the luma histograms go to 16 interleaved copies per bin in LDS (the residue histogram is one narrow peak: with a single
+//   * the luma histograms go to 8 interleaved copies per bin in LDS (the residue histogram is one narrow peak: with a single
 //     copy the 64 lanes of a wave queue up on one address);
 //   * chroma is predicted at full resolution straight from the HALF-resolution planes -- the x2 interpolation of
 //     decorrelate.cpp:610-648 (one level of truncating 5/3 synthesis with zero high bands = averages of neighbours, columns first)
@@ -22,7 +22,9 @@ namespace qsvc {
 
 // ---------------------------------------------------------------------------------------------
 // luma: a thread owns one run of 8 samples in each of 4 rows; LDS histograms of the odd picture and of residue + 128
-#define PL_K 16   // histogram copies per bin
+#ifndef PL_K
+#define PL_K 8    // histogram copies per bin: 16 KB of LDS per workgroup = 8 waves per SIMD (round 4: with 16 copies and 32 KB the kernel ran
+#endif            // at 5 waves per SIMD and waited half of its cycles on memory; 8 copies: 0.187 -> 0.158 ms per 1080p step, 4K 1.30 -> 1.04 ms)
 __device__ __forceinline__ void pred_luma_body(const PredArgs& a, uint8_t* smem, const int bx_, const int by_, const int bz_, const int tx_, const int ty_) {
   unsigned (*hs)[256 * PL_K] = (unsigned (*)[256 * PL_K])smem;
   const int tid = ty_ * 64 + tx_;

@@ -25,6 +25,7 @@ for k in f:
     fb, wb = sum(f[k]) * 1024 / n, sum(w.get(k, [0])) * 1024 / max(len(w.get(k, [0])), 1)
     out[k] = {"launches_profiled": n, "fetch_bytes_per_launch_raw": int(fb), "write_bytes_per_launch": int(wb),
               "hbm_bytes_per_launch_raw": int(fb + wb), "hbm_bytes_per_launch_fetch_doubled": int(2 * fb + wb),
-              "hbm_bytes_per_step_raw": int((sum(f[k]) + sum(w.get(k, [0]))) * 1024 / steps), "encodes_profiled": steps}
+              "hbm_bytes_per_step_raw": int((sum(f[k]) + sum(w.get(k, [0]))) * 1024 / steps),
+              "hbm_bytes_per_step_fetch_doubled": int((2 * sum(f[k]) + sum(w.get(k, [0]))) * 1024 / steps), "encodes_profiled": steps}
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True)[:1500])
