@@ -220,57 +220,96 @@ const char* parse_stream(const uint8_t* cs, size_t n, int max_layers, DecPlane& 
 // ---- device: MQ decoder + Tier-1 decoding, one code-block per lane ----------------------------------------------------------
 __constant__ uint32_t c_dmq[47] = T1_MQ_TABLE_INIT;  // qe | nmps << 16 | nlps << 22 | switch << 28
 
-struct MqDec {
+// Round 4 form of the block decoder.  One code-block per wave with ONE decoding lane, as in round 3 (the decoding direction is
+// serial per block and its control flow is data dependent at every sample: lanes that decode different blocks in one wave each
+// pay for every other lane's path), but the per-decision cost is cut from about 600 instructions-and-waits to about a hundred:
+//   * state = one 32-bit FLAG WORD PER STRIPE COLUMN in LDS (significance of the column's 6 x 3 neighbourhood, signs of its six
+//     rows, "visited" and "refined" of its four samples) instead of a byte per sample: a column nobody can code in this pass is
+//     skipped with one test (no significant neighbour for the significance pass, no significant sample for the refinement, an
+//     all-zero word = run mode for the clean-up), and a sample's context is a table look-up on 9 bits of the word;
+//   * the MQ decoder's probability table lives in LDS and every context slot holds its table ENTRY (Qe and both successors), so a
+//     decision costs one LDS read, and one more only when the state changes (round 3: a byte from LDS, then the entry through the
+//     vector memory path of a __constant__ array, 300+ cycles, per decision);
+//   * renormalisation shifts by the whole count at once; the code bytes come through a 16-byte register window refilled 8 bytes
+//     ahead, not one global byte load per byte.
+// The magnitude bits still go to the coefficient plane as OR-atomics that return nothing (bit 31 = the sign); k_dec_dequant turns
+// the words into coefficients.  The per-sample "last coded plane" bytes are only written for blocks whose passes were truncated
+// (quality layers left out): a fully decoded block has none.  The wave's other 63 lanes build the tables and clear the flag words.
+#define DEC_LANES 1
+#define DEC_FW_WORDS (18 * 66)     // flag words: stripes -1 .. 16, columns -1 .. 64
+#define DFW(s, x) fw[((s) + 1) * 66 + (x) + 1]
+#define DF_SIGALL 0x3FFFFu
+#define DF_CHI 18
+#define DF_PI 24
+#define DF_MU 28
+struct MqDec2 {
   uint32_t A, C; int CT;
-  const uint8_t *bp, *end;
-  uint8_t* ctx;   // LDS: ctx[cx * 64] = state << 1 | mps
-  __device__ void bytein() {
-    if (bp < end) {
-      if (*bp == 0xFF) {
-        const int nx = bp + 1 < end ? bp[1] : 0xFF;
-        if (nx > 0x8F) { C += 0xFF00; CT = 8; } else { bp++; C += (uint32_t)nx << 9; CT = 7; }
-      } else { bp++; C += (uint32_t)(bp < end ? *bp : 0xFF) << 8; CT = 8; }
+  const uint8_t* base; int len, pos;   // the segment; bytes consumed
+  uint64_t w0, w1; int wpos;            // bytes [wpos, wpos + 8) and [wpos + 8, wpos + 16) of the segment (0xFF past its end); pos >= wpos
+  uint32_t* cw;                         // LDS: context words = table entry of the context's state | mps << 31
+  const uint32_t* tbl;                  // LDS: the 47 entries
+  __device__ __forceinline__ uint64_t fetch8(int at) const {
+    uint64_t v = ~0ull;
+    if (at + 8 <= len) __builtin_memcpy(&v, base + at, 8);
+    else for (int k = 0; k < 8; k++) if (at + k < len) v = (v & ~(0xFFull << (8 * k))) | ((uint64_t)base[at + k] << (8 * k));
+    return v;
+  }
+  __device__ __forceinline__ int byte_at(int i) {   // byte i of the segment, pos <= i <= pos + 1; 0xFF past the end
+    if (i >= wpos + 16) { w0 = w1; wpos += 8; w1 = fetch8(wpos + 8); }   // (the next 8 bytes are requested 8 bytes before they are needed)
+    const int o = i - wpos;
+    return (int)(((o < 8 ? w0 : w1) >> (8 * (o & 7))) & 0xFF);
+  }
+  __device__ __forceinline__ void bytein() {   // T.800 C.3.4
+    if (pos < len) {
+      const int b = byte_at(pos);
+      if (b == 0xFF) {
+        const int nx = pos + 1 < len ? byte_at(pos + 1) : 0xFF;
+        if (nx > 0x8F) { C += 0xFF00; CT = 8; } else { pos++; C += (uint32_t)nx << 9; CT = 7; }
+      } else { pos++; C += (uint32_t)(pos < len ? byte_at(pos) : 0xFF) << 8; CT = 8; }
     } else { C += 0xFF00; CT = 8; }
   }
-  __device__ void init(const uint8_t* data, int len, uint8_t* lds_ctx) {
-    ctx = lds_ctx;
-    for (int i = 0; i < 19; i++) ctx[i * 64] = 0;
-    ctx[0] = 4 << 1; ctx[17 * 64] = 3 << 1; ctx[18 * 64] = 46 << 1;
-    bp = data; end = data + len;
-    C = (uint32_t)(len > 0 ? data[0] : 0xFF) << 16;
+  __device__ void init(const uint8_t* data, int n, uint32_t* lds_cw, const uint32_t* lds_tbl) {
+    cw = lds_cw; tbl = lds_tbl; base = data; len = n; pos = 0; wpos = 0;
+    w0 = fetch8(0); w1 = fetch8(8);
+    for (int i = 0; i < 19; i++) cw[i] = tbl[0];
+    cw[0] = tbl[4]; cw[17] = tbl[3]; cw[18] = tbl[46];
+    C = (uint32_t)(len > 0 ? byte_at(0) : 0xFF) << 16;
     bytein();
     C <<= 7; CT -= 7; A = 0x8000;
   }
-  __device__ int decode(int cx) {
-    const int sm = ctx[cx * 64], st = sm >> 1, mps = sm & 1;
-    const uint32_t e = c_dmq[st], qe = e & 0xFFFF;
-    int d;
+  __device__ __forceinline__ int decode(int cx) {   // T.800 C.3.2
+    const uint32_t e = cw[cx], qe = e & 0xFFFF;
+    const int mps = (int)(e >> 31);
+    int d, lps;   // lps: the state moves along the LPS branch
     A -= qe;
     if ((C >> 16) < qe) {
-      if (A < qe) { d = mps; ctx[cx * 64] = (uint8_t)((((e >> 16) & 63) << 1) | mps); }
-      else { d = 1 - mps; ctx[cx * 64] = (uint8_t)((((e >> 22) & 63) << 1) | (mps ^ ((e >> 28) & 1))); }
+      lps = !(A < qe);
       A = qe;
     } else {
       C -= qe << 16;
       if (A & 0x8000) return mps;
-      if (A < qe) { d = 1 - mps; ctx[cx * 64] = (uint8_t)((((e >> 22) & 63) << 1) | (mps ^ ((e >> 28) & 1))); }
-      else { d = mps; ctx[cx * 64] = (uint8_t)((((e >> 16) & 63) << 1) | mps); }
+      lps = A < qe;
     }
-    do { if (CT == 0) bytein(); A <<= 1; C <<= 1; CT--; } while ((A & 0x8000) == 0);
+    d = lps ? 1 - mps : mps;
+    const uint32_t ns = lps ? (e >> 22) & 63 : (e >> 16) & 63;
+    const uint32_t nm = lps ? (uint32_t)mps ^ ((e >> 28) & 1) : (uint32_t)mps;
+    cw[cx] = tbl[ns] | nm << 31;
+    int sh = __builtin_clz(A) - 16;   // A < 0x8000 here: 1 .. 15 shifts
+    while (sh > 0) {
+      if (CT == 0) bytein();
+      const int n = sh < CT ? sh : CT;
+      A <<= n; C <<= n; CT -= n; sh -= n;
+    }
     return d;
   }
 };
-
-enum { DF_SIG = 1, DF_VISIT = 2, DF_REFINED = 4, DF_NEG = 8 };
-#define DFL(y, x) fl[((y) + 1) * 66 + (x) + 1]
-
-__device__ __forceinline__ int d_zc(const uint8_t* fl, int y, int x, int orient) {  // Table D.1
-  int h = (DFL(y, x - 1) & DF_SIG) + (DFL(y, x + 1) & DF_SIG);
-  int v = (DFL(y - 1, x) & DF_SIG) + (DFL(y + 1, x) & DF_SIG);
-  int d = (DFL(y - 1, x - 1) & DF_SIG) + (DFL(y - 1, x + 1) & DF_SIG) + (DFL(y + 1, x - 1) & DF_SIG) + (DFL(y + 1, x + 1) & DF_SIG);
-  if (orient == 1) { int t = h; h = v; v = t; }
+// zero-coding context (Table D.1) of the 8 neighbours in a 9-bit window (bit 3 r + c, r = row above / own / below, c = left / own / right)
+__device__ __forceinline__ int d_zc_of(int n9, int orient) {
+  int h = ((n9 >> 3) & 1) + ((n9 >> 5) & 1), v = ((n9 >> 1) & 1) + ((n9 >> 7) & 1);
+  const int d = (n9 & 1) + ((n9 >> 2) & 1) + ((n9 >> 6) & 1) + ((n9 >> 8) & 1);
+  if (orient == 1) { const int t = h; h = v; v = t; }
   if (orient == 3) {
-    int hv = h + v;
+    const int hv = h + v;
     if (d >= 3) return 8;
     if (d == 2) return hv >= 1 ? 7 : 6;
     if (d == 1) return hv >= 2 ? 5 : (hv == 1 ? 4 : 3);
@@ -282,107 +321,143 @@ __device__ __forceinline__ int d_zc(const uint8_t* fl, int y, int x, int orient)
   if (v == 1) return 3;
   return d >= 2 ? 2 : (d == 1 ? 1 : 0);
 }
-__device__ __forceinline__ int d_sc(const uint8_t* fl, int y, int x, int* xorbit) {  // Tables D.2 / D.3
-  int hc = 0, vc = 0, f;
-  f = DFL(y, x - 1); if (f & DF_SIG) hc += (f & DF_NEG) ? -1 : 1;
-  f = DFL(y, x + 1); if (f & DF_SIG) hc += (f & DF_NEG) ? -1 : 1;
-  f = DFL(y - 1, x); if (f & DF_SIG) vc += (f & DF_NEG) ? -1 : 1;
-  f = DFL(y + 1, x); if (f & DF_SIG) vc += (f & DF_NEG) ? -1 : 1;
-  hc = hc > 1 ? 1 : (hc < -1 ? -1 : hc);
-  vc = vc > 1 ? 1 : (vc < -1 ? -1 : vc);
-  const int k = (hc + 1) * 3 + (vc + 1);  // ctx {13,12,11,10,9,10,11,12,13}, xor {1,1,1,1,0,0,0,0,0}
-  *xorbit = k < 4;
-  return k == 4 ? 9 : (k == 3 || k == 5 ? 10 : (k == 2 || k == 6 ? 11 : (k == 1 || k == 7 ? 12 : 13)));
-}
-__device__ __forceinline__ int d_anysig(const uint8_t* fl, int y, int x) {
-  return (DFL(y, x - 1) | DFL(y, x + 1) | DFL(y - 1, x) | DFL(y + 1, x) | DFL(y - 1, x - 1) | DFL(y - 1, x + 1) | DFL(y + 1, x - 1) | DFL(y + 1, x + 1)) & DF_SIG;
-}
-
-// Round 3 form of the block decoder.  The decoding direction is serial per block and its control flow is data dependent at every
-// sample (which pass a sample belongs to, run mode, renormalisation shifts), so lanes that decode different blocks in one wave
-// each pay for every other lane's path: with 64 blocks per wave the wave executed the union of 64 control flows (measured:
-// 159 ms for the 15 657 blocks of config 3, and no faster with the flags in LDS -- it was instruction stream, not memory).  A
-// GPU has more wave slots than a sequence has code-blocks per round: so ONE CODE-BLOCK PER WAVE (a single active lane; the
-// other 63 idle), a wave runs only its own block's path.  The per-sample flag plane lives in LDS (66 x 66 bytes per wave, up to
-// 29 waves per CU), and the magnitude bits go to the coefficient plane as OR-atomics that return nothing (bit 31 = the sign):
-// the kernel never waits for global memory except for its code bytes.  k_dec_dequant then turns the words into coefficients.
-#define DEC_LANES 1
-#define DEC_FL_BYTES (66 * 66)
 __global__ void __launch_bounds__(64) k_t1_decode_lds(const DecCb* cbs, int ncb, const uint8_t* segs, uint8_t* lastp_all, void* coefv, int lane0, int nlanes) {
-  __shared__ uint8_t s_ctx[19 * 64];
-  __shared__ __attribute__((aligned(4))) uint8_t s_fl[DEC_LANES * DEC_FL_BYTES];
-  // a whole wave is launched, lanes lane0 .. lane0 + nlanes - 1 decode (0 and DEC_LANES, passed as arguments: with the lane index a
-  // compile-time constant the build of ROCm 7.2 produced a kernel that decoded garbage -- 16 VGPRs, everything scalarised)
-  const int dl = (int)threadIdx.x - lane0;
-  if (dl < 0 || dl >= nlanes) return;
-  const int b = blockIdx.x * DEC_LANES + dl;
+  __shared__ uint32_t s_fw[DEC_FW_WORDS];
+  __shared__ uint32_t s_tbl[48];
+  __shared__ uint32_t s_cw[20];
+  __shared__ uint8_t s_zc[512];
+  const int b = blockIdx.x;
   if (b >= ncb) return;
   const DecCb cb = cbs[b];
-  uint8_t* fl = s_fl + dl * DEC_FL_BYTES;   // this lane's flag plane (a word stride of 1089: lanes start one bank apart)
-  for (int k = 0; k < DEC_FL_BYTES / 4; k++) ((uint32_t*)fl)[k] = 0;
+  {  // the whole wave: tables and a clean flag plane
+    const int t = threadIdx.x;
+    for (int k = t; k < DEC_FW_WORDS; k += 64) s_fw[k] = 0;
+    if (t < 47) s_tbl[t] = c_dmq[t];
+    for (int k = t; k < 512; k += 64) s_zc[k] = (uint8_t)d_zc_of(k, cb.orient);
+  }
+  __syncthreads();
+  // lane lane0 decodes (passed as an argument: with the lane index a compile-time constant the ROCm 7.2 build scalarised the whole
+  // kernel and decoded garbage)
+  if ((int)threadIdx.x != lane0 || nlanes < 1) return;
+  uint32_t* fw = s_fw;
   uint8_t* lastp = lastp_all + (size_t)b * 64 * 64;
   int32_t* mag = (int32_t*)coefv + cb.plane_off + (size_t)cb.y0 * cb.W + cb.x0;  // row stride cb.W
-  const int w = cb.w, h = cb.h, orient = cb.orient, W = cb.W;
-  MqDec m;
-  m.init(segs + cb.seg, cb.len, s_ctx + dl);
+  const int w = cb.w, h = cb.h, W = cb.W, nstr = (h + 3) >> 2;
+  const bool full = cb.npasses >= 3 * cb.nbps - 2;   // every pass present: every sample's last coded plane is 0
+  MqDec2 m;
+  m.init(segs + cb.seg, cb.len, s_cw, s_tbl);
   int np = 0;
 #define MAG_OR(y, x, bits) atomicOr((unsigned*)&mag[(size_t)(y) * W + (x)], (unsigned)(bits))   /* no value comes back: never waited for */
-#define DEC_SIGN(y, x) do { int xb_, cx_ = d_sc(fl, (y), (x), &xb_); int s_ = m.decode(cx_) ^ xb_; DFL((y), (x)) |= (uint8_t)(DF_SIG | (s_ ? DF_NEG : 0)); \
-                            if (s_) MAG_OR((y), (x), 0x80000000u); } while (0)
+  // sample (stripe s, column x, row k) becomes significant with sign neg: every word whose neighbourhood holds it (t1_set_sig of
+  // tests/emul/t1_legacy.h in the decoding direction; `f` is the column's own word, kept in a register by the caller)
+  auto set_sig = [&](int s, int x, int k, int neg, uint32_t& f) {
+    f |= (1u << (3 * (k + 1) + 1)) | ((uint32_t)neg << (DF_CHI + k + 1));
+    atomicOr(&DFW(s, x - 1), 1u << (3 * (k + 1) + 2));
+    atomicOr(&DFW(s, x + 1), 1u << (3 * (k + 1) + 0));
+    if (k == 0) {
+      atomicOr(&DFW(s - 1, x - 1), 1u << 17);
+      atomicOr(&DFW(s - 1, x), (1u << 16) | ((uint32_t)neg << (DF_CHI + 5)));
+      atomicOr(&DFW(s - 1, x + 1), 1u << 15);
+    } else if (k == 3) {
+      atomicOr(&DFW(s + 1, x - 1), 1u << 2);
+      atomicOr(&DFW(s + 1, x), (1u << 1) | ((uint32_t)neg << DF_CHI));
+      atomicOr(&DFW(s + 1, x + 1), 1u << 0);
+    }
+  };
+  // sign decoding (Tables D.2 / D.3): horizontal neighbours from the words left and right, vertical ones from the own word
+  auto dec_sign = [&](int s, int x, int k, uint32_t f) {
+    const uint32_t l = DFW(s, x - 1), r = DFW(s, x + 1);
+    const int rr = k + 1;
+    int hc = 0, vc = 0;
+    if (f & (1u << (3 * rr + 0))) hc += (l >> (DF_CHI + rr)) & 1 ? -1 : 1;
+    if (f & (1u << (3 * rr + 2))) hc += (r >> (DF_CHI + rr)) & 1 ? -1 : 1;
+    if (f & (1u << (3 * (rr - 1) + 1))) vc += (f >> (DF_CHI + rr - 1)) & 1 ? -1 : 1;
+    if (f & (1u << (3 * (rr + 1) + 1))) vc += (f >> (DF_CHI + rr + 1)) & 1 ? -1 : 1;
+    hc = hc > 1 ? 1 : (hc < -1 ? -1 : hc);
+    vc = vc > 1 ? 1 : (vc < -1 ? -1 : vc);
+    const int q = (hc + 1) * 3 + (vc + 1);  // ctx {13,12,11,10,9,10,11,12,13}, xor {1,1,1,1,0,0,0,0,0}
+    const int cx = q == 4 ? 9 : (q == 3 || q == 5 ? 10 : (q == 2 || q == 6 ? 11 : (q == 1 || q == 7 ? 12 : 13)));
+    return m.decode(cx) ^ (q < 4);
+  };
   for (int p = cb.nbps - 1; p >= 0 && np < cb.npasses; p--) {
     if (p != cb.nbps - 1) {
-      for (int y0 = 0; y0 < h; y0 += 4)
-        for (int x = 0; x < w; x++)
-          for (int y = y0; y < y0 + 4 && y < h; y++) {
-            const uint8_t f = DFL(y, x);
-            if ((f & DF_SIG) || !d_anysig(fl, y, x)) continue;
-            if (m.decode(d_zc(fl, y, x, orient))) { MAG_OR(y, x, 1u << p); DEC_SIGN(y, x); }
-            lastp[y * 64 + x] = (uint8_t)p;
-            DFL(y, x) |= DF_VISIT;
+      // significance propagation
+      for (int s = 0; s < nstr; s++) {
+        const int hs = h - 4 * s < 4 ? h - 4 * s : 4;
+        for (int x = 0; x < w; x++) {
+          uint32_t f = DFW(s, x);
+          if ((f & DF_SIGALL) == 0) continue;   // nothing significant anywhere around this column
+          const uint32_t f0 = f;
+          for (int k = 0; k < hs; k++) {
+            if (f & (1u << (3 * k + 4))) continue;                 // already significant
+            const uint32_t n9 = (f >> (3 * k)) & 0x1EF;
+            if (!n9) continue;
+            if (m.decode(s_zc[n9])) {
+              const int neg = dec_sign(s, x, k, f);
+              set_sig(s, x, k, neg, f);
+              MAG_OR(4 * s + k, x, (1u << p) | (neg ? 0x80000000u : 0u));
+            }
+            f |= 1u << (DF_PI + k);
+            if (!full) lastp[(4 * s + k) * 64 + x] = (uint8_t)p;
           }
-      if (++np >= cb.npasses) break;
-      for (int y0 = 0; y0 < h; y0 += 4)
-        for (int x = 0; x < w; x++)
-          for (int y = y0; y < y0 + 4 && y < h; y++) {
-            const uint8_t f = DFL(y, x);
-            if (!(f & DF_SIG) || (f & DF_VISIT)) continue;
-            const int cx = (f & DF_REFINED) ? 16 : (d_anysig(fl, y, x) ? 15 : 14);
-            if (m.decode(cx)) MAG_OR(y, x, 1u << p);
-            lastp[y * 64 + x] = (uint8_t)p;
-            DFL(y, x) |= DF_REFINED;
-          }
-      if (++np >= cb.npasses) break;
-    }
-    for (int y0 = 0; y0 < h; y0 += 4)
-      for (int x = 0; x < w; x++) {
-        int y = y0;
-        if (y0 + 3 < h) {
-          bool run = true;
-          for (int k = 0; k < 4; k++)
-            if ((DFL(y0 + k, x) & (DF_SIG | DF_VISIT)) || d_anysig(fl, y0 + k, x)) { run = false; break; }
-          if (run) {
-            if (!m.decode(17)) { for (int k = 0; k < 4; k++) lastp[(y0 + k) * 64 + x] = (uint8_t)p; continue; }
-            int first = m.decode(18) << 1;
-            first |= m.decode(18);
-            for (int k = 0; k < first; k++) lastp[(y0 + k) * 64 + x] = (uint8_t)p;
-            y = y0 + first;
-            MAG_OR(y, x, 1u << p); lastp[y * 64 + x] = (uint8_t)p;
-            DEC_SIGN(y, x);
-            y++;
-          }
-        }
-        for (; y < y0 + 4 && y < h; y++) {
-          const uint8_t f = DFL(y, x);
-          if (f & (DF_SIG | DF_VISIT)) continue;
-          if (m.decode(d_zc(fl, y, x, orient))) { MAG_OR(y, x, 1u << p); DEC_SIGN(y, x); }
-          lastp[y * 64 + x] = (uint8_t)p;
+          if (f != f0) DFW(s, x) = f;
         }
       }
+      if (++np >= cb.npasses) break;
+      // magnitude refinement
+      for (int s = 0; s < nstr; s++) {
+        const int hs = h - 4 * s < 4 ? h - 4 * s : 4;
+        for (int x = 0; x < w; x++) {
+          uint32_t f = DFW(s, x);
+          if ((f & 0x2490u) == 0) continue;     // no significant sample in this column (bits 4, 7, 10, 13)
+          const uint32_t f0 = f;
+          for (int k = 0; k < hs; k++) {
+            if (!(f & (1u << (3 * k + 4))) || (f & (1u << (DF_PI + k)))) continue;
+            const int cx = (f & (1u << (DF_MU + k))) ? 16 : (((f >> (3 * k)) & 0x1EF) ? 15 : 14);
+            if (m.decode(cx)) MAG_OR(4 * s + k, x, 1u << p);
+            f |= 1u << (DF_MU + k);
+            if (!full) lastp[(4 * s + k) * 64 + x] = (uint8_t)p;
+          }
+          if (f != f0) DFW(s, x) = f;
+        }
+      }
+      if (++np >= cb.npasses) break;
+    }
+    // clean-up
+    for (int s = 0; s < nstr; s++) {
+      const int hs = h - 4 * s < 4 ? h - 4 * s : 4;
+      for (int x = 0; x < w; x++) {
+        uint32_t f = DFW(s, x);
+        const uint32_t f0 = f;
+        int k = 0;
+        if (hs == 4 && (f & (DF_SIGALL | (0xFu << DF_PI))) == 0) {   // run mode
+          if (!m.decode(17)) {
+            if (!full) for (int q = 0; q < 4; q++) lastp[(4 * s + q) * 64 + x] = (uint8_t)p;
+            continue;
+          }
+          k = m.decode(18) << 1;
+          k |= m.decode(18);
+          if (!full) for (int q = 0; q <= k; q++) lastp[(4 * s + q) * 64 + x] = (uint8_t)p;
+          const int neg = dec_sign(s, x, k, f);
+          set_sig(s, x, k, neg, f);
+          MAG_OR(4 * s + k, x, (1u << p) | (neg ? 0x80000000u : 0u));
+          k++;
+        }
+        for (; k < hs; k++) {
+          if (f & ((1u << (3 * k + 4)) | (1u << (DF_PI + k)))) continue;
+          if (m.decode(s_zc[(f >> (3 * k)) & 0x1EF])) {
+            const int neg = dec_sign(s, x, k, f);
+            set_sig(s, x, k, neg, f);
+            MAG_OR(4 * s + k, x, (1u << p) | (neg ? 0x80000000u : 0u));
+          }
+          if (!full) lastp[(4 * s + k) * 64 + x] = (uint8_t)p;
+        }
+        f &= ~(0xFu << DF_PI);
+        if (f != f0) DFW(s, x) = f;
+      }
+    }
     np++;
-    for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++) DFL(y, x) &= (uint8_t)~DF_VISIT;
   }
-#undef DEC_SIGN
 }
 #undef MAG_OR
 

@@ -71,3 +71,37 @@ def test_two_ranks_two_sequences_each_batched_halo_records(tmp_path):
             assert r1["low_stream0"].tobytes() == out[(hip.LOW, 3)][2 * 3]
     finally:
         e.close()
+
+
+def test_one_rank_rccl_communicator_and_batched_exchange_in_a_process_that_imported_torch(tmp_path):
+    """What bench.py does at WORLD_SIZE > 1, as far as one GPU allows: torch imported (gloo only), librccl loaded by the library, ONE
+    communicator on the first of two contexts, qsvc_halo_exchange_batch on a line of one rank (no neighbour: nothing moves, every
+    context's halo slots are cleared) -- the load / init / group-call path must work and change nothing."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch                                   # CPU only, as in bench.py
+from qsvc_amd import hip
+from qsvc_amd.synth import make_clip
+W, H, bs = 128, 96, 16
+engs = [hip.Engine(0) for _ in range(2)]
+uid = hip.Engine.comm_unique_id()
+engs[0].comm_init(0, 1, uid)
+want = []
+for k, e in enumerate(engs):
+    clip = make_clip("pan_noise", 5, W, H, 30 + k)
+    e.seq_config(W, H); e.put_frames(hip.LOW, 0, clip)
+    e.analyze_step(1, 5, bs, 4)
+    want.append(e.get_frames(hip.LOW, 1, 0, 3))
+    e.motion_estimate(1, 5, bs, 4); e.decorrelate(1, 5, bs, 4)
+hip.Engine.halo_exchange_batch(engs, 1)
+for k, e in enumerate(engs):
+    e.update(1, 5, bs, 0.25)
+    assert np.array_equal(e.get_frames(hip.LOW, 1, 0, 3), want[k]), k
+for e in engs:
+    e.close()
+print("ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
