@@ -481,14 +481,8 @@ def main():
                     res[t] = motion_chain.mux_components(np.ascontiguousarray(comps4))
                     k += 4 * nf
                 fields = motion_chain.field_chain(res, TRLS)
-                planes = dec.j2k_decode_planes(streams)
-                k = 0
-                for (kind, t, n) in items:
-                    fr = np.empty((n, W * H * 3 // 2), dtype=np.uint8)
-                    for i in range(n):
-                        fr[i] = np.concatenate([planes[k].reshape(-1), planes[k + 1].reshape(-1), planes[k + 2].reshape(-1)])
-                        k += 3
-                    dec.put_frames(kind, t, fr)
+                # texture_expand.py: every subband's pictures from their code-streams, one batch, straight into the resident sequences
+                dec.j2k_decode_multi([(kind, t, out[(kind, t)]) for (kind, t, n) in items])
                 for (t, Pt, St, bst) in comp.levels:
                     dec.put_motion(hip.MOTION_FILTERED, t, fields[t], bst)
                     dec.put_frame_types(t, types[t])

@@ -212,6 +212,15 @@ int qsvc_j2k_dwt(qsvc_ctx* ctx, const uint8_t* plane, int H, int W, int reversib
  * share the transform (5/3 or 9/7).  Scope: one tile, LRCP, no precinct partition, code-block style 0. */
 int qsvc_j2k_decode_planes(qsvc_ctx* ctx, int nstreams, const uint8_t* const* streams, const size_t* lens, int max_layers,
                            void* out, size_t cap, size_t* offs, int* widths, int* heights);
+/* The same straight into a device-resident sequence (the decoder's qsvc_put_frames): pictures [first, first + count) of sequence
+ * (kind, t) holding `total` pictures, from 3 * count code-streams in (picture, component Y U V) order, as
+ * texture_expand_fb_j2k.py:153-181 reads <file>_{Y,U,V}_NNNN.j2c; the planes must have the sequence's geometry (qsvc_seq_config). */
+int qsvc_j2k_decode_frames(qsvc_ctx* ctx, int kind, int t, int first, int count, int total, const uint8_t* const* streams,
+                           const size_t* lens, int max_layers);
+/* Several sequences in ONE decoding batch (what `texture_expand` does for high_{T-1} .. high_1 and low_{T-1}, texture_expand.py:85-131):
+ * sequence k receives counts[k] pictures from firsts[k] on; the streams follow each other in (sequence, picture, component) order. */
+int qsvc_j2k_decode_multi(qsvc_ctx* ctx, int nseq, const int* kinds, const int* ts, const int* firsts, const int* counts, const int* totals,
+                          const uint8_t* const* streams, const size_t* lens, int max_layers);
 /* Host threads that write the code-streams of one qsvc_j2k_encode_* call (Tier-2: packet headers, tag trees, markers; the
  * planes of a call are independent).  n >= 1 sets the count for this context; n = 0 returns to the default, which is the
  * environment variable QSVC_T2_THREADS as it was when the context coded its first plane, else 8.  Never more threads than

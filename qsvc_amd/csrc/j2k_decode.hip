@@ -13,6 +13,8 @@
 #include <exception>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "j2k_kernels.h"
@@ -554,9 +556,10 @@ struct J2kDecState {
   DevBuf cbs_d, segs_d, flags_d, lastp_d, coefA, coefB, planes_d, out_d;
 };
 
-extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* const* streams, const size_t* lens, int max_layers,
-                                      void* out, size_t cap, size_t* offs, int* widths, int* heights) {
-  if (!c || nstreams < 1 || !streams || !lens || !out || !offs) return QSVC_ERR_INVALID;
+// dev_dst != nullptr: the planes go straight to device memory at dev_dst + dev_offs[i] (qsvc_j2k_decode_frames), geometry checked
+// against (fw, fh); else to the host buffer `out`, back to back.
+static int decode_impl(qsvc_ctx* c, int nstreams, const uint8_t* const* streams, const size_t* lens, int max_layers, void* out, size_t cap,
+                       size_t* offs, int* widths, int* heights, uint8_t* dev_dst, const size_t* dev_offs, int fw, int fh) {
   (void)hipSetDevice(c->dev);
   if (!c->j2kdec) c->j2kdec = new J2kDecState();
   J2kDecState& S = *c->j2kdec;
@@ -565,16 +568,39 @@ extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* 
   std::vector<uint8_t> segs;
   size_t total = 0, out_total = 0;
   int maxW = 0, maxH = 0, maxL = 0;
+  // Tier-2 parsing: the streams are independent -- each into its own tables on a few host threads, then merged in stream order
+  struct Parsed { std::vector<DecCb> cbs; std::vector<uint8_t> segs; const char* err = nullptr; bool nomem = false; };
+  std::vector<Parsed> parsed(nstreams);
+  for (int i = 0; i < nstreams; i++) if (!streams[i]) return c->fail(QSVC_ERR_INVALID, "code-stream %d is null", i);
+  {
+    const int nthr = std::max(1, std::min({nstreams, 8, c->t2_threads > 0 ? c->t2_threads : 8}));
+    std::atomic<int> next{0};
+    auto work = [&]() {
+      for (int i; (i = next.fetch_add(1)) < nstreams;) {
+        planes[i].off = 0;
+        try {  // the parser sizes containers from header fields: an allocation failure is an error code, never an exception across the C ABI
+          parsed[i].err = parse_stream(streams[i], lens[i], max_layers, planes[i], parsed[i].cbs, parsed[i].segs);
+        } catch (const std::exception&) { parsed[i].nomem = true; }
+      }
+    };
+    std::vector<std::thread> th;
+    try {
+      for (int k = 1; k < nthr; k++) th.emplace_back(work);
+    } catch (const std::exception&) {}   // (fewer helpers than asked for: the caller's thread does the rest)
+    work();
+    for (auto& t : th) t.join();
+  }
   for (int i = 0; i < nstreams; i++) {
     planes[i].off = total; planes[i].out_off = out_total;
-    if (!streams[i]) return c->fail(QSVC_ERR_INVALID, "code-stream %d is null", i);
-    const char* e = nullptr;
-    try {  // the parser sizes containers from header fields: an allocation failure is an error code, never an exception across the C ABI
-      e = streams[i] ? parse_stream(streams[i], lens[i], max_layers, planes[i], cbs, segs) : "null stream";
+    if (parsed[i].nomem) return c->fail(QSVC_ERR_NOMEM, "code-stream %d: out of host memory while parsing", i);
+    if (parsed[i].err) return c->fail(QSVC_ERR_UNSUPPORTED, "code-stream %d: %s", i, parsed[i].err);
+    try {
+      const unsigned long long sbase = segs.size();
+      for (DecCb d : parsed[i].cbs) { d.seg += sbase; d.plane_off = total; cbs.push_back(d); }
+      segs.insert(segs.end(), parsed[i].segs.begin(), parsed[i].segs.end());
     } catch (const std::exception&) {
       return c->fail(QSVC_ERR_NOMEM, "code-stream %d: out of host memory while parsing", i);
     }
-    if (e) return c->fail(QSVC_ERR_UNSUPPORTED, "code-stream %d: %s", i, e);
     if (planes[i].rev != planes[0].rev) return c->fail(QSVC_ERR_UNSUPPORTED, "the streams of one call must share the transform");
     total += (size_t)planes[i].W * planes[i].H;
     offs[i] = out_total;
@@ -585,14 +611,21 @@ extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* 
     maxW = std::max(maxW, planes[i].W); maxH = std::max(maxH, planes[i].H); maxL = std::max(maxL, planes[i].L);
   }
   offs[nstreams] = out_total;
-  if (out_total > cap) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes needed, %zu given)", out_total, cap);
+  if (dev_dst) {
+    for (int i = 0; i < nstreams; i++) {
+      const int ew = (i % 3) ? fw / 2 : fw, eh = (i % 3) ? fh / 2 : fh;
+      if (planes[i].W != ew || planes[i].H != eh || planes[i].prec != 8)
+        return c->fail(QSVC_ERR_INVALID, "code-stream %d holds a %dx%d plane of %d bits, the sequence expects %dx%d of 8", i, planes[i].W, planes[i].H, planes[i].prec, ew, eh);
+      planes[i].out_off = dev_offs[i];
+    }
+  } else if (out_total > cap) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes needed, %zu given)", out_total, cap);
   const int ncb = (int)cbs.size();
   const bool rev = planes[0].rev != 0;
   int r;
   if ((r = S.coefA.ensure(c, total * 4))) return r;
   if ((r = S.coefB.ensure(c, total * 4))) return r;
   if ((r = S.planes_d.ensure(c, planes.size() * sizeof(DecPlane)))) return r;
-  if ((r = S.out_d.ensure(c, out_total + 16))) return r;
+  if (!dev_dst && (r = S.out_d.ensure(c, out_total + 16))) return r;
   HIPCHK(c, hipMemsetAsync(S.coefA.p, 0, total * 4, c->st));
   HIPCHK(c, hipMemcpyAsync(S.planes_d.p, planes.data(), planes.size() * sizeof(DecPlane), hipMemcpyHostToDevice, c->st));
   Prof pf;
@@ -626,12 +659,25 @@ extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* 
     }
   }
   hipLaunchKernelGGL(k_dec_finish, dim3((maxW + 63) / 64, (maxH + 3) / 4, nstreams), dim3(64, 4), 0, c->st, (const DecPlane*)S.planes_d.p,
-                     S.coefA.p, (uint8_t*)S.out_d.p);
+                     S.coefA.p, dev_dst ? dev_dst : (uint8_t*)S.out_d.p);
   pf.end(c);
-  HIPCHK(c, hipMemcpyAsync(out, S.out_d.p, out_total, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  if (!dev_dst) HIPCHK(c, hipMemcpyAsync(out, S.out_d.p, out_total, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(c, hipStreamSynchronize(c->st));  // (the parsed tables are local: the kernels must be through with them)
   HIPCHK(c, hipGetLastError());
   return QSVC_OK;
+}
+
+// internal (qsvc_api.hip: qsvc_j2k_decode_frames): the 3 * count planes of `count` pictures into a device-resident I420 sequence
+extern "C" int qsvc_j2k_decode_to_device(qsvc_ctx* c, int nstreams, const uint8_t* const* streams, const size_t* lens, int max_layers,
+                                         uint8_t* dev_dst, const size_t* dev_offs, int fw, int fh) {
+  std::vector<size_t> offs((size_t)nstreams + 1);
+  return decode_impl(c, nstreams, streams, lens, max_layers, nullptr, 0, offs.data(), nullptr, nullptr, dev_dst, dev_offs, fw, fh);
+}
+
+extern "C" int qsvc_j2k_decode_planes(qsvc_ctx* c, int nstreams, const uint8_t* const* streams, const size_t* lens, int max_layers,
+                                      void* out, size_t cap, size_t* offs, int* widths, int* heights) {
+  if (!c || nstreams < 1 || !streams || !lens || !out || !offs) return QSVC_ERR_INVALID;
+  return decode_impl(c, nstreams, streams, lens, max_layers, out, cap, offs, widths, heights, nullptr, nullptr, 0, 0);
 }
 
 void j2k_decode_release(qsvc_ctx* c) {

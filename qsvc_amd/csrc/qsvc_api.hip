@@ -184,6 +184,48 @@ int qsvc_get_frames(qsvc_ctx* c, int kind, int t, int first, int count, uint8_t*
   return QSVC_OK;
 }
 
+// The decoder's counterpart of qsvc_put_frames: pictures [firsts[k], firsts[k] + counts[k]) of sequence (kinds[k], ts[k]) of
+// totals[k] pictures straight from their code-streams (3 per picture: Y, U, V, as texture_expand_fb_j2k.py:153-181 reads
+// <file>_{Y,U,V}_NNNN.j2c), all sequences of the call in ONE decoding batch, into the resident sequences without a trip through
+// host memory.  Destination pointers are taken after every buffer has its size (a later ensure() may move an earlier buffer only if
+// it is the same buffer: two entries of one call must not name the same sequence with different totals).
+int qsvc_j2k_decode_multi(qsvc_ctx* c, int nseq, const int* kinds, const int* ts, const int* firsts, const int* counts, const int* totals,
+                          const uint8_t* const* streams, const size_t* lens, int max_layers) {
+  if (!c || !kinds || !ts || !firsts || !counts || !totals || !streams || !lens || nseq < 1) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
+  if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+  (void)hipSetDevice(c->dev);
+  std::vector<DevBuf*> bufs(nseq);
+  int npic = 0;
+  for (int k = 0; k < nseq; k++) {
+    int* n;
+    int r = seq_sel(c, kinds[k], ts[k], &bufs[k], &n);
+    if (r) return r;
+    if (firsts[k] < 0 || counts[k] < 0 || firsts[k] + counts[k] > totals[k]) return c->fail(QSVC_ERR_INVALID, "bad frame range");
+    if ((r = bufs[k]->ensure(c, (size_t)totals[k] * c->F))) return r;
+    *n = totals[k];
+    npic += counts[k];
+  }
+  c->cup_src = nullptr;
+  if (!npic) return QSVC_OK;
+  // one base pointer for the batch: offsets relative to the lowest buffer address
+  uintptr_t base = ~(uintptr_t)0;
+  for (int k = 0; k < nseq; k++) if (counts[k]) base = std::min(base, (uintptr_t)bufs[k]->p);
+  std::vector<size_t> offs((size_t)3 * npic);
+  const size_t N = (size_t)c->W * c->H, Nc = (size_t)(c->W / 2) * (c->H / 2);
+  size_t q = 0;
+  for (int k = 0; k < nseq; k++)
+    for (int i = 0; i < counts[k]; i++, q += 3) {
+      const size_t f = (size_t)((uintptr_t)bufs[k]->p - base) + (size_t)(firsts[k] + i) * c->F;
+      offs[q] = f; offs[q + 1] = f + N; offs[q + 2] = f + N + Nc;
+    }
+  return qsvc_j2k_decode_to_device(c, 3 * npic, streams, lens, max_layers, (uint8_t*)base, offs.data(), c->W, c->H);
+}
+int qsvc_j2k_decode_frames(qsvc_ctx* c, int kind, int t, int first, int count, int total, const uint8_t* const* streams, const size_t* lens,
+                           int max_layers) {
+  return qsvc_j2k_decode_multi(c, 1, &kind, &t, &first, &count, &total, streams, lens, max_layers);
+}
+
 int qsvc_put_motion(qsvc_ctx* c, int kind, int t, int nB, int bs, const int16_t* mv) {
   if (!c || !mv || t < 1 || t > QSVC_MAX_T || bs <= 0 || nB < 0) return QSVC_ERR_INVALID;
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }

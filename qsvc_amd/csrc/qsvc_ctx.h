@@ -137,5 +137,7 @@ extern "C" int qsvc_resolve(qsvc_ctx* c);  // internal (not in include/qsvc_hip.
 extern "C" int qsvc_motion_planes(qsvc_ctx* c, int nlevels, const int* ts, const int* fields, int block_size, const int16_t* filtered_host,
                                   int16_t* residues, std::vector<int16_t>& planes, int* BY, int* BX);
 extern "C" void qsvc_motion_prm(qsvc_j2k_params* prm);
+extern "C" int qsvc_j2k_decode_to_device(qsvc_ctx* c, int nstreams, const uint8_t* const* streams, const size_t* lens, int max_layers,
+                                         uint8_t* dev_dst, const size_t* dev_offs, int fw, int fh);   // j2k_decode.hip
 void j2k_release(qsvc_ctx* c);
 void j2k_decode_release(qsvc_ctx* c);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "qsvc_analyze_step", "qsvc_un_update", "qsvc_correlate", "qsvc_synthesize_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_halo_batch_bytes", "qsvc_halo_batch_export_host", "qsvc_halo_batch_import_host",
     "qsvc_halo_exchange_batch", "qsvc_dwt53_trunc",
-    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_motion_encode", "qsvc_compress_code", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_stats", "qsvc_set_tier2_threads", "qsvc_set_profiling", "qsvc_get_timings",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_motion_encode", "qsvc_compress_code", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_decode_frames", "qsvc_j2k_decode_multi", "qsvc_j2k_stats", "qsvc_set_tier2_threads", "qsvc_set_profiling", "qsvc_get_timings",
 ]
 
 
@@ -94,6 +94,9 @@ def load_library() -> C.CDLL:
     L.qsvc_j2k_dwt.argtypes = [vp, u8p, i, i, i, i, vp]
     L.qsvc_j2k_decode_planes.argtypes = [vp, i, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i, vp, C.c_size_t, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.qsvc_j2k_decode_frames.argtypes = [vp, i, i, i, i, i, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i]
+    L.qsvc_j2k_decode_multi.argtypes = [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i]
     L.qsvc_j2k_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qsvc_set_tier2_threads.argtypes = [vp, i]
     L.qsvc_set_profiling.argtypes = [vp, i]
@@ -426,6 +429,29 @@ class Engine:
             a = out[offs[k]:offs[k] + w * h * (2 if p16 else 1)]
             res.append(a.view(np.int16).reshape(h, w).copy() if p16 else a.reshape(h, w).copy())
         return res
+
+    def j2k_decode_frames(self, kind, t, streams, first=0, total=None, max_layers=0):
+        """3 code-streams per picture (Y, U, V) -> pictures [first, first + n) of the device-resident sequence (kind, t) of `total`."""
+        streams = [bytes(s) for s in streams]
+        n = len(streams) // 3
+        assert len(streams) == 3 * n and n >= 1
+        ptrs = (C.c_char_p * len(streams))(*streams)
+        lens = (C.c_size_t * len(streams))(*[len(s) for s in streams])
+        self._chk(self.L.qsvc_j2k_decode_frames(self.h, kind, t, first, n, n + first if total is None else total, ptrs, lens, int(max_layers)))
+
+    def j2k_decode_multi(self, items, max_layers=0):
+        """items: [(kind, t, [streams: 3 per picture])] -> every sequence resident (its picture count = len(streams) // 3), one batch."""
+        items = [(k, t, [bytes(s) for s in ss]) for (k, t, ss) in items if len(ss)]
+        n = len(items)
+        if not n:
+            return
+        IA = C.c_int * n
+        cnt = [len(ss) // 3 for (_, _, ss) in items]
+        allcs = [s for (_, _, ss) in items for s in ss]
+        ptrs = (C.c_char_p * len(allcs))(*allcs)
+        lens = (C.c_size_t * len(allcs))(*[len(s) for s in allcs])
+        self._chk(self.L.qsvc_j2k_decode_multi(self.h, n, IA(*[k for k, _, _ in items]), IA(*[t for _, t, _ in items]), IA(*([0] * n)), IA(*cnt), IA(*cnt),
+                                               ptrs, lens, int(max_layers)))
 
     def j2k_stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

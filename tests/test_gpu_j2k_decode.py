@@ -119,3 +119,32 @@ def test_corrupt_main_headers_are_refused(eng):
         with pytest.raises(hip.QsvcError):
             eng.j2k_decode_planes([bad])
     np.testing.assert_array_equal(eng.j2k_decode_planes([cs])[0], y)
+
+
+def test_decode_into_resident_sequences_equals_host_planes():
+    """qsvc_j2k_decode_multi: the subbands' pictures straight from their code-streams into device-resident sequences, one batch for
+    several sequences -- the same pictures qsvc_j2k_decode_planes returns to the host."""
+    from qsvc_amd import hip
+    from qsvc_amd.pipeline import CompressParams, Compressor
+    from qsvc_amd.synth import make_clip
+    W, H = 192, 128
+    e = hip.Engine(0)
+    d = hip.Engine(0)
+    try:
+        comp = Compressor(e, CompressParams(pixels_in_x=W, pixels_in_y=H, TRLs=3, GOPs=1, block_size=16, block_size_min=16, SRLs=4, lossless=True))
+        comp.configure(); comp.load(make_clip("edge", comp.pictures, W, H, 5))
+        out = comp.compress()
+        d.seq_config(W, H)
+        d.j2k_decode_multi([(kind, t, ss) for (kind, t), ss in out.items()])
+        for (kind, t), ss in out.items():
+            n = len(ss) // 3
+            got = d.get_frames(kind, t, 0, n)
+            np.testing.assert_array_equal(got, e.get_frames(kind, t, 0, n), err_msg=f"{kind} {t}")     # lossless: the encoder's pictures
+            planes = d.j2k_decode_planes(ss)
+            for i in range(n):
+                np.testing.assert_array_equal(got[i], np.concatenate([p.reshape(-1) for p in planes[3 * i:3 * i + 3]]))
+        with pytest.raises(hip.QsvcError):   # a stream of another geometry is refused, nothing is written out of place
+            d.seq_config(96, 64)
+            d.j2k_decode_frames(hip.LOW, 2, out[(hip.LOW, 2)][:3])
+    finally:
+        e.close(); d.close()
