@@ -364,14 +364,13 @@ def main():
             dist.barrier()
 
     # the MQ coder kernel in work: the library's default is the two-wave pipeline (64 code-blocks per wave pair); QSVC_MQ_PIPE=0
-    # selects the one-wave form (QSVC_MQ_LANES blocks per wave)
-    # With several sequences in flight the pipeline runs in its small-LDS form (two ring slots, a third of the staging area: its
-    # workgroups leave room on a CU for the other sequences' kernels; QSVC_MQ_LDS is read at every launch); the single-sequence
-    # figure below uses the library's default.  A caller's own QSVC_MQ_LDS wins.
+    # selects the one-wave form (QSVC_MQ_LANES blocks per wave).  With several sequences in flight the pipeline runs in its small-LDS
+    # form (two ring slots, a third of the staging area: its workgroups leave room on a CU for the other sequences' kernels) -- a
+    # per-context switch (qsvc_set_tuning); the single-sequence figure below uses the library's default.  A caller's own QSVC_MQ_LDS wins.
     user_lds = os.environ.get("QSVC_MQ_LDS")
-    if user_lds is None and S > 1:
-        os.environ["QSVC_MQ_LDS"] = "small"
-    small = os.environ.get("QSVC_MQ_LDS") == "small"
+    small = (user_lds == "small") if user_lds is not None else S > 1
+    for e in engs:
+        e.set_tuning("mq_lds_small", int(small))
     mq_symbol = (("k_t1_mq_pipe<64, 2, 116, 48>" if small else "k_t1_mq_pipe<64, 4, 196, 144>") if os.environ.get("QSVC_MQ_PIPE", "1") != "0"
                  else "k_t1_mq<%s>" % os.environ.get("QSVC_MQ_LANES", "64"))
     shard_check = None
@@ -431,7 +430,7 @@ def main():
     serial_ms, iso = None, {}
     if world == 1 and not args.no_iso:  # ONE sequence alone on the chip: its latency, and every kernel group's ISOLATED duration (HIP events)
         if user_lds is None:
-            os.environ.pop("QSVC_MQ_LDS", None)
+            engs[0].set_tuning("mq_lds_small", 0)
         t2_single = t2_timed
         if user_t2 is None:  # one sequence alone: its Tier-2 may use the cores the other sessions' would
             t2_single = max(1, min(16, ncpu // max(1, local_world)))  # (16: 7.0 ms; 8: 7.6; 32: noisy)

@@ -433,6 +433,7 @@ struct PlaneSrc { const uint8_t* src; int stride, W, H; const qsvc_j2k_params* p
 // Encode a batch of device-resident planes.  All planes share the transform/quantiser/code-block parameters
 // of src[0].prm; the number of layers and the slopes may differ per plane (they only steer the host's PCRD).
 static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8_t* out, size_t cap, size_t* offs) {
+  TuningScope tscope(&c->tune);
   if (!c->j2k) c->j2k = new J2kState();
   J2kState& S = *c->j2k;
   // A batch is a run of picture planes (8-bit, one transform, step, level count and code-block size) optionally FOLLOWED by a run of
@@ -598,9 +599,8 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   // Tier-1 kernels and flags it, and the stage is run again with the host's list and larger buffers.
   const int MQW = 64;
   const int nslots = ((ncb + MQW - 1) / MQW) * MQW;
-  const bool mq_sort = [] { const char* e = getenv("QSVC_MQ_SORT"); return !e || atoi(e) != 0; }();
-  static const bool devlist_env = [] { const char* e = getenv("QSVC_T1_DEVLIST"); return !(e && e[0] == '0'); }();
-  bool devlist = devlist_env && mq_sort && S.jobs_cap > 0 && (!want_dist || S.jobs_cap_dist);
+  const bool mq_sort = c->tune.mq_sort != 0;
+  bool devlist = c->tune.t1_devlist && mq_sort && S.jobs_cap > 0 && (!want_dist || S.jobs_cap_dist);
   if (!S.res.resize(ncb) || !S.h_err.resize(2) || (want_dist && (!S.plen.resize((size_t)ncb * T1_MAXPASS) || !S.pdist.resize((size_t)ncb * T1_MAXPASS))))
     return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
   int& err = S.h_err[1];
@@ -671,7 +671,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     // (profiles/r03_*): no gain -- the modelling workgroups (11 KB of LDS each, 14 per CU) leave no room for an MQ
     // workgroup (25-40 KB) on any CU until they drain, so the side streams' kernels start when the modelling ends anyway
     // (single sequence 6.35 -> 6.77 ms with 4 parts, 12 sequences in flight 5200 -> 4280 fps).
-    int nparts = [] { const char* e = getenv("QSVC_T1_PARTS"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    int nparts = c->tune.t1_parts;
     if (!mq_sort || nslots < 64 * 16) nparts = 1;
     int cut[5] = {0, 0, 0, 0, 0};
     {

@@ -600,8 +600,7 @@ void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, in
       else { if (l == 0) DWT_LAUNCH(false, true, true); else DWT_LAUNCH(false, false, true); }
     } else {
       // the packed 5/3 kernel: levels of at least 4 x 4 samples, code-blocks at least 8 wide (QSVC_DWT_PK=0: the general kernel)
-      static const bool pk_env = [] { const char* e = getenv("QSVC_DWT_PK"); return !(e && e[0] == '0'); }();
-      const bool pk = reversible && pk_env && minW >= 4 && minH >= 4 && cbw_log2 >= 3 && cbh_log2 >= 2;
+      const bool pk = reversible && tuning().dwt_pk && minW >= 4 && minH >= 4 && cbw_log2 >= 3 && cbh_log2 >= 2;
       if (pk) { if (l == 0) hipLaunchKernelGGL(k_dwt53_pk<true>, grid, block, 0, st, a); else hipLaunchKernelGGL(k_dwt53_pk<false>, grid, block, 0, st, a); }
       else if (reversible) { if (l == 0) DWT_LAUNCH(true, true, false); else DWT_LAUNCH(true, false, false); }
       else { if (l == 0) DWT_LAUNCH(false, true, false); else DWT_LAUNCH(false, false, false); }

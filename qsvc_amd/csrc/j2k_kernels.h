@@ -1,5 +1,6 @@
 // qsvc_amd/csrc/j2k_kernels.h -- device-side structures and launch wrappers of j2k_kernels.hip
 #pragma once
+#include "tuning.h"
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>

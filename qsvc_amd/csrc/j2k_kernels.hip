@@ -409,8 +409,7 @@ void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, c
   // QSVC_MQ_LDS=small: the pipeline with a two-slot ring and a third of the staging area (25 instead of 40 KB of LDS per wave
   // pair): + 5 % throughput when many sequences share the GPU (its workgroups leave room for the other kernels' on a CU),
   // + 4 % latency for one sequence alone.
-  const bool pipe = [] { const char* e = getenv("QSVC_MQ_PIPE"); return e ? atoi(e) != 0 : true; }();
-  const bool small = [] { const char* e = getenv("QSVC_MQ_LDS"); return e && !strcmp(e, "small"); }();
+  const bool pipe = tuning().mq_pipe != 0, small = tuning().mq_lds_small != 0;
   if (pipe) {
     if (small)
       hipLaunchKernelGGL((k_t1_mq_pipe<64, 2, T1_STAGE_SMALL, T1_STAGE_SMALL_FLUSH>), dim3((nslots + 63) / 64), dim3(128), 0, st, cbs, ncb, nbps, joboff, order, nslots,
@@ -423,7 +422,7 @@ void launch_t1_mq(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, c
   // lanes (code-blocks) per MQ wave: the coder is straight-line (no divergent path in a decision), so a wave costs the same
   // whatever the number of lanes in work; 64 is best for one sequence (245 waves, one per CU) and for many.  QSVC_MQ_LANES
   // (4, 8, 16, 32; read at every launch) is kept for experiments.
-  const int ml = [] { const char* e = getenv("QSVC_MQ_LANES"); int v = e ? atoi(e) : 64; return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 64; }();
+  const int ml = tuning().mq_lanes;
   long long* pdp = want_dist ? pass_dist : nullptr;
 #define MQ_LAUNCH(N) hipLaunchKernelGGL(k_t1_mq<N>, dim3((nslots + N - 1) / N), dim3(N), 0, st, cbs, ncb, nbps, joboff, order, nslots, segs, cnt, dist, outbuf, outcap, res, pass_len, pdp)
   switch (ml) { case 4: MQ_LAUNCH(4); break; case 8: MQ_LAUNCH(8); break; case 16: MQ_LAUNCH(16); break; case 32: MQ_LAUNCH(32); break; default: MQ_LAUNCH(64); }

@@ -46,7 +46,7 @@ static void launch_pyr_margin(hipStream_t st, const T* src, size_t src_pic_strid
 }
 void launch_pyr_level_u8(hipStream_t st, const uint8_t* frames, size_t F, int W, int H, int16_t* dst, int P, int R, int C) {
   dim3 block(64, 4);
-  if (pyr_tile_applies(W, H) && getenv("QSVC_PYR_TILE") == nullptr) {
+  if (pyr_tile_applies(W, H) && tuning().pyr_tile) {
     // the LL quadrant out of LDS tiles (mctf_pyr.hip); what a block window reads beyond it, coefficient by coefficient
     const int Rl = imin(R, H / 2), Cl = imin(C, W / 2);
     launch_pyr_ll_tile(st, frames, F, W, H, dst, P, Rl, Cl);
@@ -59,7 +59,7 @@ void launch_pyr_level_u8(hipStream_t st, const uint8_t* frames, size_t F, int W,
 void launch_pyr_level_s16(hipStream_t st, const int16_t* src, int16_t* dst, int W, int H, int P, int l, int R, int C) {
   dim3 block(64, 4);
   const int ny = H >> (l - 1), nx = W >> (l - 1);
-  if (pyr_tile16_applies(W, ny, nx) && getenv("QSVC_PYR_TILE") == nullptr) {
+  if (pyr_tile16_applies(W, ny, nx) && tuning().pyr_tile) {
     // the LL quadrant out of LDS tiles (mctf_pyr.hip); what a block window reads beyond it (bands of this and of earlier levels), per coefficient
     const int Rl = imin(R, ny / 2), Cl = imin(C, nx / 2);
     launch_pyr_ll_tile16(st, src, dst, W, H, P, ny, nx, Rl, Cl);
@@ -79,9 +79,9 @@ __global__ void __launch_bounds__(64) k_me_search8(MeArgs a) { me_search8_body<T
 void launch_me_search(hipStream_t st, const MeArgs& a0, int mv_bound) {
   MeArgs a = a0;
   a.ring = 0;
-  if (!(me_piece_applies(a) && getenv("QSVC_ME_PIECE") == nullptr)) a.zero_words = nullptr;  // only the piece launch zeroes
+  if (!(me_piece_applies(a) && tuning().me_piece)) a.zero_words = nullptr;  // only the piece launch zeroes
   a.rby_lo = a.rby_hi = a.rbx_lo = a.rbx_hi = 0;
-  if (me_piece_applies(a) && getenv("QSVC_ME_PIECE") == nullptr) {
+  if (me_piece_applies(a) && tuning().me_piece) {
     // one launch: inner blocks (one lane per 8x8 samples, no border rule) and, as a second role of the same grid, the ring of the
     // block grid where a displaced window can leave the picture (border-rule bodies)
     const int bs = a.g.bs, b1 = mv_bound + 1;
@@ -502,7 +502,7 @@ bool launch_predict_overlap(hipStream_t st, const PredArgs& a, int16_t* ppl0, in
   return true;
 }
 
-bool pred_fast_path(const PredArgs& a) { return pred_run_applies(a) && getenv("QSVC_PRED_RUN") == nullptr; }
+bool pred_fast_path(const PredArgs& a) { return pred_run_applies(a) && tuning().pred_run; }
 void launch_predict(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
   dim3 block(64, 4);
@@ -859,7 +859,7 @@ __global__ void __launch_bounds__(256) k_upd_chroma_tile(UpdArgs a) {
     a.low[(size_t)(a.dst_mul * j) * g.F + coff + (size_t)cj * cw + ci] = (uint8_t)(int16_t)a53_low(col, cj, g.H);
   }
 }
-bool upd_fast_path(const UpdArgs& a) { return upd_run_applies(a) && getenv("QSVC_UPD_RUN") == nullptr; }
+bool upd_fast_path(const UpdArgs& a) { return upd_run_applies(a) && tuning().upd_run; }
 void launch_update(hipStream_t st, const UpdArgs& a) {
   const LevelGeom& g = a.g;
   dim3 block(64, 4);

@@ -14,6 +14,16 @@
 
 using namespace qsvc;
 
+namespace qsvc {
+static thread_local const Tuning* t_tuning = nullptr;
+const Tuning& tuning() {
+  static const Tuning defaults = Tuning::from_env();
+  return t_tuning ? *t_tuning : defaults;
+}
+TuningScope::TuningScope(const Tuning* t) : prev(t_tuning) { t_tuning = t; }
+TuningScope::~TuningScope() { t_tuning = prev; }
+}  // namespace qsvc
+
 // ------------------------------------------------------------------------------------------------
 int qsvc_ctx::fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -98,6 +108,7 @@ int qsvc_init(int device, qsvc_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return QSVC_ERR_HIP;
   qsvc_ctx* c = new qsvc_ctx();
   c->dev = device;
+  c->tune = Tuning::from_env();
   if (hipStreamCreate(&c->st) != hipSuccess) { delete c; return QSVC_ERR_HIP; }
   c->lv.resize(QSVC_MAX_T + 1);
   *out = c;
@@ -306,6 +317,13 @@ static int level_geom(qsvc_ctx* c, int t, int P, int bs, int S, LevelGeom* g) {
   return QSVC_OK;
 }
 
+int qsvc_set_tuning(qsvc_ctx* c, const char* name, int value) {
+  if (!c || !name) return QSVC_ERR_INVALID;
+  { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }   // (a pending replay runs with the switches its calls were made with)
+  if (!c->tune.set(name, value)) return c->fail(QSVC_ERR_INVALID, "unknown tuning switch '%s' or value %d out of range", name, value);
+  return QSVC_OK;
+}
+
 int qsvc_set_mctf_options(qsvc_ctx* c, int block_overlaping, int border_size, int subpixel_accuracy) {
   if (!c) return QSVC_ERR_INVALID;
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
@@ -407,6 +425,7 @@ static int me_replay(qsvc_ctx* c, const LevelGeom& g, Level& lv, const uint8_t* 
 
 static int motion_estimate_impl(qsvc_ctx* c, int t, int P, int bs, int S) {
   (void)hipSetDevice(c->dev);
+  TuningScope tscope(&c->tune);
   LevelGeom g;
   int r = level_geom(c, t, P, bs, S, &g);
   if (r) return r;
@@ -471,7 +490,7 @@ static int motion_estimate_impl(qsvc_ctx* c, int t, int P, int bs, int S) {
     pf.end(c);
     prev = a.mv_out;
     bound = imin(2 * (bound + 1), S);
-    if (l == 0) lv.hist_zeroed = a.zero_words != nullptr && getenv("QSVC_ME_PIECE") == nullptr;
+    if (l == 0) lv.hist_zeroed = a.zero_words != nullptr && c->tune.me_piece;
   }
   HIPCHK(c, hipGetLastError());
   return g.sub ? me_subpel(c, g, lv, frames, L, nullptr) : QSVC_OK;
@@ -648,6 +667,7 @@ int qsvc_resolve(qsvc_ctx* c) {
 
 static int decorrelate_impl(qsvc_ctx* c, int t, int P, int bs, int S, int always_B) {
   (void)hipSetDevice(c->dev);
+  TuningScope tscope(&c->tune);
   LevelGeom g;
   int r = level_geom(c, t, P, bs, S, &g);
   if (r) return r;
@@ -686,8 +706,7 @@ static int decorrelate_impl(qsvc_ctx* c, int t, int P, int bs, int S, int always
   } else launch_predict(c->st, a);
   pf.end(c);
   if (!fast) HIPCHK(c, hipMemcpyAsync(lv.mv_filt.p, lv.mv_raw.p, mvbytes, hipMemcpyDeviceToDevice, c->st));
-  static const bool defer_env = [] { const char* e = getenv("QSVC_DEFER_IB"); return !(e && e[0] == '0'); }();
-  const bool defer = !always_B && c->defer_ok && defer_env && !c->resolving;
+  const bool defer = !always_B && c->defer_ok && c->tune.defer_ib && !c->resolving;
   if (defer) {
     // deferred decision: the histograms travel to the host behind the kernels, the level goes on as if every picture were 'B'
     // (what it almost always is); qsvc_resolve applies decorrelate.cpp:964-1000 at the next point that needs the outcome
@@ -736,6 +755,7 @@ static int decorrelate_impl(qsvc_ctx* c, int t, int P, int bs, int S, int always
 
 static int update_impl(qsvc_ctx* c, int t, int P, int bs, float uf) {
   (void)hipSetDevice(c->dev);
+  TuningScope tscope(&c->tune);
   LevelGeom g;
   int r = level_geom(c, t, P, bs, 0, &g);
   if (r) return r;
@@ -854,6 +874,7 @@ int qsvc_un_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   if (!c) return QSVC_ERR_INVALID;
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   (void)hipSetDevice(c->dev);
+  TuningScope tscope(&c->tune);
   LevelGeom g;
   int r = synth_geom(c, t, P, bs, 0, &g, true);
   if (r) return r;
@@ -891,6 +912,7 @@ int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   if (!c) return QSVC_ERR_INVALID;
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
   (void)hipSetDevice(c->dev);
+  TuningScope tscope(&c->tune);
   LevelGeom g;
   int r = synth_geom(c, t, P, bs, S, &g, false);
   if (r) return r;

@@ -11,6 +11,7 @@
 
 #include "../../include/qsvc_hip.h"
 #include "mctf_kernels.h"
+#include "tuning.h"
 
 #define QSVC_MAX_T 15
 
@@ -91,6 +92,7 @@ struct qsvc_ctx {
   int W = 0, H = 0;
   size_t F = 0;
   int keep_pred = 0;
+  qsvc::Tuning tune;         // this context's A/B switches (tuning.h): the QSVC_* environment as it was at qsvc_init, then qsvc_set_tuning
   int opt_ov = 0, opt_bord = 0, opt_sub = 0;  // --block_overlaping, --border_size, --subpixel_accuracy (qsvc_set_mctf_options)
   std::vector<Level> lv;
   std::vector<DevBuf> snap;  // ME pyramid snapshots per DWT level

@@ -23,7 +23,7 @@ SYMBOLS = [
     "qsvc_analyze_step", "qsvc_un_update", "qsvc_correlate", "qsvc_synthesize_step", "qsvc_halo_bytes", "qsvc_halo_export_host", "qsvc_halo_import_host", "qsvc_comm_unique_id",
     "qsvc_comm_init", "qsvc_comm_destroy", "qsvc_halo_exchange", "qsvc_halo_batch_bytes", "qsvc_halo_batch_export_host", "qsvc_halo_batch_import_host",
     "qsvc_halo_exchange_batch", "qsvc_dwt53_trunc",
-    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_motion_encode", "qsvc_compress_code", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_decode_frames", "qsvc_j2k_decode_multi", "qsvc_j2k_stats", "qsvc_set_tier2_threads", "qsvc_set_profiling", "qsvc_get_timings",
+    "qsvc_j2k_encode_frames", "qsvc_j2k_encode_multi", "qsvc_j2k_encode_plane", "qsvc_j2k_encode_planes_s16", "qsvc_motion_encode", "qsvc_compress_code", "qsvc_j2k_dwt", "qsvc_j2k_decode_planes", "qsvc_j2k_decode_frames", "qsvc_j2k_decode_multi", "qsvc_j2k_stats", "qsvc_set_tier2_threads", "qsvc_set_tuning", "qsvc_set_profiling", "qsvc_get_timings",
 ]
 
 
@@ -99,6 +99,7 @@ def load_library() -> C.CDLL:
                                         C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), i]
     L.qsvc_j2k_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.qsvc_set_tier2_threads.argtypes = [vp, i]
+    L.qsvc_set_tuning.argtypes = [vp, C.c_char_p, i]
     L.qsvc_set_profiling.argtypes = [vp, i]
     L.qsvc_get_timings.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), i]
     _lib = L
@@ -461,6 +462,10 @@ class Engine:
     def set_tier2_threads(self, n: int):
         """Host threads writing the code-streams of one encode call (0 = default: QSVC_T2_THREADS at the first encode, else 8)."""
         self._chk(self.L.qsvc_set_tier2_threads(self.h, int(n)))
+
+    def set_tuning(self, name: str, value: int):
+        """An A/B switch of the kernel forms for this context (include/qsvc_hip.h: qsvc_set_tuning); results never depend on it."""
+        self._chk(self.L.qsvc_set_tuning(self.h, name.encode(), int(value)))
 
     # ---- profiling
     def set_profiling(self, on=True):

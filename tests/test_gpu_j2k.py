@@ -153,13 +153,12 @@ def test_trailing_blocks_without_bit_planes(eng):
     for (H, W, levels) in ((128, 128, 1), (192, 256, 2), (64, 320, 0)):
         y = np.full((H, W), 128, dtype=np.uint8)
         y[:40, :40] = _luma("noise", 40, 40, 9)  # texture in the top-left corner only: the high bands' last blocks stay empty
-        for pipe in ("1", "0"):
-            import os
-            os.environ["QSVC_MQ_PIPE"] = pipe
+        for pipe in (1, 0):
+            eng.set_tuning("mq_pipe", pipe)
             try:
                 cs = eng.j2k_encode_plane(y, hip.j2k_params(reversible=True, levels=levels))
             finally:
-                os.environ.pop("QSVC_MQ_PIPE", None)
+                eng.set_tuning("mq_pipe", 1)
             assert cs == J.encode_plane(y, reversible=True, levels=levels)
             np.testing.assert_array_equal(J.decode(cs), y)
 
@@ -210,25 +209,26 @@ def test_random_planes_equal_restatement(eng):
 
 
 def test_both_mq_kernel_forms_give_the_same_streams(eng):
-    """The MQ coder runs as a two-wave pipeline (k_t1_mq_pipe, the default) or as one wave per 64 blocks (QSVC_MQ_PIPE=0, any
-    QSVC_MQ_LANES); the switches are read at every launch.  Same bytes, and equal to the restatement's."""
-    import os
+    """The MQ coder runs as a two-wave pipeline (k_t1_mq_pipe, the default, in two LDS sizes) or as one wave per 4 .. 64 blocks, with the
+    blocks sorted by expected length or not: per-context switches (qsvc_set_tuning; a context starts from the QSVC_* environment as it
+    was when it was created).  Same bytes, and equal to the restatement's.  So with the other kernel forms kept for comparison."""
     from qsvc_amd import hip
     y = _luma("pan_noise", 352, 288, 12)
     prm = hip.j2k_params(reversible=True, levels=4)
     want = J.encode_plane(y, reversible=True, levels=4)
-    saved = {k: os.environ.get(k) for k in ("QSVC_MQ_PIPE", "QSVC_MQ_LANES", "QSVC_MQ_SORT", "QSVC_MQ_LDS")}
+    defaults = {"mq_pipe": 1, "mq_lds_small": 0, "mq_lanes": 64, "mq_sort": 1, "dwt_pk": 1, "t1_devlist": 1}
     try:
-        for env in ({}, {"QSVC_MQ_LDS": "small"}, {"QSVC_MQ_PIPE": "0"}, {"QSVC_MQ_PIPE": "0", "QSVC_MQ_LANES": "16"}, {"QSVC_MQ_SORT": "0"}):
-            for k in saved:
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            assert eng.j2k_encode_plane(y, prm) == want, env
+        for sw in ({}, {"mq_lds_small": 1}, {"mq_pipe": 0}, {"mq_pipe": 0, "mq_lanes": 16}, {"mq_sort": 0}, {"dwt_pk": 0}, {"t1_devlist": 0}):
+            for k, v in dict(defaults, **sw).items():
+                eng.set_tuning(k, v)
+            assert eng.j2k_encode_plane(y, prm) == want, sw
+        with pytest.raises(hip.QsvcError):
+            eng.set_tuning("no_such_switch", 1)
+        with pytest.raises(hip.QsvcError):
+            eng.set_tuning("mq_lanes", 5)
     finally:
-        for k, v in saved.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
+        for k, v in defaults.items():
+            eng.set_tuning(k, v)
 
 
 def test_too_many_bitplanes_is_an_error_not_a_fault(eng):
