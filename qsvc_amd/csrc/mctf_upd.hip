@@ -208,9 +208,86 @@ __device__ __forceinline__ void upd_border_body(const UpdArgs& a, const int k, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// SCATTER form (round 4).  The ordered gather above tests every block within reach of a run of 8 targets -- (2 R / bs + 2)^2
+// candidates per side, nearly all of them misses -- and that test, not the memory system, was what the update step cost (65 %
+// VALU issue at 10 % of the HBM peak).  Here a workgroup owns a TILE of targets and walks the sources instead: every (block,
+// run of 8 columns, quad of rows) within reach of the tile is one task; its four aligned 8-byte rows of residue are OR-ed into a
+// byte image of the tile in LDS at the displaced position (three aligned words per row, no return value needed) and a second
+// image counts the non-zero contributions per target.  A target with at most one non-zero source per side is order-free
+// (clamp(v + 0) = v), so the tile's runs are then applied exactly as before: one packed update per side from the image; a run
+// whose counter image shows two sources on one target -- motion discontinuities -- replays that side block by block in the
+// reference's order (upd_side<true>).  The counters are bytes: the form is used while fewer than 256 blocks lie within reach of
+// a target (upd_scatter_applies); beyond that the gather above runs.
+#define US_W 128                      // luma tile: targets per row ...
+#define US_H 32                       // ... and rows
+#define US_STR (US_W + 16)            // bytes per image row: 8 guard bytes on either side
+#define UC_STR (PCT_FW + 16)          // the chroma tile's footprint likewise
+#define US_SMEM (4 * US_H * US_STR)   // luma: image + counters of both sides
+#define UC_SMEM (PCT_SP_BYTES + 2 * PCT_FH * UC_STR)   // chroma: the footprint + one side's image and counters (the row pass' low band reuses them)
+#define UPD_SC_SMEM (US_SMEM > UC_SMEM ? US_SMEM : UC_SMEM)
+template <int STR>
+__device__ __forceinline__ void upd_scatter(const UpdSrc& s, int y0, int nrows, int x0, int ncols, int R, uint8_t* acc, uint8_t* cnt, int tid) {
+  const int lbs = s.lbs;
+  const int by_lo = imax((y0 - R) >> lbs, 0), by_hi = imin((y0 + nrows - 1 + R) >> lbs, s.nby - 1);
+  const int bx_lo = imax((x0 - R) >> lbs, 0), bx_hi = imin((x0 + ncols - 1 + R) >> lbs, s.nbx - 1);
+  if (by_hi < by_lo || bx_hi < bx_lo) return;
+  const int ncx = (bx_hi - bx_lo + 1) << (lbs - 3);          // runs of 8 source columns in a block row's candidates
+  const int ntask = ncx * ((by_hi - by_lo + 1) << (lbs - 2));  // x quads of source rows
+  const float inv = 1.0f / (float)ncx;
+  for (int t = tid; t < ntask; t += 256) {
+    const int qi = (int)(((float)t + 0.5f) * inv), cxi = t - qi * ncx;
+    const int sy0 = (by_lo << lbs) + 4 * qi, sx0 = (bx_lo << lbs) + 8 * cxi;
+    const int o = (sy0 >> lbs) * s.BX + (sx0 >> lbs);
+    const int dy = s.mvy[o], dx = s.mvx[o];
+    const int pos = sx0 + dx - x0 + 8, row0 = sy0 + dy - y0;   // where the run's first sample lands in the image
+    if (pos <= 0 || pos >= ncols + 8 || sx0 >= s.Ws || row0 <= -4 || row0 >= nrows || sy0 >= s.Hs) continue;
+    const int nv = s.Ws - sx0;
+    const uint64_t smask = nv >= 8 ? ~0ull : (~0ull >> (64 - 8 * nv));
+    uint64_t raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) raw[k] = ld8(s.high + (size_t)imin(sy0 + k, s.Hs - 1) * s.stride + sx0);
+    const int sh = (pos & 3) * 8, wofs = pos & ~3;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int row = row0 + k;
+      if ((unsigned)row >= (unsigned)nrows || sy0 + k >= s.Hs) continue;
+      const uint64_t r = (raw[k] ^ 0x8080808080808080ull) & smask;
+      if (!r) continue;
+      const uint32_t rl = (uint32_t)r, rh = (uint32_t)(r >> 32);
+      const uint32_t tl = ((((rl & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | rl) & 0x80808080u) >> 7;   // 1 per non-zero byte
+      const uint32_t th = ((((rh & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | rh) & 0x80808080u) >> 7;
+      const uint64_t c = (uint64_t)tl | (uint64_t)th << 32;
+      const uint64_t r01 = r << sh, c01 = c << sh;
+      const uint32_t r2 = (uint32_t)((r >> 32) >> (32 - sh)), c2 = (uint32_t)((c >> 32) >> (32 - sh));
+      uint32_t* ap = (uint32_t*)(acc + row * STR + wofs);
+      uint32_t* cp = (uint32_t*)(cnt + row * STR + wofs);
+      __hip_atomic_fetch_or(ap, (uint32_t)r01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_or(ap + 1, (uint32_t)(r01 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(cp, (uint32_t)c01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(cp + 1, (uint32_t)(c01 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (sh) {
+        __hip_atomic_fetch_or(ap + 2, r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(cp + 2, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+}
+// one side's update of the run at (row, 8 run) of the tile from the images
+template <int STR>
+__device__ __forceinline__ uint64_t upd_from_image(const UpdSrc& s, const uint8_t* acc, const uint8_t* cnt, int row, int run, int ty, int tx0, int R,
+                                                   float uf, uint64_t v) {
+  const uint64_t a = *(const uint64_t*)(acc + row * STR + 8 + 8 * run), c = *(const uint64_t*)(cnt + row * STR + 8 + 8 * run);
+  if (c & 0xFEFEFEFEFEFEFEFEull) { bool d; return upd_side<true>(s, ty, tx0, R, uf, v, d); }   // two sources on one target: in order
+  return upd_apply8(v, a, uf);
+}
+__device__ __forceinline__ void upd_zero(uint8_t* p, int bytes, int tid) {   // bytes % 16 == 0, p 16-byte aligned
+  for (int i = tid; i < bytes / 16; i += 256) ((uint4*)p)[i] = make_uint4(0, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // chroma: one 64 x 14 tile of one stored component per workgroup.  Tiles no update can reach (Q3: sources exist in the top-left
 // quadrant only) and pictures without a contributing B picture keep the stored chroma: analysis(synthesis(u)) == u exactly.
-template <int NX>
+template <int NX, bool SC>
 __device__ __forceinline__ void upd_chroma_body(const UpdArgs& a, uint8_t* smem, const int bx_, const int by_, const int bz_, const int tid) {
   uint8_t (*sP)[PCT_FW] = (uint8_t (*)[PCT_FW])smem;
   uint32_t (*sL)[PCT_W / 2] = (uint32_t (*)[PCT_W / 2])(smem + PCT_SP_BYTES);
@@ -239,13 +316,51 @@ __device__ __forceinline__ void upd_chroma_body(const UpdArgs& a, uint8_t* smem,
     s[q].nby = imin(g.BY, ((chh - 1) >> lbs) + 1); s[q].nbx = imin(g.BX, ((cw - 1) >> lbs) + 1);
   }
   // A. the footprint: interpolated stored chroma (update.cpp:472-503), then both sides' updates
-  for (int k = tid; k < PCT_FH * (PCT_FW / 8); k += PCT_T) {
-    const int ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
-    uint64_t v = 0;
-    if ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) {
-      v = upd_run<NX>(s, yy, xx, a.reach, a.uf, chroma_run8(u, g, yy, xx));
+  if (!SC) {
+    for (int k = tid; k < PCT_FH * (PCT_FW / 8); k += PCT_T) {
+      const int ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
+      uint64_t v = 0;
+      if ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) {
+        v = upd_run<NX>(s, yy, xx, a.reach, a.uf, chroma_run8(u, g, yy, xx));
+      }
+      *(uint64_t*)&sP[ry][8 * run] = v;
     }
-    *(uint64_t*)&sP[ry][8 * run] = v;
+  } else {  // scatter form: one side at a time through the image behind the footprint (a thread keeps its runs from phase to phase)
+    uint8_t* acc = smem + PCT_SP_BYTES;
+    uint8_t* cnt = acc + PCT_FH * UC_STR;
+    constexpr int NRUN = PCT_FH * (PCT_FW / 8), NIT = (NRUN + PCT_T - 1) / PCT_T;
+    uint64_t v[NIT];
+    ChromaLd ld[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+      const int k = tid + i * PCT_T, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8);
+      ld[i] = chroma_run8_ld(u, g, yb + ry, xb + 8 * run);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+      const int k = tid + i * PCT_T, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
+      v[i] = (k < NRUN && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) ? chroma_run8_fin(ld[i], u, g, yy, xx) : 0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (!s[q].high) continue;   // (uniform)
+      upd_zero(acc, 2 * PCT_FH * UC_STR, tid);
+      __syncthreads();
+      upd_scatter<UC_STR>(s[q], yb, PCT_FH, xb, PCT_FW, a.reach, acc, cnt, tid);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NIT; i++) {
+        const int k = tid + i * PCT_T, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
+        if (k < NRUN && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W)
+          v[i] = upd_from_image<UC_STR>(s[q], acc, cnt, ry, run, yy, xx, a.reach, a.uf, v[i]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+      const int k = tid + i * PCT_T, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8);
+      if (k < NRUN) *(uint64_t*)&sP[ry][8 * run] = v[i];
+    }
   }
   __syncthreads();
   // cells on the picture's border: the ordered gather over everything that clips onto them
@@ -281,6 +396,57 @@ __device__ __forceinline__ void upd_chroma_body(const UpdArgs& a, uint8_t* smem,
   }
 }
 
+__device__ __forceinline__ void upd_luma_tile(const UpdArgs& a, uint8_t* smem, const int bx_, const int by_, const int j, const int tid) {
+  const LevelGeom& g = a.g;
+  const int x0 = bx_ * US_W, y0 = by_ * US_H;
+  const int ncols = imin(US_W, g.W - x0), nrows = imin(US_H, g.H - y0);
+  UpdSide sd[2];
+  upd_sides(a, j, sd);
+  const uint8_t* src = frame_y(a.frames, g, a.src_mul * j);
+  uint8_t* dst = a.low + (size_t)(a.dst_mul * j) * g.F;
+  uint64_t v[2];
+  bool ok[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int i = tid + 256 * k, row = i >> 4, run = i & 15;
+    ok[k] = row < nrows && 8 * run < ncols;
+    v[k] = ok[k] ? ld8(src + (size_t)(y0 + row) * g.W + x0 + 8 * run) : 0ull;
+  }
+  const bool any = sd[0].high || sd[1].high;
+  if (any) {
+    const UpdSrc s[2] = {upd_src_luma(g, sd[0]), upd_src_luma(g, sd[1])};
+    uint8_t* acc = smem;                       // [2][US_H][US_STR]
+    uint8_t* cnt = smem + 2 * US_H * US_STR;
+    upd_zero(smem, US_SMEM, tid);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (s[q].high) upd_scatter<US_STR>(s[q], y0, nrows, x0, ncols, a.reach, acc + q * US_H * US_STR, cnt + q * US_H * US_STR, tid);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      if (!ok[k]) continue;
+      const int i = tid + 256 * k, row = i >> 4, run = i & 15;
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (s[q].high)
+          v[k] = upd_from_image<US_STR>(s[q], acc + q * US_H * US_STR, cnt + q * US_H * US_STR, row, run, y0 + row, x0 + 8 * run, a.reach, a.uf, v[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    if (!ok[k]) continue;
+    const int i = tid + 256 * k, ty = y0 + (i >> 4), tx0 = x0 + 8 * (i & 15);
+    uint8_t* d = dst + (size_t)ty * g.W + tx0;
+    const bool edge = any && (ty == 0 || ty == g.H - 1 || tx0 == 0 || tx0 + 8 == g.W);   // border cells belong to the border role
+    if (!edge) *(uint2*)d = make_uint2((uint32_t)v[k], (uint32_t)(v[k] >> 32));
+    else if (ty != 0 && ty != g.H - 1) {
+      for (int c = 0; c < 8; c++)
+        if (tx0 + c != 0 && tx0 + c != g.W - 1) d[c] = (uint8_t)(v[k] >> (8 * c));
+    }
+  }
+}
+
 // One launch per level: the chroma tiles first (the longest workgroups), then the luma strips, then the border cells.
 template <int NX>
 __global__ void __launch_bounds__(256) k_upd_level(UpdArgs a, int ncx, int ncy, int nlx, int nly) {
@@ -288,7 +454,7 @@ __global__ void __launch_bounds__(256) k_upd_level(UpdArgs a, int ncx, int ncy, 
   const int np = a.g.nB + 1;
   int b = blockIdx.x;
   const int nchroma = ncx * ncy * np * 2, nluma = nlx * nly * np;
-  if (b < nchroma) { upd_chroma_body<NX>(a, smem, b % ncx, (b / ncx) % ncy, b / (ncx * ncy), threadIdx.x); return; }
+  if (b < nchroma) { upd_chroma_body<NX, false>(a, smem, b % ncx, (b / ncx) % ncy, b / (ncx * ncy), threadIdx.x); return; }
   b -= nchroma;
   if (b < nluma) { upd_luma_body<NX>(a, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x & 63, threadIdx.x >> 6); return; }
   b -= nluma;
@@ -296,14 +462,90 @@ __global__ void __launch_bounds__(256) k_upd_level(UpdArgs a, int ncx, int ncy, 
   upd_border_body(a, (b % nbb) * 256 + threadIdx.x, b / nbb);
 }
 
+// The stored chroma no update can reach (Q3: three quarters of every plane) is a plain copy; one workgroup per 64 x 14 tile made
+// that copy cost its workgroup dispatches (about a nanosecond each, 8 000 per launch at 1080p).  Here the plane outside the
+// rectangle of active tiles [0, ya) x [0, xa) is two regions -- A: rows ya.., contiguous; B: rows 0..ya, columns xa.. -- copied 16 KB
+// per workgroup.
+#define UPD_COPY_BYTES 16384
+struct UpdCopyGeom { int ya, xa, nWA, nWB, rowsB; };
+__device__ __forceinline__ void upd_copy_span(uint8_t* d, const uint8_t* s, int n, int tid) {   // n % 4 == 0, both 4-byte aligned
+  if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0) {
+    const int nv = n >> 4;
+    for (int i = tid; i < nv; i += 256) ((uint4*)d)[i] = ((const uint4*)s)[i];
+    for (int i = (nv << 2) + tid; i < (n >> 2); i += 256) ((uint32_t*)d)[i] = ((const uint32_t*)s)[i];
+  } else {
+    for (int i = tid; i < (n >> 2); i += 256) ((uint32_t*)d)[i] = ((const uint32_t*)s)[i];
+  }
+}
+__device__ __forceinline__ void upd_chroma_copy(const UpdArgs& a, const UpdCopyGeom& cg, int k, int plane, int tid) {
+  const LevelGeom& g = a.g;
+  const int j = plane >> 1, c = 1 + (plane & 1), cw = g.W >> 1, chh = g.H >> 1;
+  const uint8_t* u = frame_c(a.frames, g, a.src_mul * j, c);
+  uint8_t* dst = a.low + (size_t)(a.dst_mul * j) * g.F + (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh;
+  if (k < cg.nWA) {
+    const size_t o0 = (size_t)cg.ya * cw + (size_t)k * UPD_COPY_BYTES, end = (size_t)chh * cw;
+    upd_copy_span(dst + o0, u + o0, (int)(end - o0 < UPD_COPY_BYTES ? end - o0 : UPD_COPY_BYTES), tid);
+    return;
+  }
+  const int r0 = (k - cg.nWA) * cg.rowsB, r1 = imin(cg.ya, r0 + cg.rowsB), wB = cw - cg.xa;
+  const bool wide = ((((uintptr_t)dst | (uintptr_t)u) & 15) == 0) && (cw & 15) == 0 && (cg.xa & 15) == 0;   // (uniform)
+  const int sh = wide ? 4 : 2, per = wB >> sh, total = (r1 - r0) * per;
+  const float inv = 1.0f / (float)per;
+  for (int i = tid; i < total; i += 256) {
+    const int r = (int)(((float)i + 0.5f) * inv), q = i - r * per;
+    const size_t o = (size_t)(r0 + r) * cw + cg.xa + ((size_t)q << sh);
+    if (wide) *(uint4*)(dst + o) = *(const uint4*)(u + o);
+    else *(uint32_t*)(dst + o) = *(const uint32_t*)(u + o);
+  }
+}
+// the scatter form of the same launch: the chroma tiles an update can reach, luma tiles of US_W x US_H targets, border cells, the
+// copy of the rest of the chroma
+__global__ void __launch_bounds__(256) k_upd_level_sc(UpdArgs a, int ncxa, int ncya, int nlx, int nly, UpdCopyGeom cg) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[UPD_SC_SMEM];
+  const int np = a.g.nB + 1;
+  int b = blockIdx.x;
+  const int nchroma = ncxa * ncya * np * 2, nluma = nlx * nly * np;
+  if (b < nchroma) { upd_chroma_body<0, true>(a, smem, b % ncxa, (b / ncxa) % ncya, b / (ncxa * ncya), threadIdx.x); return; }
+  b -= nchroma;
+  if (b < nluma) { upd_luma_tile(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x); return; }
+  b -= nluma;
+  const int nbb = (2 * a.g.W + 2 * (a.g.H - 2) + 255) / 256;
+  if (b < nbb * np) { upd_border_body(a, (b % nbb) * 256 + threadIdx.x, b / nbb); return; }
+  b -= nbb * np;
+  const int ncopy = cg.nWA + cg.nWB;
+  upd_chroma_copy(a, cg, b % ncopy, b / ncopy, threadIdx.x);
+}
+
 bool upd_run_applies(const UpdArgs& a) {
   const LevelGeom& g = a.g;
   return g.bs >= 8 && (g.bs & (g.bs - 1)) == 0 && g.W % 8 == 0 && g.H % 2 == 0 && g.H % g.bs == 0 && g.W % g.bs == 0 && g.H >= 8 && g.W >= 16 &&
          a.reach <= 255;
 }
+// fewer than 256 blocks within reach of a target: the byte counters of the scatter form cannot wrap
+static bool upd_scatter_applies(const UpdArgs& a) {
+  const int nb = 2 * a.reach / a.g.bs + 2;
+  return nb * nb < 256;
+}
 void launch_update_run(hipStream_t st, const UpdArgs& a) {
   const LevelGeom& g = a.g;
   const int np = g.nB + 1, nx = upd_max_cols(g.bs, a.reach);
+  if (tuning().upd_scatter && upd_scatter_applies(a)) {
+    const int cw = g.W / 2, chh = g.H / 2;
+    const int nlx = (g.W + US_W - 1) / US_W, nly = (g.H + US_H - 1) / US_H, ncx = (cw + PCT_W - 1) / PCT_W, ncy = (chh + PCT_H - 1) / PCT_H;
+    // tile (bx, by) is active iff 2 by PCT_H - 2 < chh + reach and 2 bx PCT_W - 2 < cw + reach (upd_chroma_body)
+    const int ncya = imin(ncy, (chh + a.reach + 1) / (2 * PCT_H) + 1), ncxa = imin(ncx, (cw + a.reach + 1) / (2 * PCT_W) + 1);
+    UpdCopyGeom cg;
+    cg.ya = imin(chh, ncya * PCT_H); cg.xa = imin(cw, ncxa * PCT_W);
+    const size_t nA = (size_t)(chh - cg.ya) * cw;
+    cg.nWA = (int)((nA + UPD_COPY_BYTES - 1) / UPD_COPY_BYTES);
+    const int wB = cw - cg.xa;
+    cg.rowsB = wB > 0 ? imax(1, UPD_COPY_BYTES / wB) : 1;
+    cg.nWB = wB > 0 ? (cg.ya + cg.rowsB - 1) / cg.rowsB : 0;
+    const int nbb = (2 * g.W + 2 * (g.H - 2) + 255) / 256;
+    const unsigned nwg = (unsigned)(ncxa * ncya * np * 2 + nlx * nly * np + nbb * np + (cg.nWA + cg.nWB) * np * 2);
+    hipLaunchKernelGGL(k_upd_level_sc, dim3(nwg), dim3(256), 0, st, a, ncxa, ncya, nlx, nly, cg);
+    return;
+  }
   const int nlx = (g.W + 511) / 512, nly = (g.H + 3) / 4, ncx = (g.W / 2 + PCT_W - 1) / PCT_W, ncy = (g.H / 2 + PCT_H - 1) / PCT_H;
   const int nbb = (2 * g.W + 2 * (g.H - 2) + 255) / 256;
   const dim3 grid((unsigned)(ncx * ncy * np * 2 + nlx * nly * np + nbb * np)), block(256);

@@ -19,6 +19,7 @@ struct Tuning {
   int me_piece = 1;       // QSVC_ME_PIECE     set: the border-rule search kernels for every block
   int pred_run = 1;       // QSVC_PRED_RUN     set: the general predict kernels
   int upd_run = 1;        // QSVC_UPD_RUN      set: the general update kernels
+  int upd_scatter = 1;    // QSVC_UPD_SCATTER=0 the ordered gather by runs instead of the scatter tiles
   int dwt_pk = 1;         // QSVC_DWT_PK=0     the general DWT tile kernel for 5/3 too
   int defer_ib = 1;       // QSVC_DEFER_IB=0   the I/B decision of every level taken at once (one host round trip per level)
   static Tuning from_env() {
@@ -34,6 +35,7 @@ struct Tuning {
     if (getenv("QSVC_ME_PIECE")) t.me_piece = 0;
     if (getenv("QSVC_PRED_RUN")) t.pred_run = 0;
     if (getenv("QSVC_UPD_RUN")) t.upd_run = 0;
+    if ((e = getenv("QSVC_UPD_SCATTER"))) t.upd_scatter = e[0] != '0';
     if ((e = getenv("QSVC_DWT_PK"))) t.dwt_pk = e[0] != '0';
     if ((e = getenv("QSVC_DEFER_IB"))) t.defer_ib = e[0] != '0';
     return t;
@@ -41,7 +43,7 @@ struct Tuning {
   bool set(const char* name, int v) {
     struct { const char* n; int* p; } tab[] = {{"mq_pipe", &mq_pipe}, {"mq_lds_small", &mq_lds_small}, {"mq_lanes", &mq_lanes}, {"mq_sort", &mq_sort},
                                                {"t1_parts", &t1_parts}, {"t1_devlist", &t1_devlist}, {"pyr_tile", &pyr_tile}, {"me_piece", &me_piece},
-                                               {"pred_run", &pred_run}, {"upd_run", &upd_run}, {"dwt_pk", &dwt_pk}, {"defer_ib", &defer_ib}};
+                                               {"pred_run", &pred_run}, {"upd_run", &upd_run}, {"upd_scatter", &upd_scatter}, {"dwt_pk", &dwt_pk}, {"defer_ib", &defer_ib}};
     for (auto& t : tab)
       if (!strcmp(t.n, name)) {
         if (t.p == &mq_lanes && !(v == 4 || v == 8 || v == 16 || v == 32 || v == 64)) return false;
