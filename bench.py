@@ -148,6 +148,34 @@ def spawn_ranks(n):
     return rc
 
 
+def cgroup_cpu():
+    """CPU time used / throttled by this container so far (cgroup v2 cpu.stat, microseconds) and its quota in CPUs (cpu.max); None
+    where the files do not exist.  The GPU boxes of the pool give a one-GPU job 16 CPUs whatever the machine has."""
+    try:
+        st = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines())
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        return {"usage_us": int(st["usage_usec"]), "throttled_us": int(st.get("throttled_usec", 0)), "quota_cpus": None if q[0] == "max" else int(q[0]) / int(q[1])}
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
+
+
+def task_cpu():
+    """CPU seconds of this process's live threads by thread name (/proc/self/task/*/stat: utime + stime)."""
+    out, tick = {}, os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                st = open(f"/proc/self/task/{tid}/stat").read()
+            except OSError:
+                continue
+            name = st[st.index("(") + 1:st.rindex(")")]
+            f = st[st.rindex(")") + 2:].split()
+            out[name] = out.get(name, 0.0) + (int(f[11]) + int(f[12])) / tick
+    except OSError:
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,13 +362,17 @@ def main():
 
     failures = []
 
+    sess_cpu = [0.0]
+
     def run_steps(n):
         """n steps; a step = every session completing one whole encode.  Any session's exception fails the run."""
         def work(k):
+            c0 = time.thread_time()
             try:
                 for _ in range(n):
                     step(k)
                 engs[k].sync()
+                sess_cpu[0] += time.thread_time() - c0   # (the session thread's own CPU time: Python + the library calls it makes)
             except BaseException as ex:  # noqa: BLE001
                 failures.append((k, repr(ex)))
                 if lock is not None:
@@ -412,10 +444,13 @@ def main():
         e.set_profiling(True)
     barrier()
     phase.update(analyze_calls_return=0.0, motion_call=0.0, texture_call=0.0, n=0)
+    cpu0, tk0 = cgroup_cpu(), task_cpu()
+    sess_cpu[0] = 0.0
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    cpu1, tk1, sess_s = cgroup_cpu(), task_cpu(), sess_cpu[0]
     nbytes = nbytes_of[0]
     if dist is not None:
         import torch
@@ -424,6 +459,16 @@ def main():
         dt = float(tt.item())
     timings = eng.timings()
     stats = eng.j2k_stats()
+    host_cpu = None
+    if cpu0 and cpu1:   # what the timed region cost on the host: the whole container (every session, Tier-2 and HIP runtime thread)
+        host_cpu = {"cpu_ms_per_step": round((cpu1["usage_us"] - cpu0["usage_us"]) / 1e3 / max(args.steps, 1), 2),
+                    "cpus_busy": round((cpu1["usage_us"] - cpu0["usage_us"]) / 1e6 / dt, 2), "quota_cpus": cpu1["quota_cpus"],
+                    "throttled_ms_in_timed_region": round((cpu1["throttled_us"] - cpu0["throttled_us"]) / 1e3, 1),
+                    "source": "cgroup v2 cpu.stat / cpu.max of the container"}
+        # who used it: the session threads (their own CPU clocks), then the live threads by name -- Tier-2 workers ("qsvc-t2"), the
+        # main thread and whatever the HIP / ROCr runtime keeps (its signal handlers and helpers carry the process name)
+        by = {k: tk1.get(k, 0.0) - tk0.get(k, 0.0) for k in tk1}
+        host_cpu["cpus_by_thread"] = dict({"session_threads": round(sess_s / dt, 2)}, **{k: round(v / dt, 2) for k, v in sorted(by.items(), key=lambda kv: -kv[1]) if v / dt >= 0.05})
     phase_timed = {k: round(v / max(phase["n"], 1) * 1e3, 3) for k, v in phase.items() if k != "n"}
     for e in engs:
         e.set_profiling(False)
@@ -672,7 +717,7 @@ def main():
             "ebcot_codeblocks_per_s_kernel": round(ncb_step / (t1ms * 1e-3), 1) if t1ms else None,
             "codestream_bytes_per_step": int(nbytes), "codestream_bytes_per_step_all_sessions": int(sum(nbytes_of)),
             "motion_codestream_bytes_per_step": int(mv_bytes_of[0]), "mq_symbols_per_step": int(stats["symbols"]),
-            "kernels": per, "host_stages": host, "session0_calls_ms": phase_timed, "roofline": roof, "roofline_streaming": streaming,
+            "kernels": per, "host_stages": host, "host_cpu": host_cpu, "session0_calls_ms": phase_timed, "roofline": roof, "roofline_streaming": streaming,
         }
         if serial_ms is not None:
             line["single_sequence"] = {"ms_per_encode": round(serial_ms, 3), "frames_per_s": round(P / (serial_ms * 1e-3), 2),

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <pthread.h>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -210,6 +211,7 @@ struct T2Pool {
     nworkers = n;
     for (int t = 0; t < n; t++)
       th.emplace_back([this, t] {
+        (void)pthread_setname_np(pthread_self(), "qsvc-t2");   // (bench.py's host_cpu tells the threads apart by name)
         int seen = 0;
         for (;;) {
           std::function<void(int)> f;
@@ -297,7 +299,7 @@ struct J2kState {
 // shadow copy is what was last uploaded from; the source of the async copy is the shadow, which outlives the call.
 static int upload_if_changed(qsvc_ctx* c, void* dev, const void* src, size_t bytes, std::vector<uint8_t>& shadow, const void*& at) {
   if (at == dev && shadow.size() == bytes && (bytes == 0 || memcmp(shadow.data(), src, bytes) == 0)) return QSVC_OK;
-  hipError_t e = hipStreamSynchronize(c->st);  // (a copy still reading the old shadow must have finished before it is overwritten)
+  hipError_t e = ctx_sync(c);  // (a copy still reading the old shadow must have finished before it is overwritten)
   if (e != hipSuccess) return c->hipfail(e, "hipStreamSynchronize");
   shadow.assign((const uint8_t*)src, (const uint8_t*)src + bytes);
   at = dev;
@@ -624,7 +626,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     HIPCHK(c, hipMemcpyAsync(&perr, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
     {
       const auto w0 = std::chrono::steady_clock::now();
-      HIPCHK(c, hipStreamSynchronize(c->st));
+      HIPCHK(c, ctx_sync(c));
       c->host_time("host_wait_dwt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
     }
     // a block with more bit-planes than its subband allows (or than the 15-bit magnitude format holds) must never reach
@@ -722,8 +724,9 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
       HIPCHK(c, hipMemcpyAsync(S.pdist.data(), S.pdist_d.p, (size_t)ncb * T1_MAXPASS * 8, hipMemcpyDeviceToHost, c->st));
     }
     {
+      HostCpu hc(c, "host_cpu_wait_tier1");
       const auto w0 = std::chrono::steady_clock::now();
-      HIPCHK(c, hipStreamSynchronize(c->st));
+      HIPCHK(c, ctx_sync(c));
       c->host_time(src[0].s16 ? "host_mv_wait_tier1" : "host_wait_tier1", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
     }
     HIPCHK(c, hipGetLastError());
@@ -838,7 +841,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     offs[np] = pos;
     double t2_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2a_begin).count();
     if (pos > cap) {
-      (void)hipStreamSynchronize(c->st);
+      (void)ctx_sync(c);
       return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes needed, %zu given)", pos, cap);
     }
     const auto t2b_begin = std::chrono::steady_clock::now();
@@ -847,11 +850,11 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     S.pool->run([&](int tid) {
       (void)hipSetDevice(c->dev);
       for (int p = tid; p < np; p += nthreads) {
-        if (piece_of[p] > waited[tid]) { (void)hipEventSynchronize(S.copied[piece_of[p]]); waited[tid] = piece_of[p]; }  // pieces complete in order
+        if (piece_of[p] > waited[tid]) { (void)(c->tune.sync_block ? wait_event_sleeping(S.copied[piece_of[p]]) : hipEventSynchronize(S.copied[piece_of[p]])); waited[tid] = piece_of[p]; }  // pieces complete in order
         rc2[p] = stream_of(p, out + offs[p], (size_t)rc[p]);
       }
     });
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    { HostCpu hc2(c, "host_cpu_wait_copy"); HIPCHK(c, ctx_sync(c)); }
     HIPCHK(c, hipGetLastError());
     for (int p = 0; p < np; p++) if (rc2[p] != rc[p]) return c->fail(QSVC_ERR_HIP, "internal: Tier-2 length of plane %d changed between the passes", p);
     t2_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2b_begin).count();
@@ -948,6 +951,7 @@ int qsvc_compress_code(qsvc_ctx* c, int nseq, const int* kinds, const int* ts, c
   if (!c || !kinds || !ts || !firsts || !counts || !prms || !out || !offs || nseq < 1) return QSVC_ERR_INVALID;
   (void)hipSetDevice(c->dev);
   if (!c->F) return c->fail(QSVC_ERR_STATE, "qsvc_seq_config not called");
+  HostCpu hc(c, "host_cpu_code_call");
   std::vector<PlaneSrc> src;
   for (int i = 0; i < nseq; i++) {
     int r = add_sequence(c, kinds[i], ts[i], firsts[i], counts[i], &prms[i], src);
@@ -995,7 +999,7 @@ int qsvc_compress_code(qsvc_ctx* c, int nseq, const int* kinds, const int* ts, c
       const size_t bytes = planes.size() * sizeof(int16_t), N = (size_t)BY * BX;
       if ((r = c->j2k->mvup_d.ensure(c, bytes))) return r;
       HIPCHK(c, hipMemcpyAsync(c->j2k->mvup_d.p, planes.data(), bytes, hipMemcpyHostToDevice, c->st));
-      HIPCHK(c, hipStreamSynchronize(c->st));  // (`planes` is pageable and local)
+      HIPCHK(c, ctx_sync(c));  // (`planes` is pageable and local)
       for (size_t p = 0; p < planes.size() / N; p++) src.push_back({(const uint8_t*)c->j2k->mvup_d.p + p * N * 2, BX, BX, BY, &mprm, 1});
     }
   }
@@ -1067,7 +1071,7 @@ int qsvc_j2k_dwt(qsvc_ctx* c, const uint8_t* plane, int H, int W, int reversible
   else launch_dwt_tiles(c->st, (const PlaneDesc*)S.planes_d.p, 1, W, H, W, H, nullptr, L, reversible != 0, S.llA.p, S.llB.p, nullptr, nullptr,
                         S.coefA.p, 6, 6, (int*)S.err_d.p, nullptr, nullptr);
   HIPCHK(c, hipMemcpyAsync(out, S.coefA.p, N * 4, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   HIPCHK(c, hipGetLastError());
   return QSVC_OK;
 }

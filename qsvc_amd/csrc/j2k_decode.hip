@@ -662,7 +662,7 @@ static int decode_impl(qsvc_ctx* c, int nstreams, const uint8_t* const* streams,
                      S.coefA.p, dev_dst ? dev_dst : (uint8_t*)S.out_d.p);
   pf.end(c);
   if (!dev_dst) HIPCHK(c, hipMemcpyAsync(out, S.out_d.p, out_total, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));  // (the parsed tables are local: the kernels must be through with them)
+  HIPCHK(c, ctx_sync(c));  // (the parsed tables are local: the kernels must be through with them)
   HIPCHK(c, hipGetLastError());
   return QSVC_OK;
 }

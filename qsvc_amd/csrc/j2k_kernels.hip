@@ -522,7 +522,14 @@ __device__ __forceinline__ uint64_t cm2_transpose64(uint64_t v, int lane) {
 }
 
 #define CM2_CW_STRIDE 67
-#define CM2_OUT_BYTES 9984    // (with the list of the sparse form at CM2_LIST_AT: 480 entries)  // the largest pass segment (clean-up: 10 decisions per stripe column at most)
+// The staging buffer of a plane's three decision streams.  16 360 bytes of LDS per wave in all = ten waves per CU (round 4: with
+// room for the worst case, 9 984 bytes = 20.4 KB per wave, seven waves fitted; the modelling kernel is VALU-bound and every wave
+// more shows in the throughput figure).  A plane whose decisions do not fit (more than about 1.4 per sample: rare) writes its
+// passes straight to memory, byte by byte.
+#ifndef CM2_OUT_BYTES
+#define CM2_OUT_BYTES 5888
+#endif
+static_assert(CM2_LIST_AT + CM2_LIST_MAX * 8 <= CM2_OUT_BYTES, "the sparse form's list lies inside the staging buffer");
 static_assert(T1_TABLES_BYTES == CM2_TAB_BYTES, "table block size");
 __global__ void __launch_bounds__(64) k_t1_tables(uint8_t* tabs) {
   const int t = threadIdx.x;
@@ -534,7 +541,7 @@ __global__ void __launch_bounds__(64) k_t1_tables(uint8_t* tabs) {
 }
 void launch_t1_tables(hipStream_t st, uint8_t* tabs) { hipLaunchKernelGGL(k_t1_tables, dim3(1), dim3(64), 0, st, tabs); }
 
-__global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff, const int* order,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_t1_cm2(const CbDesc* cbs, int ncb, const int* nbps_in, const int* joboff, const int* order,
                                                 const unsigned long long* mags, uint8_t* segs, int* cnt, long long* dist, int want_dist, const uint8_t* tabs) {
   __shared__ uint32_t s_cw[18][CM2_CW_STRIDE];   // one-cell apron of zeros; odd stride: the emission lanes (stripe, 16-column run) read 2-way, the best 64 lanes can get
   __shared__ __attribute__((aligned(16))) uint32_t s_sp[64];
@@ -543,6 +550,10 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
   __shared__ __attribute__((aligned(16))) uint8_t s_sign[256];
   __shared__ __attribute__((aligned(16))) uint32_t s_pk[64][8];   // per column: its 16 stripes' decisions per pass + "listed" flag (cm2_pack_pk)
   __shared__ __attribute__((aligned(16))) uint64_t s_cmp8[256];
+#ifdef CM2_EXP_PAD
+  __shared__ uint32_t s_pad[CM2_EXP_PAD / 4];
+  if (ncb < 0) { s_pad[threadIdx.x] = 1; __syncthreads(); cnt[0] = (int)s_pad[threadIdx.x ^ 1]; }   // (experiment: LDS footprint sensitivity)
+#endif
   // order != nullptr: workgroup k models block order[k] (the MQ stage's slot table: longest blocks first; ncb = an idle slot)
   const int lane = threadIdx.x, b = order ? order[blockIdx.x] : (int)blockIdx.x;
   if (b >= ncb) return;
@@ -779,20 +790,17 @@ __global__ void __launch_bounds__(64) k_t1_cm2(const CbDesc* cbs, int ncb, const
       uint8_t* dst = seg + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
       for (int o = lane * 16; o < tot3[pass]; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(src + o);
     }
-  } else {  // a dense plane: one pass at a time through the buffer (the per-pass column form)
+  } else {  // more decisions than the buffer holds: one pass at a time, straight to memory (the per-pass column form)
     for (int pass = pass0; pass < 3; pass++) {
+      uint8_t* dst = seg + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
       Cm2ByteSink B;
-      B.out = s_out + off3[pass]; B.n = 0;
+      B.out = dst + off3[pass]; B.n = 0;
       for (int i = lane * 16; i < lane * 16 + 16; i++) {
         const int s = i >> 6, x = i & 63;
         if (s < nstr && x < w)
           cm2_column(B, cx, pass, &s_cw[s][x], &s_cw[s + 1][x], &s_cw[s + 2][x], want_dist ? mg[i] : 0ull, d3[pass]);
       }
-      if (lane < 16 && tot3[pass] + lane < ((tot3[pass] + 15) & ~15)) s_out[tot3[pass] + lane] = (uint8_t)T1_PAD;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
-      uint8_t* dst = seg + (pass == 0 ? 0 : (pass == 1 ? T1_SEG1 : T1_SEG2));
-      for (int o = lane * 16; o < tot3[pass]; o += 64 * 16) *(uint4*)(dst + o) = *(const uint4*)(s_out + o);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+      if (lane < 16 && tot3[pass] + lane < ((tot3[pass] + 15) & ~15)) dst[tot3[pass] + lane] = (uint8_t)T1_PAD;
     }
   }
   for (int pass = 0; pass < 3; pass++) {

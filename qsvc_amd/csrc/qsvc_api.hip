@@ -7,6 +7,7 @@
 //   level chain          analyze_step.py:117-232
 #include "qsvc_ctx.h"
 
+#include <mutex>
 #include <math.h>
 #include <stdarg.h>
 #include <algorithm>
@@ -124,6 +125,7 @@ void qsvc_destroy(qsvc_ctx* c) {
   c->mvtmp[0].release(); c->mvtmp[1].release(); c->rp[0].release(); c->rp[1].release(); c->sp[0].release(); c->sp[1].release();
   for (int s_ = 0; s_ < 2; s_++) { c->halo_tx[s_].release(); c->halo_rx[s_].release(); c->halo_btx[s_].release(); c->halo_brx[s_].release(); }
   if (c->halo_ev) (void)hipEventDestroy(c->halo_ev);
+  if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
   c->margin.release(); c->cup.release(); c->ovl[0].release(); c->ovl[1].release();
   if (c->comm) qsvc_comm_destroy(c);
   c->scal.release(); c->allB.release(); c->tmp16[0].release(); c->tmp16[1].release(); c->hhist.release();
@@ -139,7 +141,7 @@ void* qsvc_stream(qsvc_ctx* c) { return c ? (void*)c->st : nullptr; }
 int qsvc_sync(qsvc_ctx* c) {
   if (!c) return QSVC_ERR_INVALID;
   { int rr_ = qsvc_resolve(c); if (rr_) return rr_; }
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   return QSVC_OK;
 }
 
@@ -150,7 +152,7 @@ int qsvc_seq_config(qsvc_ctx* c, int W, int H, int keep_prediction) {
   if (W < 16 || H < 16 || W > 16384 || H > 16384) return c->fail(QSVC_ERR_INVALID, "bad geometry %dx%d", W, H);
   if ((W & 1) || (H & 1)) return c->fail(QSVC_ERR_UNSUPPORTED, "odd picture size %dx%d (4:2:0 needs even sizes)", W, H);
   (void)hipSetDevice(c->dev);
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   free_seq(c);
   c->W = W; c->H = H; c->F = (size_t)W * H + 2 * (size_t)(W / 2) * (H / 2);
   c->keep_pred = keep_prediction;
@@ -180,7 +182,7 @@ int qsvc_put_frames(qsvc_ctx* c, int kind, int t, int first, int count, int tota
   *n = total;
   c->cup_src = nullptr;  // pictures change: the interpolated chroma planes are stale
   HIPCHK(c, hipMemcpyAsync((uint8_t*)b->p + (size_t)first * c->F, src, (size_t)count * c->F, hipMemcpyHostToDevice, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   return QSVC_OK;
 }
 int qsvc_get_frames(qsvc_ctx* c, int kind, int t, int first, int count, uint8_t* dst) {
@@ -191,7 +193,7 @@ int qsvc_get_frames(qsvc_ctx* c, int kind, int t, int first, int count, uint8_t*
   if (r) return r;
   if (first < 0 || count < 0 || first + count > *n) return c->fail(QSVC_ERR_STATE, "sequence kind %d t=%d holds %d pictures", kind, t, *n);
   HIPCHK(c, hipMemcpyAsync(dst, (uint8_t*)b->p + (size_t)first * c->F, (size_t)count * c->F, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   return QSVC_OK;
 }
 
@@ -249,7 +251,7 @@ int qsvc_put_motion(qsvc_ctx* c, int kind, int t, int nB, int bs, const int16_t*
   l.mv_bs = bs;
   l.mv_bound = -1;
   HIPCHK(c, hipMemcpyAsync(b.p, mv, bytes, hipMemcpyHostToDevice, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   return QSVC_OK;
 }
 int qsvc_get_motion(qsvc_ctx* c, int kind, int t, int b_pictures, int block_size, int16_t* mv) {
@@ -265,7 +267,7 @@ int qsvc_get_motion(qsvc_ctx* c, int kind, int t, int b_pictures, int block_size
   size_t bytes = (size_t)b_pictures * 4 * (c->H / l.mv_bs) * (c->W / l.mv_bs) * sizeof(int16_t);
   if (!bytes) return QSVC_OK;
   HIPCHK(c, hipMemcpyAsync(mv, b.p, bytes, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   return QSVC_OK;
 }
 int qsvc_put_frame_types(qsvc_ctx* c, int t, int nB, const char* types) {
@@ -291,7 +293,7 @@ int qsvc_get_histograms(qsvc_ctx* c, int t, int b_pictures, uint32_t* hist) {
   if (b_pictures > l.high_n) return c->fail(QSVC_ERR_STATE, "histograms of t=%d cover %d pictures (asked for %d)", t, l.high_n, b_pictures);
   if (!b_pictures) return QSVC_OK;
   HIPCHK(c, hipMemcpyAsync(hist, l.hist.p, (size_t)b_pictures * 3 * 256 * 4, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   return QSVC_OK;
 }
 
@@ -622,7 +624,7 @@ int qsvc_resolve(qsvc_ctx* c) {
   if (c->resolving) return QSVC_OK;
   if (c->pending.empty()) { c->calls.clear(); return QSVC_OK; }
   (void)hipSetDevice(c->dev);
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   c->resolving = true;
   int redo_level = 0, r = QSVC_OK;
   for (size_t k = 0; k < c->pending.size() && !redo_level; k++) {
@@ -721,7 +723,7 @@ static int decorrelate_impl(qsvc_ctx* c, int t, int P, int bs, int S, int always
     const size_t hbytes = (size_t)g.nB * 3 * 256 * 4;
     if (!c->hhist.ensure(hbytes)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%zu)", hbytes);
     HIPCHK(c, hipMemcpyAsync(c->hhist.p, lv.hist.p, hbytes, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, ctx_sync(c));
     for (int i = 0; i < g.nB; i++) {
       const uint32_t* h = (const uint32_t*)c->hhist.p + (size_t)i * 3 * 256;
       if (picture_is_I(h, g.H, g.W, g.BY, g.BX)) {  // 'I': the odd picture itself, zero motion
@@ -789,7 +791,7 @@ static int update_impl(qsvc_ctx* c, int t, int P, int bs, float uf) {
     for (int s = 0; s < 2; s++)
       if (lv.halo[s])
         HIPCHK(c, hipMemcpyAsync(halo_types[s], (const uint8_t*)lv.halo[s] + g.F + 4 * fld * sizeof(int16_t), 16, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, ctx_sync(c));
     // frame types to the device (tiny)
     if ((r = c->tmp16[0].ensure(c, (size_t)g.nB + 16))) return r;
     if (g.nB) HIPCHK(c, hipMemcpyAsync(c->tmp16[0].p, lv.types.data(), g.nB, hipMemcpyHostToDevice, c->st));
@@ -812,7 +814,7 @@ static int update_impl(qsvc_ctx* c, int t, int P, int bs, float uf) {
   pf.end(c);
   c->cup_src = nullptr;  // low_t was written: nothing interpolated from pictures may be reused across this point
   HIPCHK(c, hipGetLastError());
-  if (!resident) HIPCHK(c, hipStreamSynchronize(c->st));  // lv.types / halo buffers may be changed by the caller next
+  if (!resident) HIPCHK(c, ctx_sync(c));  // lv.types / halo buffers may be changed by the caller next
   return QSVC_OK;
 }
 
@@ -841,6 +843,8 @@ int qsvc_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
 }
 
 int qsvc_analyze_step(qsvc_ctx* c, int t, int P, int bs, int S, int always_B, float uf) {
+  if (!c) return QSVC_ERR_INVALID;
+  HostCpu hc(c, "host_cpu_analyze_call");
   int r = qsvc_motion_estimate(c, t, P, bs, S);
   if (r) return r;
   if ((r = qsvc_decorrelate(c, t, P, bs, S, always_B))) return r;
@@ -889,7 +893,7 @@ int qsvc_un_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   if (g.nB) launch_mv_maxabs(c->st, (const int16_t*)lv.mv_filt.p, (size_t)g.nB * 4 * fld, (int*)c->scal.p);
   int reach = 0;
   HIPCHK(c, hipMemcpyAsync(&reach, c->scal.p, sizeof(int), hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   if ((r = types_to_device(c, lv, g.nB))) return r;
   UpdArgs a;
   a.g = g; a.frames = (const uint8_t*)lv.low.p; a.high = (const uint8_t*)lv.high.p;
@@ -904,7 +908,7 @@ int qsvc_un_update(qsvc_ctx* c, int t, int P, int bs, float uf) {
   pf.end(c);
   c->cup_src = nullptr;
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   return QSVC_OK;
 }
 
@@ -943,7 +947,7 @@ int qsvc_correlate(qsvc_ctx* c, int t, int P, int bs, int S) {
   } else launch_predict(c->st, a);
   pf.end(c);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   return QSVC_OK;
 }
 
@@ -992,7 +996,7 @@ int qsvc_halo_export_host(qsvc_ctx* c, int t, int side, void* dst) {
   int r = halo_pack(c, t, side);
   if (r) return r;
   HIPCHK(c, hipMemcpyAsync(dst, c->halo_tx[side].p, qsvc_halo_bytes(c, c->lv[t].mv_bs), hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   return QSVC_OK;
 }
 int qsvc_halo_import_host(qsvc_ctx* c, int t, int side, const void* src) {
@@ -1006,7 +1010,7 @@ int qsvc_halo_import_host(qsvc_ctx* c, int t, int side, const void* src) {
   int r = c->halo_rx[side].ensure(c, n);
   if (r) return r;
   HIPCHK(c, hipMemcpyAsync(c->halo_rx[side].p, src, n, hipMemcpyHostToDevice, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   lv.halo[side] = c->halo_rx[side].p;
   return QSVC_OK;
 }
@@ -1146,7 +1150,7 @@ int qsvc_halo_batch_export_host(qsvc_ctx* const* ctxs, int n, int t, int side, v
   (void)hipSetDevice(o->dev);
   if ((r = batch_pack(ctxs, n, t, side, rec))) return r;
   HIPCHK(o, hipMemcpyAsync(dst, o->halo_btx[side].p, (size_t)n * rec, hipMemcpyDeviceToHost, o->st));
-  HIPCHK(o, hipStreamSynchronize(o->st));
+  HIPCHK(o, ctx_sync(o));
   return QSVC_OK;
 }
 int qsvc_halo_batch_import_host(qsvc_ctx* const* ctxs, int n, int t, int side, const void* src) {
@@ -1162,7 +1166,7 @@ int qsvc_halo_batch_import_host(qsvc_ctx* const* ctxs, int n, int t, int side, c
     // (the slots may still be read by the previous level's update of any context: their streams are joined first)
     for (int k = 1; k < n; k++) { HIPCHK(o, hipEventRecord(ctxs[k]->halo_ev, ctxs[k]->st)); HIPCHK(o, hipStreamWaitEvent(o->st, ctxs[k]->halo_ev, 0)); }
     HIPCHK(o, hipMemcpyAsync(o->halo_brx[side].p, src, (size_t)n * rec, hipMemcpyHostToDevice, o->st));
-    HIPCHK(o, hipStreamSynchronize(o->st));  // the caller's buffer is free on return
+    HIPCHK(o, ctx_sync(o));  // the caller's buffer is free on return
   }
   return batch_take(ctxs, n, t, side, rec, src != nullptr);
 }
@@ -1231,7 +1235,7 @@ int qsvc_motion_planes(qsvc_ctx* c, int nlevels, const int* ts, const int* field
       if (fields[k]) HIPCHK(c, hipMemcpyAsync(filt.data() + o, c->lv[ts[k]].mv_filt.p, (size_t)fields[k] * per * sizeof(int16_t), hipMemcpyDeviceToHost, c->st));
       o += (size_t)fields[k] * per;
     }
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, ctx_sync(c));
   }
   // residues, in place of the fields (a level's reference is the NEXT level's field, still unmodified: levels in ascending order)
   o = 0;
@@ -1299,7 +1303,7 @@ int qsvc_dwt53_trunc(qsvc_ctx* c, int16_t* plane, int H, int W, int stride, int 
     HIPCHK(c, hipMemcpy2DAsync(A, (size_t)stride * 2, B, (size_t)stride * 2, (size_t)nx * 2, ny, hipMemcpyDeviceToDevice, c->st));
   }
   HIPCHK(c, hipMemcpyAsync(plane, A, bytes, hipMemcpyDeviceToHost, c->st));
-  HIPCHK(c, hipStreamSynchronize(c->st));
+  HIPCHK(c, ctx_sync(c));
   HIPCHK(c, hipGetLastError());
   return QSVC_OK;
 }
@@ -1313,7 +1317,7 @@ int qsvc_set_tier2_threads(qsvc_ctx* c, int n) {
 }
 int qsvc_set_profiling(qsvc_ctx* c, int on) {
   if (!c) return QSVC_ERR_INVALID;
-  (void)hipStreamSynchronize(c->st);
+  (void)ctx_sync(c);
   for (auto& s : c->segs) s.used = 0;  // the event pairs stay (creating events costs more than the kernels they bracket)
   c->hsegs.clear();
   c->profiling = on;
@@ -1321,7 +1325,7 @@ int qsvc_set_profiling(qsvc_ctx* c, int on) {
 }
 int qsvc_get_timings(qsvc_ctx* c, const char** names, float* ms, int* launches, int cap) {
   if (!c) return QSVC_ERR_INVALID;
-  (void)hipStreamSynchronize(c->st);
+  (void)ctx_sync(c);
   int n = 0;
   for (auto& s : c->segs) {
     if (n >= cap) break;

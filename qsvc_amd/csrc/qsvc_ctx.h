@@ -1,5 +1,6 @@
 // qsvc_amd/csrc/qsvc_ctx.h -- the context behind the C ABI (internal).
 #pragma once
+#include <time.h>
 #define QSVC_ALLB_MAX 4096
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -108,6 +109,7 @@ struct qsvc_ctx {
   DevBuf halo_tx[2], halo_rx[2];  // boundary records: [0] left neighbour, [1] right neighbour
   DevBuf halo_btx[2], halo_brx[2];  // batched exchange (qsvc_halo_batch_*): n records back to back, owned by the batch's first context
   hipEvent_t halo_ev = nullptr;   // this context's record is packed / the batch's records have arrived
+  hipEvent_t sync_ev = nullptr;   // ctx_sync's marker
   uint8_t halo_tb[2][16];
   void* comm = nullptr;            // ncclComm_t (RCCL), line topology
   int rank = 0, nranks = 1;
@@ -131,6 +133,41 @@ struct qsvc_ctx {
   int fail(int code, const char* fmt, ...);
   int hipfail(hipError_t e, const char* what);
 };
+
+// CPU time of the calling thread spent in a scope, as a host segment (qsvc_get_timings; profiling on): tells waiting from working
+struct HostCpu {
+  qsvc_ctx* c; const char* name; timespec t0;
+  HostCpu(qsvc_ctx* c_, const char* n) : c(c_), name(n) { clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t0); }
+  ~HostCpu() {
+    timespec t1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1);
+    c->host_time(name, (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+  }
+};
+// Waiting for the device without burning a CPU.  The runtime's waits (hipStreamSynchronize, hipEventSynchronize) spin -- with
+// hipDeviceScheduleBlockingSync still for most of a wait of a few milliseconds (measured: 4.7 ms of CPU for 8 ms of waiting) -- and a
+// host that keeps a dozen sequences in flight per GPU, each with a session thread and Tier-2 workers that wait several times per step,
+// then spends its CPUs on waiting: bench.py host_cpu showed 15.7 of the box's 16-CPU quota busy and the container throttled.
+// tuning().sync_block (default): 100 us of spinning for the quick completions, then query + sleep in steps of 20 us (one to two hundred
+// microseconds more latency per step of 23 ms, a fraction of the CPU); 0: the runtime's own wait.
+inline hipError_t wait_event_sleeping(hipEvent_t ev) {
+  timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec) < 100000) continue;   // the first 100 us: spin
+    const timespec nap = {0, 20000};
+    nanosleep(&nap, nullptr);
+  }
+}
+inline hipError_t ctx_sync(qsvc_ctx* c) {
+  if (!c->tune.sync_block) return hipStreamSynchronize(c->st);
+  hipError_t e;
+  if (!c->sync_ev && (e = hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming)) != hipSuccess) return e;
+  if ((e = hipEventRecord(c->sync_ev, c->st)) != hipSuccess) return e;
+  if ((e = wait_event_sleeping(c->sync_ev)) != hipSuccess) return e;
+  return hipStreamSynchronize(c->st);   // (nothing left to wait for: lets the runtime retire the stream's finished commands)
+}
 
 // Take every pending I/B decision (one stream synchronisation); if a picture turns out 'I', redo what was computed from the
 // speculative 'B'.  Every entry point that reads or replaces level state calls this first; returns QSVC_OK or an error.

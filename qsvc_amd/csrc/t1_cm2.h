@@ -373,8 +373,10 @@ T1HD void cm2_win_at(Cm2Win& c, const uint32_t* sp, const uint32_t* cw, int cwst
 // Sparse bit-planes (most columns "plain"): the columns that are not plain are listed -- column, and where its decisions go in
 // each of the three streams -- and worked off 64 at a time, instead of every lane walking all of its 16 columns.
 struct Cm2Entry { uint16_t col, o0, o1, o2; };   // col = stripe * 64 + x; byte offsets into the three streams
-#define CM2_LIST_MAX 480
-#define CM2_LIST_AT 6144            // the list lives in the upper part of the (then small) stream buffer
+#ifndef CM2_LIST_MAX
+#define CM2_LIST_MAX 256
+#define CM2_LIST_AT 3840            // the list lives in the upper part of the (then small) stream buffer
+#endif
 // the centre column is four insignificant zeros without a significant neighbour: its only decision is RUN = 0 (clean-up pass)
 T1HD bool cm2_plain_run(const Cm2Win& c) {
   const uint32_t w = c.w;
