@@ -218,12 +218,16 @@ __device__ __forceinline__ void upd_border_body(const UpdArgs& a, const int k, c
 // whose counter image shows two sources on one target -- motion discontinuities -- replays that side block by block in the
 // reference's order (upd_side<true>).  The counters are bytes: the form is used while fewer than 256 blocks lie within reach of
 // a target (upd_scatter_applies); beyond that the gather above runs.
+#ifndef US_W
 #define US_W 128                      // luma tile: targets per row ...
 #define US_H 32                       // ... and rows
+#endif
+#define US_RX (US_W / 8)              // runs of 8 per tile row
+#define US_NK ((US_H * US_RX + 255) / 256)   // runs per thread
 #define US_STR (US_W + 16)            // bytes per image row: 8 guard bytes on either side
 #define UC_STR (PCT_FW + 16)          // the chroma tile's footprint likewise
 #define US_SMEM (4 * US_H * US_STR)   // luma: image + counters of both sides
-#define UC_SMEM (PCT_SP_BYTES + 2 * PCT_FH * UC_STR)   // chroma: the footprint + one side's image and counters (the row pass' low band reuses them)
+#define UC_SMEM (4 * PCT_FH * UC_STR)   // chroma: image + counters of both sides; the finished footprint and the row pass' low band then take their place
 #define UPD_SC_SMEM (US_SMEM > UC_SMEM ? US_SMEM : UC_SMEM)
 template <int STR>
 __device__ __forceinline__ void upd_scatter(const UpdSrc& s, int y0, int nrows, int x0, int ncols, int R, uint8_t* acc, uint8_t* cnt, int tid) {
@@ -325,9 +329,10 @@ __device__ __forceinline__ void upd_chroma_body(const UpdArgs& a, uint8_t* smem,
       }
       *(uint64_t*)&sP[ry][8 * run] = v;
     }
-  } else {  // scatter form: one side at a time through the image behind the footprint (a thread keeps its runs from phase to phase)
-    uint8_t* acc = smem + PCT_SP_BYTES;
-    uint8_t* cnt = acc + PCT_FH * UC_STR;
+  } else {  // scatter form: both sides' images first (they fill the tile's LDS), then the finished footprint in their place
+    static_assert(4 * PCT_FH * UC_STR >= PCT_SMEM_BYTES, "footprint + low band fit where the images were");
+    uint8_t* acc = smem;                       // [2][PCT_FH][UC_STR]
+    uint8_t* cnt = smem + 2 * PCT_FH * UC_STR;
     constexpr int NRUN = PCT_FH * (PCT_FW / 8), NIT = (NRUN + PCT_T - 1) / PCT_T;
     uint64_t v[NIT];
     ChromaLd ld[NIT];
@@ -336,26 +341,28 @@ __device__ __forceinline__ void upd_chroma_body(const UpdArgs& a, uint8_t* smem,
       const int k = tid + i * PCT_T, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8);
       ld[i] = chroma_run8_ld(u, g, yb + ry, xb + 8 * run);
     }
+    upd_zero(smem, UC_SMEM, tid);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (s[q].high) upd_scatter<UC_STR>(s[q], yb, PCT_FH, xb, PCT_FW, a.reach, acc + q * PCT_FH * UC_STR, cnt + q * PCT_FH * UC_STR, tid);
 #pragma unroll
     for (int i = 0; i < NIT; i++) {
       const int k = tid + i * PCT_T, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
       v[i] = (k < NRUN && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) ? chroma_run8_fin(ld[i], u, g, yy, xx) : 0ull;
     }
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      if (!s[q].high) continue;   // (uniform)
-      upd_zero(acc, 2 * PCT_FH * UC_STR, tid);
-      __syncthreads();
-      upd_scatter<UC_STR>(s[q], yb, PCT_FH, xb, PCT_FW, a.reach, acc, cnt, tid);
-      __syncthreads();
+    for (int i = 0; i < NIT; i++) {
+      const int k = tid + i * PCT_T, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
+      if (k < NRUN && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W) {
 #pragma unroll
-      for (int i = 0; i < NIT; i++) {
-        const int k = tid + i * PCT_T, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8), yy = yb + ry, xx = xb + 8 * run;
-        if (k < NRUN && (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W)
-          v[i] = upd_from_image<UC_STR>(s[q], acc, cnt, ry, run, yy, xx, a.reach, a.uf, v[i]);
+        for (int q = 0; q < 2; q++)
+          if (s[q].high)
+            v[i] = upd_from_image<UC_STR>(s[q], acc + q * PCT_FH * UC_STR, cnt + q * PCT_FH * UC_STR, ry, run, yy, xx, a.reach, a.uf, v[i]);
       }
-      __syncthreads();
     }
+    __syncthreads();   // every read of the images is done: the footprint takes their place
 #pragma unroll
     for (int i = 0; i < NIT; i++) {
       const int k = tid + i * PCT_T, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8);
@@ -404,11 +411,11 @@ __device__ __forceinline__ void upd_luma_tile(const UpdArgs& a, uint8_t* smem, c
   upd_sides(a, j, sd);
   const uint8_t* src = frame_y(a.frames, g, a.src_mul * j);
   uint8_t* dst = a.low + (size_t)(a.dst_mul * j) * g.F;
-  uint64_t v[2];
-  bool ok[2];
+  uint64_t v[US_NK];
+  bool ok[US_NK];
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int i = tid + 256 * k, row = i >> 4, run = i & 15;
+  for (int k = 0; k < US_NK; k++) {
+    const int i = tid + 256 * k, row = i / US_RX, run = i % US_RX;
     ok[k] = row < nrows && 8 * run < ncols;
     v[k] = ok[k] ? ld8(src + (size_t)(y0 + row) * g.W + x0 + 8 * run) : 0ull;
   }
@@ -421,22 +428,28 @@ __device__ __forceinline__ void upd_luma_tile(const UpdArgs& a, uint8_t* smem, c
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 2; q++)
+#ifndef UPD_EXP_NO_SCATTER
       if (s[q].high) upd_scatter<US_STR>(s[q], y0, nrows, x0, ncols, a.reach, acc + q * US_H * US_STR, cnt + q * US_H * US_STR, tid);
+#endif
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < US_NK; k++) {
       if (!ok[k]) continue;
-      const int i = tid + 256 * k, row = i >> 4, run = i & 15;
+      const int i = tid + 256 * k, row = i / US_RX, run = i % US_RX;
 #pragma unroll
       for (int q = 0; q < 2; q++)
+#ifndef UPD_EXP_NO_APPLY
         if (s[q].high)
+#else
+        if (s[q].high && a.reach > 1000)
+#endif
           v[k] = upd_from_image<US_STR>(s[q], acc + q * US_H * US_STR, cnt + q * US_H * US_STR, row, run, y0 + row, x0 + 8 * run, a.reach, a.uf, v[k]);
     }
   }
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < US_NK; k++) {
     if (!ok[k]) continue;
-    const int i = tid + 256 * k, ty = y0 + (i >> 4), tx0 = x0 + 8 * (i & 15);
+    const int i = tid + 256 * k, ty = y0 + i / US_RX, tx0 = x0 + 8 * (i % US_RX);
     uint8_t* d = dst + (size_t)ty * g.W + tx0;
     const bool edge = any && (ty == 0 || ty == g.H - 1 || tx0 == 0 || tx0 + 8 == g.W);   // border cells belong to the border role
     if (!edge) *(uint2*)d = make_uint2((uint32_t)v[k], (uint32_t)(v[k] >> 32));
@@ -505,11 +518,17 @@ __global__ void __launch_bounds__(256) k_upd_level_sc(UpdArgs a, int ncxa, int n
   const int np = a.g.nB + 1;
   int b = blockIdx.x;
   const int nchroma = ncxa * ncya * np * 2, nluma = nlx * nly * np;
+#ifdef UPD_EXP_NO_CHROMA
+  if (b < nchroma) return;
+#endif
   if (b < nchroma) { upd_chroma_body<0, true>(a, smem, b % ncxa, (b / ncxa) % ncya, b / (ncxa * ncya), threadIdx.x); return; }
   b -= nchroma;
   if (b < nluma) { upd_luma_tile(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x); return; }
   b -= nluma;
   const int nbb = (2 * a.g.W + 2 * (a.g.H - 2) + 255) / 256;
+#ifdef UPD_EXP_NO_BORDER
+  if (b < nbb * np) return;
+#endif
   if (b < nbb * np) { upd_border_body(a, (b % nbb) * 256 + threadIdx.x, b / nbb); return; }
   b -= nbb * np;
   const int ncopy = cg.nWA + cg.nWB;
