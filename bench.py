@@ -37,6 +37,7 @@ CONFIGS = {
     4: dict(W=3840, H=2160, TRLS=5, GOPS=2, BS=16, S0=4, SRLS=6, G=32, reversible=0, sessions=4, pmc="r04_cfg4_pmc_hbm.json", name="4K"),
 }
 W, H, TRLS, GOPS, BS, S0, SRLS = 1920, 1080, 4, 2, 8, 4, 5   # overwritten from CONFIGS[--config] in main()
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 2   # wave64 instructions/s: 1024 SIMD-32 units, 2 cycles each (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_FILE = "r04_pmc_hbm.json"  # tools/refresh_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, one sequence in flight
 
@@ -653,6 +654,28 @@ def main():
                         tot += e["fetch_bytes_per_launch_raw"] * e["launches_profiled"] / max(e.get("encodes_profiled", 5), 1)
             return int(tot) if seen else None
 
+        sq = {}
+        try:  # SQ counters of the same kernels (tools/refresh_profiles.sh: three --pmc passes, one sequence in flight)
+            sq = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE.replace("pmc_hbm", "pmc_sq"))))
+        except Exception:
+            pass
+
+        def valu_of(prefixes, iso_ms):
+            """Vector-ALU accounting of a kernel group: wave-instructions per step (SQ_INSTS_VALU x launches / encodes profiled), the time
+            they take at the chip's vector issue peak (1024 SIMD-32 units x 2.4 GHz / 2 cycles per wave64 instruction = 1.2288e12
+            wave-instructions/s, MI355X_MICROARCH.md) and their share of the group's isolated duration.  The MCTF and DWT kernels work on
+            bytes and 16-bit pairs: the useful rate is lane-operations per byte, not bytes per second."""
+            tot, seen = 0.0, False
+            for kn, e in sq.items():
+                if isinstance(e, dict) and any(kn.startswith(px) for px in prefixes) and "SQ_INSTS_VALU" in e:
+                    seen = True
+                    tot += e["SQ_INSTS_VALU"] * e.get("launches", 0) / max(e.get("encodes_profiled", 5), 1)
+            if not seen:
+                return None
+            floor_ms = tot / VALU_PEAK_WAVE_INSTS * 1e3
+            return {"wave_insts_per_step": int(tot), "floor_ms_at_issue_peak": round(floor_ms, 4),
+                    "frac_of_issue_peak": round(floor_ms / iso_ms, 4) if iso_ms and iso_ms > 0 else None}
+
         dom = "j2k_t1_mq"
         a = alg[dom] / (per[dom]["ms_per_step"] * 1e-3) / 1e9 if dom in per and per[dom]["ms_per_step"] > 0 else 0.0
         mq_traffic = traffic_of([mq_symbol]) or traffic_of(["k_t1_mq_pipe<64, 4, 196, 144>"])
@@ -686,10 +709,17 @@ def main():
                 g = alg[k] / (iso[k][0] * 1e-3) / 1e9
                 streaming[k] = {"ms_per_step_isolated": round(iso[k][0], 4), "launch_groups_per_step": iso[k][1],
                                 "algorithmic_bytes_per_step": int(alg[k]), "achieved_GBs": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4),
-                                "traffic": traffic_of(prefixes)}
+                                "traffic": traffic_of(prefixes), "valu": valu_of(prefixes, iso[k][0])}
+            for k, prefixes in (("j2k_t1_cm", ["k_t1_cm2"]), ("j2k_t1_mq", ["k_t1_mq"])):   # Tier-1: not streaming kernels, their vector work beside the others'
+                if k in iso and iso[k][0] > 0:
+                    streaming[k] = {"ms_per_step_isolated": round(iso[k][0], 4), "valu": valu_of(prefixes, iso[k][0])}
             streaming["note"] = ("isolated = one sequence in flight, HIP events on the context's stream around each kernel group; traffic = HBM bytes "
                                  "per step from profiles/" + PMC_FILE + " (FETCH_SIZE + WRITE_SIZE, raw: 1/4/8-byte accesses; null = not in that file); ME is ALU-bound "
-                                 "by design (SURVEY.md 8d), its fraction is quoted for completeness")
+                                 "by design (SURVEY.md 8d), its fraction is quoted for completeness; valu = SQ_INSTS_VALU of the same kernels from profiles/"
+                                 + PMC_FILE.replace("pmc_hbm", "pmc_sq") + " against the vector issue peak (1.2288e12 wave-instructions/s): these kernels compute on "
+                                 "bytes and 16-bit pairs, 9-30 lane-operations per algorithmic byte, so the vector units and the latency of their dependent "
+                                 "phases bound them well before HBM does (DESIGN.md 4, Round 4)")
+
         t1ms = sum(per.get(k, {}).get("ms_per_step", 0) for k in ("j2k_t1_cm", "j2k_t1_mq"))
         line = {
             "metric": f"{cfg['name']} encode fps (MCTF + {'5/3' if args.reversible else '9/7'} DWT + EBCOT)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,

@@ -13,6 +13,7 @@
 #include <exception>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -237,7 +238,6 @@ __constant__ uint32_t c_dmq[47] = T1_MQ_TABLE_INIT;  // qe | nmps << 16 | nlps <
 // The magnitude bits still go to the coefficient plane as OR-atomics that return nothing (bit 31 = the sign); k_dec_dequant turns
 // the words into coefficients.  The per-sample "last coded plane" bytes are only written for blocks whose passes were truncated
 // (quality layers left out): a fully decoded block has none.  The wave's other 63 lanes build the tables and clear the flag words.
-#define DEC_LANES 1
 #define DEC_FW_WORDS (18 * 66)     // flag words: stripes -1 .. 16, columns -1 .. 64
 #define DFW(s, x) fw[((s) + 1) * 66 + (x) + 1]
 #define DF_SIGALL 0x3FFFFu
@@ -323,31 +323,37 @@ __device__ __forceinline__ int d_zc_of(int n9, int orient) {
   if (v == 1) return 3;
   return d >= 2 ? 2 : (d == 1 ? 1 : 0);
 }
+// NB code-blocks per wave, one decoding lane each (lanes lane0 .. lane0 + NB - 1): the lanes run the same loops -- bit-plane, pass,
+// stripe, column, row -- in step, every lane on its own block's flag words and MQ state, so a decision of one lane costs the wave
+// the same instructions as a decision of all NB.  With one block per wave the kernel was bound by instruction issue (32 waves per
+// CU, each issuing for one lane of 64).
+template <int NB>
 __global__ void __launch_bounds__(64) k_t1_decode_lds(const DecCb* cbs, int ncb, const uint8_t* segs, uint8_t* lastp_all, void* coefv, int lane0, int nlanes) {
-  __shared__ uint32_t s_fw[DEC_FW_WORDS];
+  __shared__ uint32_t s_fw[NB * DEC_FW_WORDS];
   __shared__ uint32_t s_tbl[48];
-  __shared__ uint32_t s_cw[20];
-  __shared__ uint8_t s_zc[512];
-  const int b = blockIdx.x;
-  if (b >= ncb) return;
-  const DecCb cb = cbs[b];
-  {  // the whole wave: tables and a clean flag plane
+  __shared__ uint32_t s_cw[NB * 20];
+  __shared__ uint8_t s_zc3[3 * 512];   // zero coding by neighbourhood: orientation classes LL / LH, HL, HH
+  {  // the whole wave: tables and clean flag planes
     const int t = threadIdx.x;
-    for (int k = t; k < DEC_FW_WORDS; k += 64) s_fw[k] = 0;
+    for (int k = t; k < NB * DEC_FW_WORDS; k += 64) s_fw[k] = 0;
     if (t < 47) s_tbl[t] = c_dmq[t];
-    for (int k = t; k < 512; k += 64) s_zc[k] = (uint8_t)d_zc_of(k, cb.orient);
+    for (int k = t; k < 3 * 512; k += 64) s_zc3[k] = (uint8_t)d_zc_of(k & 511, k < 512 ? 0 : (k < 1024 ? 1 : 3));
   }
   __syncthreads();
-  // lane lane0 decodes (passed as an argument: with the lane index a compile-time constant the ROCm 7.2 build scalarised the whole
-  // kernel and decoded garbage)
-  if ((int)threadIdx.x != lane0 || nlanes < 1) return;
-  uint32_t* fw = s_fw;
+  // lanes lane0 .. decode (lane0 is passed as an argument: with the lane index a compile-time constant the ROCm 7.2 build scalarised
+  // the whole kernel and decoded garbage)
+  const int li = (int)threadIdx.x - lane0;
+  const int b = blockIdx.x * NB + li;
+  if (li < 0 || li >= nlanes || b >= ncb) return;
+  const DecCb cb = cbs[b];
+  uint32_t* fw = s_fw + li * DEC_FW_WORDS;
+  const uint8_t* s_zc = s_zc3 + 512 * (cb.orient == 1 ? 1 : (cb.orient == 3 ? 2 : 0));
   uint8_t* lastp = lastp_all + (size_t)b * 64 * 64;
   int32_t* mag = (int32_t*)coefv + cb.plane_off + (size_t)cb.y0 * cb.W + cb.x0;  // row stride cb.W
   const int w = cb.w, h = cb.h, W = cb.W, nstr = (h + 3) >> 2;
   const bool full = cb.npasses >= 3 * cb.nbps - 2;   // every pass present: every sample's last coded plane is 0
   MqDec2 m;
-  m.init(segs + cb.seg, cb.len, s_cw, s_tbl);
+  m.init(segs + cb.seg, cb.len, s_cw + li * 20, s_tbl);
   int np = 0;
 #define MAG_OR(y, x, bits) atomicOr((unsigned*)&mag[(size_t)(y) * W + (x)], (unsigned)(bits))   /* no value comes back: never waited for */
   // sample (stripe s, column x, row k) becomes significant with sign neg: every word whose neighbourhood holds it (t1_set_sig of
@@ -554,6 +560,27 @@ __global__ void __launch_bounds__(256) k_dec_finish(const DecPlane* planes, cons
 
 struct J2kDecState {
   DevBuf cbs_d, segs_d, flags_d, lastp_d, coefA, coefB, planes_d, out_d;
+  // page-locked staging of the merged tables (grow-only): the streams' segments and block records are put together by the parser's
+  // threads straight into these and go up by DMA (round 4: a serial merge into pageable vectors was 10 ms of a 55 ms decode)
+  uint8_t* segs_h = nullptr; size_t segs_h_cap = 0;
+  DecCb* cbs_h = nullptr; size_t cbs_h_cap = 0;
+  bool pin(size_t seg_bytes, size_t nblocks) {
+    if (seg_bytes > segs_h_cap) {
+      if (segs_h) (void)hipHostFree(segs_h);
+      segs_h = nullptr; segs_h_cap = 0;
+      const size_t want = seg_bytes + seg_bytes / 4 + 4096;
+      if (hipHostMalloc((void**)&segs_h, want, hipHostMallocDefault) != hipSuccess) return false;
+      segs_h_cap = want;
+    }
+    if (nblocks > cbs_h_cap) {
+      if (cbs_h) (void)hipHostFree(cbs_h);
+      cbs_h = nullptr; cbs_h_cap = 0;
+      const size_t want = nblocks + nblocks / 4 + 64;
+      if (hipHostMalloc((void**)&cbs_h, want * sizeof(DecCb), hipHostMallocDefault) != hipSuccess) return false;
+      cbs_h_cap = want;
+    }
+    return true;
+  }
 };
 
 // dev_dst != nullptr: the planes go straight to device memory at dev_dst + dev_offs[i] (qsvc_j2k_decode_frames), geometry checked
@@ -561,17 +588,17 @@ struct J2kDecState {
 static int decode_impl(qsvc_ctx* c, int nstreams, const uint8_t* const* streams, const size_t* lens, int max_layers, void* out, size_t cap,
                        size_t* offs, int* widths, int* heights, uint8_t* dev_dst, const size_t* dev_offs, int fw, int fh) {
   (void)hipSetDevice(c->dev);
+  TuningScope tscope(&c->tune);
   if (!c->j2kdec) c->j2kdec = new J2kDecState();
   J2kDecState& S = *c->j2kdec;
   std::vector<DecPlane> planes(nstreams);
-  std::vector<DecCb> cbs;
-  std::vector<uint8_t> segs;
   size_t total = 0, out_total = 0;
   int maxW = 0, maxH = 0, maxL = 0;
   // Tier-2 parsing: the streams are independent -- each into its own tables on a few host threads, then merged in stream order
   struct Parsed { std::vector<DecCb> cbs; std::vector<uint8_t> segs; const char* err = nullptr; bool nomem = false; };
   std::vector<Parsed> parsed(nstreams);
   for (int i = 0; i < nstreams; i++) if (!streams[i]) return c->fail(QSVC_ERR_INVALID, "code-stream %d is null", i);
+  const auto tp0 = std::chrono::steady_clock::now();
   {
     const int nthr = std::max(1, std::min({nstreams, 8, c->t2_threads > 0 ? c->t2_threads : 8}));
     std::atomic<int> next{0};
@@ -590,17 +617,16 @@ static int decode_impl(qsvc_ctx* c, int nstreams, const uint8_t* const* streams,
     work();
     for (auto& t : th) t.join();
   }
+  const auto tp1 = std::chrono::steady_clock::now();
+  c->host_time("host_dec_parse", std::chrono::duration<double, std::milli>(tp1 - tp0).count());
+  std::vector<size_t> seg_base(nstreams), cb_base(nstreams);
+  size_t seg_total = 0, cb_total = 0;
   for (int i = 0; i < nstreams; i++) {
     planes[i].off = total; planes[i].out_off = out_total;
     if (parsed[i].nomem) return c->fail(QSVC_ERR_NOMEM, "code-stream %d: out of host memory while parsing", i);
     if (parsed[i].err) return c->fail(QSVC_ERR_UNSUPPORTED, "code-stream %d: %s", i, parsed[i].err);
-    try {
-      const unsigned long long sbase = segs.size();
-      for (DecCb d : parsed[i].cbs) { d.seg += sbase; d.plane_off = total; cbs.push_back(d); }
-      segs.insert(segs.end(), parsed[i].segs.begin(), parsed[i].segs.end());
-    } catch (const std::exception&) {
-      return c->fail(QSVC_ERR_NOMEM, "code-stream %d: out of host memory while parsing", i);
-    }
+    seg_base[i] = seg_total; cb_base[i] = cb_total;
+    seg_total += parsed[i].segs.size(); cb_total += parsed[i].cbs.size();
     if (planes[i].rev != planes[0].rev) return c->fail(QSVC_ERR_UNSUPPORTED, "the streams of one call must share the transform");
     total += (size_t)planes[i].W * planes[i].H;
     offs[i] = out_total;
@@ -619,8 +645,36 @@ static int decode_impl(qsvc_ctx* c, int nstreams, const uint8_t* const* streams,
       planes[i].out_off = dev_offs[i];
     }
   } else if (out_total > cap) return c->fail(QSVC_ERR_NOMEM, "output buffer too small (%zu bytes needed, %zu given)", out_total, cap);
-  const int ncb = (int)cbs.size();
+  if (cb_total > 0x7fffffff) return c->fail(QSVC_ERR_UNSUPPORTED, "too many code-blocks in one call");
+  const int ncb = (int)cb_total;
+  if (!S.pin(seg_total + 16, cb_total + 1)) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables of the decoder)");
+  {  // the streams' tables into the merged ones, by the same few threads; then the blocks in the order the kernel takes them
+    std::vector<DecCb> tmp;
+    try { tmp.resize(cb_total); } catch (const std::exception&) { return c->fail(QSVC_ERR_NOMEM, "out of host memory while parsing"); }
+    const int nthr = std::max(1, std::min({nstreams, 8, c->t2_threads > 0 ? c->t2_threads : 8}));
+    std::atomic<int> next{0};
+    auto work = [&]() {
+      for (int i; (i = next.fetch_add(1)) < nstreams;) {
+        if (!parsed[i].segs.empty()) memcpy(S.segs_h + seg_base[i], parsed[i].segs.data(), parsed[i].segs.size());
+        DecCb* o = tmp.data() + cb_base[i];
+        for (const DecCb& d0 : parsed[i].cbs) { DecCb d = d0; d.seg += seg_base[i]; d.plane_off = planes[i].off; *o++ = d; }
+      }
+    };
+    std::vector<std::thread> th;
+    try {
+      for (int k = 1; k < nthr; k++) th.emplace_back(work);
+    } catch (const std::exception&) {}
+    work();
+    for (auto& t : th) t.join();
+    // (the lanes of a wave decode neighbouring entries and the grid is taken in order: the longest blocks first)
+    std::vector<uint32_t> ord(cb_total);
+    for (size_t k = 0; k < cb_total; k++) ord[k] = (uint32_t)k;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return tmp[a].len > tmp[b].len; });
+    for (size_t k = 0; k < cb_total; k++) S.cbs_h[k] = tmp[ord[k]];
+  }
   const bool rev = planes[0].rev != 0;
+  c->host_time("host_dec_merge", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp1).count());
+  const auto tp2 = std::chrono::steady_clock::now();
   int r;
   if ((r = S.coefA.ensure(c, total * 4))) return r;
   if ((r = S.coefB.ensure(c, total * 4))) return r;
@@ -631,14 +685,19 @@ static int decode_impl(qsvc_ctx* c, int nstreams, const uint8_t* const* streams,
   Prof pf;
   if (ncb) {
     if ((r = S.cbs_d.ensure(c, (size_t)ncb * sizeof(DecCb)))) return r;
-    if ((r = S.segs_d.ensure(c, segs.size() + 16))) return r;
+    if ((r = S.segs_d.ensure(c, seg_total + 16))) return r;
     if ((r = S.lastp_d.ensure(c, (size_t)ncb * 64 * 64))) return r;
-    HIPCHK(c, hipMemcpyAsync(S.cbs_d.p, cbs.data(), (size_t)ncb * sizeof(DecCb), hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipMemcpyAsync(S.segs_d.p, segs.data(), segs.size(), hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(S.cbs_d.p, S.cbs_h, (size_t)ncb * sizeof(DecCb), hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(S.segs_d.p, S.segs_h, seg_total, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemsetAsync(S.lastp_d.p, 0, (size_t)ncb * 64 * 64, c->st));
     pf.begin(c, "j2k_t1_decode");
-    hipLaunchKernelGGL(k_t1_decode_lds, dim3((ncb + DEC_LANES - 1) / DEC_LANES), dim3(64), 0, c->st, (const DecCb*)S.cbs_d.p, ncb,
-                       (const uint8_t*)S.segs_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p, 0, DEC_LANES);
+    {
+      const int nb = tuning().dec_lanes;   // code-blocks per wave
+      const dim3 grid((ncb + nb - 1) / nb), block(64);
+#define DEC_LAUNCH(NB) hipLaunchKernelGGL(k_t1_decode_lds<NB>, grid, block, 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.segs_d.p, (uint8_t*)S.lastp_d.p, S.coefA.p, 0, NB)
+      if (nb == 1) DEC_LAUNCH(1); else if (nb == 2) DEC_LAUNCH(2); else if (nb == 4) DEC_LAUNCH(4); else if (nb == 6) DEC_LAUNCH(6); else DEC_LAUNCH(8);
+#undef DEC_LAUNCH
+    }
     hipLaunchKernelGGL(k_dec_dequant, dim3(ncb), dim3(256), 0, c->st, (const DecCb*)S.cbs_d.p, ncb, (const uint8_t*)S.lastp_d.p, S.coefA.p);
     pf.end(c);
   }
@@ -662,8 +721,10 @@ static int decode_impl(qsvc_ctx* c, int nstreams, const uint8_t* const* streams,
                      S.coefA.p, dev_dst ? dev_dst : (uint8_t*)S.out_d.p);
   pf.end(c);
   if (!dev_dst) HIPCHK(c, hipMemcpyAsync(out, S.out_d.p, out_total, hipMemcpyDeviceToHost, c->st));
+  c->host_time("host_dec_queue", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp2).count());
   HIPCHK(c, ctx_sync(c));  // (the parsed tables are local: the kernels must be through with them)
   HIPCHK(c, hipGetLastError());
+  c->host_time("host_dec_total", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
   return QSVC_OK;
 }
 
@@ -685,6 +746,8 @@ void j2k_decode_release(qsvc_ctx* c) {
   if (!s) return;
   DevBuf* all[] = {&s->cbs_d, &s->segs_d, &s->flags_d, &s->lastp_d, &s->coefA, &s->coefB, &s->planes_d, &s->out_d};
   for (auto* b : all) b->release();
+  if (s->segs_h) (void)hipHostFree(s->segs_h);
+  if (s->cbs_h) (void)hipHostFree(s->cbs_h);
   delete s;
   c->j2kdec = nullptr;
 }

@@ -755,7 +755,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
       cm2_win_push(c, s_sp, 0, s_cw[ls][lx0], s_cw[ls + 1][lx0], s_cw[ls + 2][lx0]);
       uint32_t own = s_cw[ls + 1][lx0 + 1];
       cm2_win_push(c, s_sp, 0, s_cw[ls][lx0 + 1], own, s_cw[ls + 2][lx0 + 1]);
-#pragma unroll
+#ifndef CM2_DENSE_UNROLL
+#define CM2_DENSE_UNROLL 16
+#endif
+#pragma unroll CM2_DENSE_UNROLL
       for (int j = 0; j < 16; j++) {
         const uint32_t nm = s_cw[ls + 1][lx0 + j + 2];
         cm2_win_push(c, s_sp, own, s_cw[ls][lx0 + j + 2], nm, s_cw[ls + 2][lx0 + j + 2]);

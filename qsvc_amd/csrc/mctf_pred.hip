@@ -100,36 +100,67 @@ __device__ __forceinline__ void pred_chroma_body(const PredArgs& a, uint8_t* sme
   const int lbs = 31 - __builtin_clz(g.bs);
   const uint8_t* u0 = frame_c(a.frames, g, 2 * i, c);
   const uint8_t* u1 = frame_c(a.frames, g, 2 * i + 2, c);
-  // A. full-resolution prediction of the footprint, one run per task; a thread's (up to three) tasks have their requests in
-  // flight together: vectors, then the two stored rows of both references, then the arithmetic
-  constexpr int NT = (PCT_FH * (PCT_FW / 8) + PCT_T - 1) / PCT_T;
-  int ty_[NT], tx_[NT], mv4[NT][4];
-  bool in_[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++) {
-    const int k = tid + PCT_T * t, ry = k / (PCT_FW / 8), run = k % (PCT_FW / 8);
-    ty_[t] = yb + ry; tx_[t] = xb + 8 * run;
-    in_[t] = k < PCT_FH * (PCT_FW / 8) && (unsigned)ty_[t] < (unsigned)g.H && (unsigned)tx_[t] < (unsigned)g.W;
-    const int16_t* m = a.mv + (size_t)i * 4 * fld + (in_[t] ? (size_t)(ty_[t] >> lbs) * g.BX + (tx_[t] >> lbs) : (size_t)0);
-    mv4[t][0] = m[0]; mv4[t][1] = m[fld]; mv4[t][2] = m[2 * fld]; mv4[t][3] = m[3 * fld];
+  // (the odd picture's samples of phase C: requested now, needed after three barriers)
+  uint32_t o_c = 0;
+  {
+    const int jr = tid / (PCT_W / 4), gq = tid % (PCT_W / 4), cj = j0 + jr, ci = i0 + 4 * gq;
+    if (tid < PCT_H * (PCT_W / 4) && cj < chh && ci < cw) o_c = *(const uint32_t*)(frame_c(a.frames, g, 2 * i + 1, c) + (size_t)cj * cw + ci);
   }
-  ChromaLd c0[NT], c1[NT];
+  // A. full-resolution prediction of the footprint.  A task = one run of 8 columns x FOUR rows of one MC block (rows 4 m .. 4 m + 3 of
+  // the picture: a multiple of 4 rows lies inside one block for every block size on this path), so the vectors, the address
+  // arithmetic and the in-picture tests are paid once per four runs (round 4: they were two thirds of the per-run form's
+  // instructions).  Four displaced full-resolution rows read three stored rows R0..R2 of each reference: with Y the first
+  // displaced row, the rows are [R0, (R0+R1)>>1, R1, (R1+R2)>>1] for even Y and [(R0+R1)>>1, R1, (R1+R2)>>1, R2] for odd Y
+  // (decorrelate.cpp:610-648, columns first: the vertical mean is taken on stored samples, the horizontal one on the result).
+  {
+    static_assert((2 * PCT_H) % 4 == 0, "the footprint starts two rows above a multiple of 4");
+    constexpr int NG = (PCT_FH + 2 + 3) / 4;            // groups of 4 picture rows the footprint's rows yb .. yb + PCT_FH - 1 touch (yb = 4 m - 2)
+    static_assert(NG * (PCT_FW / 8) <= PCT_T, "one task per thread");
+    const int gi = tid / (PCT_FW / 8), run = tid % (PCT_FW / 8);
+    const int y4 = yb - 2 + 4 * gi, xx = xb + 8 * run;   // the group's first picture row (yb - 2 is a multiple of 4)
+    if (gi < NG) {
+      const bool in_pic = (unsigned)y4 < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;   // H % 4 == 0 is not given: rows are tested again below
+      uint64_t p[4] = {0, 0, 0, 0};
+      if (in_pic) {
+        const int16_t* m = a.mv + (size_t)i * 4 * fld + (size_t)(y4 >> lbs) * g.BX + (xx >> lbs);
+        const int mvx0 = m[0], mvy0 = m[fld], mvx1 = m[2 * fld], mvy1 = m[3 * fld];
+        const int Y0 = y4 + mvy0, X0 = xx + mvx0, Y1 = y4 + mvy1, X1 = xx + mvx1;
+        const bool fast = Y0 >= 0 && Y0 + 3 < g.H && X0 >= 0 && X0 + 8 < g.W && Y1 >= 0 && Y1 + 3 < g.H && X1 >= 0 && X1 + 8 < g.W && y4 + 3 < g.H;
+        if (fast) {
+          auto rows3 = [&](const uint8_t* u, int Y, int X, uint64_t R[3]) {
+            const int ja = Y >> 1, k0 = X >> 1;
+            const uint8_t* b = u + (size_t)ja * cw + k0;
+            R[0] = ld8(b); R[1] = ld8(b + (size_t)(imin(ja + 1, chh - 1) - ja) * cw); R[2] = ld8(b + (size_t)(imin(ja + 2, chh - 1) - ja) * cw);
+          };
+          uint64_t A[3], B[3];
+          rows3(u0, Y0, X0, A); rows3(u1, Y1, X1, B);
+          auto four = [&](const uint64_t R[3], int Y, int X, uint64_t out[4]) {
+            const uint64_t M01 = avg8(R[0], R[1]), M12 = avg8(R[1], R[2]);
+            const bool oy = Y & 1, ox = X & 1;
+            const uint64_t c[4] = {oy ? M01 : R[0], oy ? R[1] : M01, oy ? M12 : R[1], oy ? R[2] : M12};
 #pragma unroll
-  for (int t = 0; t < NT; t++) {
-    c0[t] = chroma_run8_ld(u0, g, ty_[t] + mv4[t][1], tx_[t] + mv4[t][0]);
-    c1[t] = chroma_run8_ld(u1, g, ty_[t] + mv4[t][3], tx_[t] + mv4[t][2]);
-  }
+            for (int r = 0; r < 4; r++) {
+              const uint32_t c0 = (uint32_t)c[r], c1 = (uint32_t)(c[r] >> 32);
+              const uint32_t cs = __builtin_amdgcn_alignbyte(c1, c0, 1), mm = avg4(c0, cs);
+              const uint32_t Aw = ox ? mm : c0, Bw = ox ? cs : mm;
+              out[r] = (uint64_t)__builtin_amdgcn_perm(Bw, Aw, 0x05010400u) | ((uint64_t)__builtin_amdgcn_perm(Bw, Aw, 0x07030602u) << 32);
+            }
+          };
+          uint64_t pa[4], pb[4];
+          four(A, Y0, X0, pa); four(B, Y1, X1, pb);
 #pragma unroll
-  for (int t = 0; t < NT; t++) {
-    const int k = tid + PCT_T * t;
-    if (k >= PCT_FH * (PCT_FW / 8)) break;
-    uint64_t p = 0;
-    if (in_[t]) {
-      const uint64_t p0 = chroma_run8_fin(c0[t], u0, g, ty_[t] + mv4[t][1], tx_[t] + mv4[t][0]);
-      const uint64_t p1 = chroma_run8_fin(c1[t], u1, g, ty_[t] + mv4[t][3], tx_[t] + mv4[t][2]);
-      p = avg8(p0, p1);
+          for (int r = 0; r < 4; r++) p[r] = avg8(pa[r], pb[r]);
+        } else {
+          for (int r = 0; r < 4; r++)
+            if (y4 + r < g.H) p[r] = avg8(chroma_run8(u0, g, y4 + r + mvy0, X0), chroma_run8(u1, g, y4 + r + mvy1, X1));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ry = y4 + r - yb;
+        if ((unsigned)ry < (unsigned)PCT_FH) *(uint64_t*)&sP[ry][8 * run] = (y4 + r < g.H) ? p[r] : 0ull;
+      }
     }
-    *(uint64_t*)&sP[k / (PCT_FW / 8)][8 * (k % (PCT_FW / 8))] = p;
   }
   __syncthreads();
   chroma_tile_lows(sP, sL, g, i0, xb, yb, tid);
@@ -141,7 +172,7 @@ __device__ __forceinline__ void pred_chroma_body(const PredArgs& a, uint8_t* sme
       chroma_tile_ll(sL, jr, gq, ll);
       const size_t coff = (size_t)g.W * g.H + (size_t)(c - 1) * cw * chh + (size_t)cj * cw + ci;
       const size_t off = (size_t)i * g.F + coff;
-      const uint32_t o = *(const uint32_t*)(frame_c(a.frames, g, 2 * i + 1, c) + (size_t)cj * cw + ci);
+      const uint32_t o = o_c;
       const uint32_t C = 0x00800080u;
       const uint32_t t01 = pk_clamp255(pk_sub(__builtin_amdgcn_perm(0u, o, 0x0c010c00u) + C, ll[0]));
       const uint32_t t23 = pk_clamp255(pk_sub(__builtin_amdgcn_perm(0u, o, 0x0c030c02u) + C, ll[1]));
@@ -163,8 +194,14 @@ __global__ void __launch_bounds__(256) k_pred_level(PredArgs a, int ncx, int ncy
   static_assert(sizeof(smem) >= PCT_SMEM_BYTES, "chroma tile fits");
   int b = blockIdx.x;
   const int nchroma = ncx * ncy * a.g.nB * 2, nluma = nlx * nly * a.g.nB;
+#ifdef PRED_EXP_NO_CHROMA
+  if (b < nchroma) return;
+#endif
   if (b < nchroma) { pred_chroma_body(a, smem, b % ncx, (b / ncx) % ncy, b / (ncx * ncy), threadIdx.x); return; }
   b -= nchroma;
+#ifdef PRED_EXP_NO_LUMA
+  if (b < nluma) return;
+#endif
   if (b < nluma) { pred_luma_body(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x & 63, threadIdx.x >> 6); return; }
   b -= nluma;
   // last role: the histogram of the motion components + 128 (decorrelate.cpp:805-812), nmh workgroups per picture, which also

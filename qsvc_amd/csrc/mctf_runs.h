@@ -91,7 +91,9 @@ __device__ __forceinline__ uint32_t residue4(uint32_t o, uint32_t p) {
 // ---------------------------------------------------------------------------------------------
 // chroma tile: a workgroup of PCT_T threads produces 64 x 14 half-resolution samples out of their full-resolution footprint
 #define PCT_W 64                      // outputs per tile row
+#ifndef PCT_H
 #define PCT_H 14                      // output rows per tile
+#endif
 #define PCT_FH (2 * PCT_H + 3)        // full-resolution rows 2 j0 - 2 .. 2 j0 + 2 PCT_H
 #define PCT_FW (2 * PCT_W + 16)       // full-resolution columns 2 i0 - 8 .. 2 i0 + 2 PCT_W + 7, in runs of 8
 #define PCT_SP_BYTES (((PCT_FH * PCT_FW) + 15) & ~15)          // the footprint (bytes) ...

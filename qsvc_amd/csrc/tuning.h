@@ -22,6 +22,7 @@ struct Tuning {
   int upd_scatter = 1;    // QSVC_UPD_SCATTER=0 the ordered gather by runs instead of the scatter tiles
   int dwt_pk = 1;         // QSVC_DWT_PK=0     the general DWT tile kernel for 5/3 too
   int defer_ib = 1;       // QSVC_DEFER_IB=0   the I/B decision of every level taken at once (one host round trip per level)
+  int dec_lanes = 1;      // QSVC_DEC_LANES     1, 2, 4, 6, 8 code-blocks per wave of the Tier-1 decoder
   int sync_block = 1;     // QSVC_SYNC_BLOCK=0 the runtime's own (spinning) waits instead of query + sleep (qsvc_ctx.h ctx_sync)
   static Tuning from_env() {
     Tuning t;
@@ -39,17 +40,19 @@ struct Tuning {
     if ((e = getenv("QSVC_UPD_SCATTER"))) t.upd_scatter = e[0] != '0';
     if ((e = getenv("QSVC_DWT_PK"))) t.dwt_pk = e[0] != '0';
     if ((e = getenv("QSVC_DEFER_IB"))) t.defer_ib = e[0] != '0';
+    if ((e = getenv("QSVC_DEC_LANES"))) { const int v = atoi(e); t.dec_lanes = (v == 2 || v == 4 || v == 6 || v == 8) ? v : 1; }
     if ((e = getenv("QSVC_SYNC_BLOCK"))) t.sync_block = e[0] != '0';
     return t;
   }
   bool set(const char* name, int v) {
     struct { const char* n; int* p; } tab[] = {{"mq_pipe", &mq_pipe}, {"mq_lds_small", &mq_lds_small}, {"mq_lanes", &mq_lanes}, {"mq_sort", &mq_sort},
                                                {"t1_parts", &t1_parts}, {"t1_devlist", &t1_devlist}, {"pyr_tile", &pyr_tile}, {"me_piece", &me_piece},
-                                               {"pred_run", &pred_run}, {"upd_run", &upd_run}, {"upd_scatter", &upd_scatter}, {"dwt_pk", &dwt_pk}, {"defer_ib", &defer_ib}, {"sync_block", &sync_block}};
+                                               {"pred_run", &pred_run}, {"upd_run", &upd_run}, {"upd_scatter", &upd_scatter}, {"dwt_pk", &dwt_pk}, {"defer_ib", &defer_ib}, {"sync_block", &sync_block}, {"dec_lanes", &dec_lanes}};
     for (auto& t : tab)
       if (!strcmp(t.n, name)) {
         if (t.p == &mq_lanes && !(v == 4 || v == 8 || v == 16 || v == 32 || v == 64)) return false;
         if (t.p == &t1_parts && (v < 1 || v > 4)) return false;
+        if (t.p == &dec_lanes && !(v == 1 || v == 2 || v == 4 || v == 6 || v == 8)) return false;
         *t.p = v;
         return true;
       }

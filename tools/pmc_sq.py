@@ -11,6 +11,7 @@ for path in sys.argv[2:]:
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 for k, d in out.items():
     d["launches"] = len(next(iter(acc[k].values())))
+    d["encodes_profiled"] = 5   # tools/refresh_profiles.sh / sq_pass.sh: 1 warm-up + 4 timed encodes of one sequence (bench.py --no-iso)
 json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
 for k in sorted(out):
     print(k, {c: round(v) for c, v in out[k].items()})
