@@ -44,6 +44,30 @@ def test_reversible_streams_decode_losslessly_in_one_batch(eng):
         np.testing.assert_array_equal(eng.j2k_decode_planes([cs])[0], y)
 
 
+def test_blocks_per_wave_of_the_block_decoder_do_not_change_the_planes(eng):
+    """k_t1_decode_lds<NB>: 1 (the default), 2, 4, 6 or 8 code-blocks per wave, one decoding lane each (a per-context switch)."""
+    from qsvc_amd import hip
+    ys = [_luma(k, W, H, 11) for (k, W, H, L) in CASES]
+    streams = [eng.j2k_encode_plane(y, hip.j2k_params(reversible=True, levels=3)) for y in ys]
+    lossy = [eng.j2k_encode_plane(ys[4], hip.j2k_params(reversible=False, levels=4, layers=2, slopes=[42000, 0]))]   # (one call, one transform)
+    ref = None
+    try:
+        for nb in (1, 2, 4, 6, 8):
+            eng.set_tuning("dec_lanes", nb)
+            got = eng.j2k_decode_planes(streams) + eng.j2k_decode_planes(lossy)
+            if ref is None:
+                ref = got
+                for y, d in zip(ys, got):
+                    np.testing.assert_array_equal(d, y)
+            else:
+                for a, b in zip(ref, got):
+                    np.testing.assert_array_equal(a, b, err_msg=f"dec_lanes={nb}")
+        with pytest.raises(hip.QsvcError):
+            eng.set_tuning("dec_lanes", 3)
+    finally:
+        eng.set_tuning("dec_lanes", 1)
+
+
 @pytest.mark.parametrize("kind,W,H,levels", CASES)
 def test_irreversible_layers_equal_restatement_and_track_openjpeg(eng, kind, W, H, levels):
     from qsvc_amd import hip

@@ -123,6 +123,39 @@ def test_hip_inverse_level_matches_oracle_from_host_inputs(eng, oracle, kind, se
     np.testing.assert_array_equal(got[1::2], want["odd"])
 
 
+@pytest.mark.parametrize("W,H,bs,R,seed", [(256, 160, 8, 4, 1), (256, 160, 8, 16, 2), (192, 128, 16, 12, 3), (128, 96, 8, 40, 4), (200, 120, 8, 7, 5)])
+def test_update_with_random_fields_both_forms(eng, oracle, W, H, bs, R, seed):
+    """The update step alone on ARBITRARY motion (every block its own random vector up to R: footprints overlap everywhere, the
+    ordered clamp-per-addition of update.cpp:85-146 matters at most targets) and random residues, from host inputs: the scatter
+    form (LDS images + ordered replay of the clashes), the gather form (QSVC_UPD_SCATTER=0) and -- reach 40: more than 255 blocks
+    within reach -- the scatter form's own fall-back all equal the restatement."""
+    from qsvc_amd import hip
+    rng = np.random.default_rng(seed)
+    P, nB = 5, 2
+    F = W * H * 3 // 2
+    low = rng.integers(0, 256, size=(P, F), dtype=np.uint8)
+    high = rng.integers(96, 160, size=(nB, F), dtype=np.uint8)
+    high[:, ::7] = rng.integers(0, 256, size=high[:, ::7].shape, dtype=np.uint8)   # some residues that saturate
+    mv = rng.integers(-R, R + 1, size=(nB, 4, H // bs, W // bs), dtype=np.int16)
+    mv[:, :, ::3, ::2] = 0   # ... and stretches of equal vectors between the discontinuities
+    types = b"BB"
+    want = oracle.update(low, W, H, bs, high, mv, types)
+    got = {}
+    for form in (1, 0):
+        eng.set_tuning("upd_scatter", form)
+        try:
+            eng.seq_config(W, H, True)
+            eng.put_frames(hip.LOW, 0, low)
+            eng.put_frames(hip.HIGH, 1, high)
+            eng.put_motion(hip.MOTION_FILTERED, 1, mv, bs)
+            eng.put_frame_types(1, types)
+            eng.update(1, P, bs)
+            got[form] = eng.get_frames(hip.LOW, 1, 0, nB + 1)
+        finally:
+            eng.set_tuning("upd_scatter", 1)
+        np.testing.assert_array_equal(got[form], want, err_msg=f"upd_scatter={form}")
+
+
 def test_inverse_level_needs_its_inputs(eng):
     from qsvc_amd import hip
     eng.seq_config(64, 64)
