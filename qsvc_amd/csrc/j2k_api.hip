@@ -673,7 +673,10 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     // (profiles/r03_*): no gain -- the modelling workgroups (11 KB of LDS each, 14 per CU) leave no room for an MQ
     // workgroup (25-40 KB) on any CU until they drain, so the side streams' kernels start when the modelling ends anyway
     // (single sequence 6.35 -> 6.77 ms with 4 parts, 12 sequences in flight 5200 -> 4280 fps).
-    int nparts = c->tune.t1_parts;
+    // Round 4: that is config 3 (15 657 blocks).  One 33-picture 4K sequence has 107 613 blocks and 7 + 5 ms of modelling + coding back
+    // to back: three parts take 31.8 -> 26.9 ms off one sequence alone (two: 30.2, four: 26.9).  t1_parts = 0 (the default) decides by
+    // the size of the batch.
+    int nparts = c->tune.t1_parts > 0 ? c->tune.t1_parts : (nslots >= 65536 ? 3 : 1);
     if (!mq_sort || nslots < 64 * 16) nparts = 1;
     int cut[5] = {0, 0, 0, 0, 0};
     {

@@ -13,7 +13,7 @@ struct Tuning {
   int mq_lds_small = 0;   // QSVC_MQ_LDS=small the pipeline with 25 instead of 40 KB of LDS per wave pair
   int mq_lanes = 64;      // QSVC_MQ_LANES     4, 8, 16, 32, 64 blocks per wave of the one-wave form
   int mq_sort = 1;        // QSVC_MQ_SORT      0: natural slot order
-  int t1_parts = 1;       // QSVC_T1_PARTS     1 .. 4 (experiment: Tier-1 in parts, MQ of part k beside modelling of part k + 1)
+  int t1_parts = 0;       // QSVC_T1_PARTS     0 (by batch size: 3 from 65 536 slots up, else 1), 1 .. 4: Tier-1 in parts, MQ of part k beside modelling of part k + 1
   int t1_devlist = 1;     // QSVC_T1_DEVLIST   0: always the host's job list
   int pyr_tile = 1;       // QSVC_PYR_TILE     set (any value): thread-per-coefficient pyramid instead of the LDS tiles
   int me_piece = 1;       // QSVC_ME_PIECE     set: the border-rule search kernels for every block
@@ -31,7 +31,7 @@ struct Tuning {
     if ((e = getenv("QSVC_MQ_LDS"))) t.mq_lds_small = !strcmp(e, "small");
     if ((e = getenv("QSVC_MQ_LANES"))) { const int v = atoi(e); t.mq_lanes = (v == 4 || v == 8 || v == 16 || v == 32) ? v : 64; }
     if ((e = getenv("QSVC_MQ_SORT"))) t.mq_sort = atoi(e) != 0;
-    if ((e = getenv("QSVC_T1_PARTS"))) { const int v = atoi(e); t.t1_parts = v < 1 ? 1 : (v > 4 ? 4 : v); }
+    if ((e = getenv("QSVC_T1_PARTS"))) { const int v = atoi(e); t.t1_parts = v < 0 ? 0 : (v > 4 ? 4 : v); }
     if ((e = getenv("QSVC_T1_DEVLIST"))) t.t1_devlist = e[0] != '0';
     if (getenv("QSVC_PYR_TILE")) t.pyr_tile = 0;
     if (getenv("QSVC_ME_PIECE")) t.me_piece = 0;
@@ -51,7 +51,7 @@ struct Tuning {
     for (auto& t : tab)
       if (!strcmp(t.n, name)) {
         if (t.p == &mq_lanes && !(v == 4 || v == 8 || v == 16 || v == 32 || v == 64)) return false;
-        if (t.p == &t1_parts && (v < 1 || v > 4)) return false;
+        if (t.p == &t1_parts && (v < 0 || v > 4)) return false;
         if (t.p == &dec_lanes && !(v == 1 || v == 2 || v == 4 || v == 6 || v == 8)) return false;
         *t.p = v;
         return true;
