@@ -550,10 +550,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
   __shared__ __attribute__((aligned(16))) uint8_t s_sign[256];
   __shared__ __attribute__((aligned(16))) uint32_t s_pk[64][8];   // per column: its 16 stripes' decisions per pass + "listed" flag (cm2_pack_pk)
   __shared__ __attribute__((aligned(16))) uint64_t s_cmp8[256];
-#ifdef CM2_EXP_PAD
-  __shared__ uint32_t s_pad[CM2_EXP_PAD / 4];
-  if (ncb < 0) { s_pad[threadIdx.x] = 1; __syncthreads(); cnt[0] = (int)s_pad[threadIdx.x ^ 1]; }   // (experiment: LDS footprint sensitivity)
-#endif
   // order != nullptr: workgroup k models block order[k] (the MQ stage's slot table: longest blocks first; ncb = an idle slot)
   const int lane = threadIdx.x, b = order ? order[blockIdx.x] : (int)blockIdx.x;
   if (b >= ncb) return;

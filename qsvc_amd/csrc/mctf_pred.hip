@@ -194,14 +194,8 @@ __global__ void __launch_bounds__(256) k_pred_level(PredArgs a, int ncx, int ncy
   static_assert(sizeof(smem) >= PCT_SMEM_BYTES, "chroma tile fits");
   int b = blockIdx.x;
   const int nchroma = ncx * ncy * a.g.nB * 2, nluma = nlx * nly * a.g.nB;
-#ifdef PRED_EXP_NO_CHROMA
-  if (b < nchroma) return;
-#endif
   if (b < nchroma) { pred_chroma_body(a, smem, b % ncx, (b / ncx) % ncy, b / (ncx * ncy), threadIdx.x); return; }
   b -= nchroma;
-#ifdef PRED_EXP_NO_LUMA
-  if (b < nluma) return;
-#endif
   if (b < nluma) { pred_luma_body(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x & 63, threadIdx.x >> 6); return; }
   b -= nluma;
   // last role: the histogram of the motion components + 128 (decorrelate.cpp:805-812), nmh workgroups per picture, which also

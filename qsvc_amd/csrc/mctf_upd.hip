@@ -428,9 +428,7 @@ __device__ __forceinline__ void upd_luma_tile(const UpdArgs& a, uint8_t* smem, c
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 2; q++)
-#ifndef UPD_EXP_NO_SCATTER
       if (s[q].high) upd_scatter<US_STR>(s[q], y0, nrows, x0, ncols, a.reach, acc + q * US_H * US_STR, cnt + q * US_H * US_STR, tid);
-#endif
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < US_NK; k++) {
@@ -438,11 +436,7 @@ __device__ __forceinline__ void upd_luma_tile(const UpdArgs& a, uint8_t* smem, c
       const int i = tid + 256 * k, row = i / US_RX, run = i % US_RX;
 #pragma unroll
       for (int q = 0; q < 2; q++)
-#ifndef UPD_EXP_NO_APPLY
         if (s[q].high)
-#else
-        if (s[q].high && a.reach > 1000)
-#endif
           v[k] = upd_from_image<US_STR>(s[q], acc + q * US_H * US_STR, cnt + q * US_H * US_STR, row, run, y0 + row, x0 + 8 * run, a.reach, a.uf, v[k]);
     }
   }
@@ -518,17 +512,11 @@ __global__ void __launch_bounds__(256) k_upd_level_sc(UpdArgs a, int ncxa, int n
   const int np = a.g.nB + 1;
   int b = blockIdx.x;
   const int nchroma = ncxa * ncya * np * 2, nluma = nlx * nly * np;
-#ifdef UPD_EXP_NO_CHROMA
-  if (b < nchroma) return;
-#endif
   if (b < nchroma) { upd_chroma_body<0, true>(a, smem, b % ncxa, (b / ncxa) % ncya, b / (ncxa * ncya), threadIdx.x); return; }
   b -= nchroma;
   if (b < nluma) { upd_luma_tile(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x); return; }
   b -= nluma;
   const int nbb = (2 * a.g.W + 2 * (a.g.H - 2) + 255) / 256;
-#ifdef UPD_EXP_NO_BORDER
-  if (b < nbb * np) return;
-#endif
   if (b < nbb * np) { upd_border_body(a, (b % nbb) * 256 + threadIdx.x, b / nbb); return; }
   b -= nbb * np;
   const int ncopy = cg.nWA + cg.nWB;
