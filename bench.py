@@ -465,7 +465,7 @@ def main():
         host_cpu = {"cpu_ms_per_step": round((cpu1["usage_us"] - cpu0["usage_us"]) / 1e3 / max(args.steps, 1), 2),
                     "cpus_busy": round((cpu1["usage_us"] - cpu0["usage_us"]) / 1e6 / dt, 2), "quota_cpus": cpu1["quota_cpus"],
                     "throttled_ms_in_timed_region": round((cpu1["throttled_us"] - cpu0["throttled_us"]) / 1e3, 1),
-                    "source": "cgroup v2 cpu.stat / cpu.max of the container"}
+                    "source": "cgroup v2 cpu.stat / cpu.max of the container" + (" (all %d ranks of this node together)" % local_world if local_world > 1 else "")}
         # who used it: the session threads (their own CPU clocks), then the live threads by name -- Tier-2 workers ("qsvc-t2"), the
         # main thread and whatever the HIP / ROCr runtime keeps (its signal handlers and helpers carry the process name)
         by = {k: tk1.get(k, 0.0) - tk0.get(k, 0.0) for k in tk1}
