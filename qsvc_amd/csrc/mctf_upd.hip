@@ -31,6 +31,7 @@ __device__ __forceinline__ uint64_t run_mask(int lo, int hi) { return (~0ull << 
 // The reference's default update factor 0.25 without floating point: v + 0.25 r is exact in float (two fraction bits), the clamp
 // and the truncating conversion of update.cpp:93-115 make it min(max(4 v + r, 0) >> 2, 255) -- on packed 16-bit lanes, four
 // instead of eleven instructions per sample.
+template <bool NEG>
 __device__ __forceinline__ uint64_t upd_apply8_quarter(uint64_t v, uint64_t r) {
   uint32_t out[2];
 #pragma unroll
@@ -42,7 +43,7 @@ __device__ __forceinline__ uint64_t upd_apply8_quarter(uint64_t v, uint64_t r) {
       const uint32_t sel = q ? 0x0c030c02u : 0x0c010c00u;   // bytes 2 q, 2 q + 1 -> the two 16-bit lanes
       const s16x2 V = S2(__builtin_amdgcn_perm(0u, vw, sel)), R = S2(pk_sub(__builtin_amdgcn_perm(0u, uw, sel), 0x00800080u));
       const s16x2 z = {0, 0}, m = {255, 255}, four = {4, 4};
-      s16x2 T = V * four + R;
+      s16x2 T = NEG ? V * four - R : V * four + R;   // un_update: the factor is -0.25 (a - r/4 is as exact as a + r/4)
       T = __builtin_elementwise_max(T, z) >> 2;
       t[q] = U(__builtin_elementwise_min(T, m));
     }
@@ -52,7 +53,8 @@ __device__ __forceinline__ uint64_t upd_apply8_quarter(uint64_t v, uint64_t r) {
 }
 // the 8 targets' values after one source run (signed residue bytes, 0 = no source)
 __device__ __forceinline__ uint64_t upd_apply8(uint64_t v, uint64_t r, float uf) {
-  if (uf == 0.25f) return upd_apply8_quarter(v, r);   // (uniform)
+  if (uf == 0.25f) return upd_apply8_quarter<false>(v, r);   // (uniform)
+  if (uf == -0.25f) return upd_apply8_quarter<true>(v, r);  // (the inverse step of the default factor)
   uint64_t o = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
