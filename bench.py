@@ -539,9 +539,19 @@ def main():
             dec = hip.Engine(devno)
             dec.seq_config(W, H)
 
-            def decode_once():
-                # motion_expand.py: the residues of every level from their code-streams (one batch), then the two correlators
-                mplanes = dec.j2k_decode_planes([cs for (t, Pt, St, bst) in comp.levels for cs in mcs[t]])
+            parts = {"motion_streams_and_correlators (beside the textures)": 0.0, "textures": 0.0, "inverse_mctf (incl. waiting for the motion side)": 0.0}
+
+            dec_m = hip.Engine(devno)   # the motion streams on a context (and stream) of their own, beside the textures
+            dec_m.seq_config(W, H)
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=1)
+
+            def motion_side():
+                # motion_expand.py: the residues of every level from their code-streams (one batch), then the two correlators.  (The
+                # component planes are the reference's raw 16-bit words: a negative residue is a 16-bit-plane block, 60 000 decisions
+                # of ONE lane -- 11 ms whatever else the chip does, which is why this runs beside the textures, not before them.)
+                ta = time.perf_counter()
+                mplanes = dec_m.j2k_decode_planes([cs for (t, Pt, St, bst) in comp.levels for cs in mcs[t]])
                 res, k = {}, 0
                 for (t, Pt, St, bst) in comp.levels:
                     nf, BY, BX = Pt // 2, H // bst, W // bst
@@ -549,16 +559,28 @@ def main():
                     res[t] = motion_chain.mux_components(np.ascontiguousarray(comps4))
                     k += 4 * nf
                 fields = motion_chain.field_chain(res, TRLS)
+                parts["motion_streams_and_correlators (beside the textures)"] += time.perf_counter() - ta
+                return fields
+
+            def decode_once():
+                tb = time.perf_counter()
+                fut = pool.submit(motion_side)
                 # texture_expand.py: every subband's pictures from their code-streams, one batch, straight into the resident sequences
                 dec.j2k_decode_multi([(kind, t, out[(kind, t)]) for (kind, t, n) in items])
+                tc = time.perf_counter()
+                fields = fut.result()
                 for (t, Pt, St, bst) in comp.levels:
                     dec.put_motion(hip.MOTION_FILTERED, t, fields[t], bst)
                     dec.put_frame_types(t, types[t])
                 for (t, Pt, St, bst) in reversed(comp.levels):
                     dec.synthesize_step(t, Pt, bst, St)
                 dec.sync()
+                td = time.perf_counter()
+                parts["textures"] += tc - tb; parts["inverse_mctf (incl. waiting for the motion side)"] += td - tc
             decode_once()
             DN = 3
+            for k_ in parts:
+                parts[k_] = 0.0
             t1 = time.perf_counter()
             for _ in range(DN):
                 decode_once()
@@ -566,13 +588,16 @@ def main():
             back = dec.get_frames(hip.LOW, 0, 0, P)
             d = back.astype(np.float64) - variant(seq_local, 0).astype(np.float64)
             mse = float((d * d).mean())
+            pool.shutdown()
+            dec_m.close()
             dec.close()
             # (lossless texture coding does not make the chain lossless: the reference's update / un_update pair truncates
             #  v + r * update_factor and is not an exact inverse, update.cpp:93-115 -- hence a PSNR, not an equality)
             decode_extra = {"ms_per_sequence": round(dms, 3), "frames_per_s": round(P / (dms * 1e-3), 1), "pictures": P,
+                            "parts_ms": {k_: round(v_ / DN * 1e3, 2) for k_, v_ in parts.items()},
                             "psnr_vs_input_db": round(99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse), 2),
-                            "what": "what `mcj2k expand` does: the motion residues from their code-streams + the two correlators, JPEG 2000 decode "
-                                    "of all subband pictures (one batch), inverse MCTF to low_0; one sequence, streams in host memory -> pictures in HBM"}
+                            "what": "what `mcj2k expand` does: the motion residues from their code-streams + the two correlators (on a second context, beside "
+                                    "the textures), JPEG 2000 decode of all subband pictures (one batch), inverse MCTF to low_0; one sequence, streams in host memory -> pictures in HBM"}
         except Exception as ex:  # an extra: never fail the headline on it
             decode_extra = {"error": repr(ex)}
 

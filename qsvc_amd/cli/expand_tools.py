@@ -230,9 +230,19 @@ def expand(argv=None):
             expand_file(e, f"low_{TRLs - 1}", GOPs + 1, W, H)
             return
         W, H, bs, L = _grid(a, TRLs)
-        for file, pictures in _texture_plan(TRLs, GOPs):
-            expand_file(e, file, pictures, W, H)
-        _run_motion_expand(e, TRLs, GOPs, H // bs, W // bs)
+        # The motion streams on a context (and stream) of their own, beside the textures: their component planes are the reference's raw
+        # 16-bit words, a negative residue makes a 16-bit-plane code-block, and one such block is ten milliseconds of one decoding lane
+        # whatever else the GPU does.  (Same files, same order of writes within each side.)
+        from concurrent.futures import ThreadPoolExecutor
+        em = C.engine()
+        try:
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                fut = pool.submit(_run_motion_expand, em, TRLs, GOPs, H // bs, W // bs)
+                for file, pictures in _texture_plan(TRLs, GOPs):
+                    expand_file(e, file, pictures, W, H)
+                fut.result()
+        finally:
+            em.close()
         sa = dict(a, block_size=",".join(map(str, L["block_size"])), pixels_in_x=",".join(map(str, L["pixels_in_x"])),
                   pixels_in_y=",".join(map(str, L["pixels_in_y"])), subpixel_accuracy=",".join(map(str, L["subpixel_accuracy"])))
         drivers.run_synthesize(e, sa)
