@@ -332,22 +332,30 @@ __global__ void __launch_bounds__(64) k_t1_decode_lds(const DecCb* cbs, int ncb,
   __shared__ uint32_t s_fw[NB * DEC_FW_WORDS];
   __shared__ uint32_t s_tbl[48];
   __shared__ uint32_t s_cw[NB * 20];
-  __shared__ uint8_t s_zc3[3 * 512];   // zero coding by neighbourhood: orientation classes LL / LH, HL, HH
+  // zero coding by neighbourhood: NB > 1: the three orientation classes LL / LH, HL, HH; NB == 1: the block's own class only (LDS sets
+  // the number of one-lane waves a CU holds: 5.5 KB per wave = 29 of them, with three tables 24)
+  constexpr int NZC = NB == 1 ? 1 : 3;
+  __shared__ uint8_t s_zc3[NZC * 512];
   {  // the whole wave: tables and clean flag planes
     const int t = threadIdx.x;
     for (int k = t; k < NB * DEC_FW_WORDS; k += 64) s_fw[k] = 0;
     if (t < 47) s_tbl[t] = c_dmq[t];
-    for (int k = t; k < 3 * 512; k += 64) s_zc3[k] = (uint8_t)d_zc_of(k & 511, k < 512 ? 0 : (k < 1024 ? 1 : 3));
+    if (NB == 1) {
+      const int o1 = blockIdx.x < (unsigned)ncb ? cbs[blockIdx.x].orient : 0;
+      for (int k = t; k < 512; k += 64) s_zc3[k] = (uint8_t)d_zc_of(k, o1);
+    } else {
+      for (int k = t; k < 3 * 512; k += 64) s_zc3[k] = (uint8_t)d_zc_of(k & 511, k < 512 ? 0 : (k < 1024 ? 1 : 3));
+    }
   }
   __syncthreads();
   // lanes lane0 .. decode (lane0 is passed as an argument: with the lane index a compile-time constant the ROCm 7.2 build scalarised
   // the whole kernel and decoded garbage)
   const int li = (int)threadIdx.x - lane0;
-  const int b = blockIdx.x * NB + li;
+  const int b = NB == 1 ? (int)blockIdx.x : (int)blockIdx.x * NB + li;   // (one block per wave: its record and pointers are wave-uniform -- scalar loads, SGPRs)
   if (li < 0 || li >= nlanes || b >= ncb) return;
   const DecCb cb = cbs[b];
   uint32_t* fw = s_fw + li * DEC_FW_WORDS;
-  const uint8_t* s_zc = s_zc3 + 512 * (cb.orient == 1 ? 1 : (cb.orient == 3 ? 2 : 0));
+  const uint8_t* s_zc = s_zc3 + (NB == 1 ? 0 : 512 * (cb.orient == 1 ? 1 : (cb.orient == 3 ? 2 : 0)));
   uint8_t* lastp = lastp_all + (size_t)b * 64 * 64;
   int32_t* mag = (int32_t*)coefv + cb.plane_off + (size_t)cb.y0 * cb.W + cb.x0;  // row stride cb.W
   const int w = cb.w, h = cb.h, W = cb.W, nstr = (h + 3) >> 2;
