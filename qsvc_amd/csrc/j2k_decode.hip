@@ -608,7 +608,7 @@ static int decode_impl(qsvc_ctx* c, int nstreams, const uint8_t* const* streams,
   for (int i = 0; i < nstreams; i++) if (!streams[i]) return c->fail(QSVC_ERR_INVALID, "code-stream %d is null", i);
   const auto tp0 = std::chrono::steady_clock::now();
   {
-    const int nthr = std::max(1, std::min({nstreams, 8, c->t2_threads > 0 ? c->t2_threads : 8}));
+    const int nthr = std::max(1, std::min({nstreams, 16, c->t2_threads > 0 ? c->t2_threads : 16}));
     std::atomic<int> next{0};
     auto work = [&]() {
       for (int i; (i = next.fetch_add(1)) < nstreams;) {
@@ -659,7 +659,7 @@ static int decode_impl(qsvc_ctx* c, int nstreams, const uint8_t* const* streams,
   {  // the streams' tables into the merged ones, by the same few threads; then the blocks in the order the kernel takes them
     std::vector<DecCb> tmp;
     try { tmp.resize(cb_total); } catch (const std::exception&) { return c->fail(QSVC_ERR_NOMEM, "out of host memory while parsing"); }
-    const int nthr = std::max(1, std::min({nstreams, 8, c->t2_threads > 0 ? c->t2_threads : 8}));
+    const int nthr = std::max(1, std::min({nstreams, 16, c->t2_threads > 0 ? c->t2_threads : 16}));
     std::atomic<int> next{0};
     auto work = [&]() {
       for (int i; (i = next.fetch_add(1)) < nstreams;) {
