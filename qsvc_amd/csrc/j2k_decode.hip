@@ -348,8 +348,10 @@ __global__ void __launch_bounds__(64) k_t1_decode_lds(const DecCb* cbs, int ncb,
     }
   }
   __syncthreads();
-  // lanes lane0 .. decode (lane0 is passed as an argument: with the lane index a compile-time constant the ROCm 7.2 build scalarised
-  // the whole kernel and decoded garbage)
+  // lanes lane0 .. lane0 + nlanes - 1 decode.  (History: round 3's kernel kept a flag BYTE per sample and cleared the plane with 32-bit
+  // stores through the byte array; with the lane index a compile-time constant that build decoded garbage, and the index became an
+  // argument.  The flag-word kernel has no such aliasing: a build with the constant index passes every decoder test (round 4); the
+  // argument stays as the first lane of the NB > 1 forms.)
   const int li = (int)threadIdx.x - lane0;
   const int b = NB == 1 ? (int)blockIdx.x : (int)blockIdx.x * NB + li;   // (one block per wave: its record and pointers are wave-uniform -- scalar loads, SGPRs)
   if (li < 0 || li >= nlanes || b >= ncb) return;
