@@ -2,7 +2,7 @@
 # On the GPU box: kernel trace of the 12-sequence bench -> how much of the wall clock has NO kernel running, and how many run at once
 set -e
 export TMPDIR=/tmp PYTHONPATH=$PWD
-rocprofv3 --kernel-trace -d gpurun_out/tm_prof -o t --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-decode --no-iso > gpurun_out/tm_prof.log 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/tm_prof -o t --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-decode --no-iso --no-cli --no-config4 > gpurun_out/tm_prof.log 2>&1
 python3 - $(find gpurun_out/tm_prof -name "*kernel_trace.csv" | head -1) <<'PY'
 import csv, sys
 ev = []
