@@ -211,8 +211,8 @@ __device__ __forceinline__ void upd_border_body(const UpdArgs& a, const int k, c
 
 // ---------------------------------------------------------------------------------------------
 // SCATTER form (round 4).  The ordered gather above tests every block within reach of a run of 8 targets -- (2 R / bs + 2)^2
-// candidates per side, nearly all of them misses -- and that test, not the memory system, was what the update step cost (65 %
-// VALU issue at 10 % of the HBM peak).  Here a workgroup owns a TILE of targets and walks the sources instead: every (block,
+// candidates per side, nearly all of them misses -- and that test, not the memory system, was what the update step cost (32 M
+// vector wave-instructions per launch, 32 lane-operations per byte, at 10 % of the HBM peak).  Here a workgroup owns a TILE of targets and walks the sources instead: every (block,
 // run of 8 columns, quad of rows) within reach of the tile is one task; its four aligned 8-byte rows of residue are OR-ed into a
 // byte image of the tile in LDS at the displaced position (three aligned words per row, no return value needed) and a second
 // image counts the non-zero contributions per target.  A target with at most one non-zero source per side is order-free
