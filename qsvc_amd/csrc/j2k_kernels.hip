@@ -521,6 +521,17 @@ __device__ __forceinline__ uint64_t cm2_transpose64(uint64_t v, int lane) {
   return (uint64_t)lo | (uint64_t)hi << 32;
 }
 
+// inclusive prefix sum over the wave's 64 lanes by DPP row shifts / broadcasts (no LDS crossbar: __shfl_up is a ds_bpermute, six
+// dependent round trips per scan, and the modelling kernel runs four scans per bit-plane)
+__device__ __forceinline__ int wave_scan_add(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
 #define CM2_CW_STRIDE 67
 // The staging buffer of a plane's three decision streams.  16 360 bytes of LDS per wave in all = ten waves per CU (round 4: with
 // room for the worst case, 9 984 bytes = 20.4 KB per wave, seven waves fitted; the modelling kernel is VALU-bound and every wave
@@ -664,10 +675,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
   }
   int off3[3], tot3[3];
   for (int pass = 0; pass < 3; pass++) {
-    int incl = n3[pass];
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const int incl = wave_scan_add(n3[pass]);
     off3[pass] = incl - n3[pass];
-    tot3[pass] = __shfl(incl, 63, 64);
+    tot3[pass] = __builtin_amdgcn_readlane(incl, 63);
   }
   uint8_t* seg = segs + (size_t)job * T1_SEG_BYTES;
   long long d3[3] = {0, 0, 0};
@@ -677,10 +687,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
   int apos, nact;
   {
     const int mine = __popc(act);
-    int incl = mine;
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const int incl = wave_scan_add(mine);
     apos = incl - mine;
-    nact = __shfl(incl, 63, 64);
+    nact = __builtin_amdgcn_readlane(incl, 63);
   }
   if (nact <= CM2_LIST_MAX && base2 + tot3[2] + 16 <= CM2_LIST_AT) {
     // ---- sparse plane: plain columns put their RUN byte, the others are listed and worked off 64 at a time ---------------
