@@ -82,3 +82,30 @@ def test_update_on_random_fields_both_forms(eng, oracle, seed):
                                               err_msg=f"case {case}: {W}x{H} bs {bs} R {R} nB {nB} types {types} uf {uf} upd_scatter={form}")
     finally:
         eng.set_tuning("upd_scatter", 1)
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_motion_estimate_on_random_geometries(eng, oracle, seed):
+    """The hierarchical search (pyramid, piece / ring kernels, literal replay at odd pyramid sizes, stand-alone kernels where the block
+    grid does not tile the picture) on random sizes, block sizes and search ranges."""
+    from qsvc_amd import hip
+    rng = np.random.default_rng(seed)
+    for case in range(10):
+        bs = int(rng.choice([8, 16, 32]))
+        W, H = 8 * int(rng.integers(4, 40)), 8 * int(rng.integers(4, 24))
+        if W < bs or H < bs:
+            continue
+        S = int(rng.choice([1, 2, 4, 8, 16]))
+        nB = int(rng.integers(1, 3))
+        P = 2 * nB + 1
+        kind = str(rng.choice(["pan_noise", "edge", "scene_cut", "binary"]))
+        low = make_clip(kind, P, W, H, int(rng.integers(1, 1000)))
+        want = oracle.motion_estimate(low, W, H, bs, S)
+        eng.seq_config(W, H, True)
+        eng.put_frames(hip.LOW, 0, low)
+        try:
+            eng.motion_estimate(1, P, bs, S)
+        except hip.QsvcError as ex:   # a geometry the path refuses loudly (DESIGN 7) is not a parity failure
+            assert "refus" in str(ex).lower() or "unsupported" in str(ex).lower() or "not " in str(ex).lower(), str(ex)
+            continue
+        np.testing.assert_array_equal(eng.get_motion(hip.MOTION_RAW, 1, nB, bs), want, err_msg=f"case {case}: {kind} {W}x{H} bs {bs} S {S} nB {nB}")
