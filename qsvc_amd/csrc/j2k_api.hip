@@ -168,25 +168,8 @@ void put_npasses(BitW& b, int n) {  // T.800 Table B.4
 // Kakadu-style logarithmic slope -> Lagrangian threshold in 8-bit-sample^2 per byte.  APPROXIMATE: the
 // `-slope` semantics are Kakadu-private; s = 256*(192 + log2(dD/dL)), D in full-scale^2.
 double slope_to_lambda(int slope) { return pow(2.0, slope / 256.0 - 176.0); }
-// passes on the convex hull of (length, distortion) with slope >= lambda (PCRD-opt, T.800 J.14)
-int passes_for_lambda(int npasses, const int* plen, const long long* pdist, double weight, double lambda) {
-  if (lambda <= 0) return npasses;
-  int best = 0, best_l = 0, cur = 0;
-  while (cur < npasses) {
-    double bs = -1; int bi = -1;
-    double cd = 0;
-    for (int i = cur; i < npasses; i++) {
-      cd += (double)pdist[i] * weight;
-      int dl = plen[i] - best_l;
-      if (dl <= 0) { if (cd > 0) { bs = 1e300; bi = i; } continue; }
-      double s = cd / dl;
-      if (s >= bs) { bs = s; bi = i; }
-    }
-    if (bi < 0 || bs < lambda) break;
-    best_l = plen[bi]; best = bi + 1; cur = bi + 1;
-  }
-  return best;
-}
+// (the passes on the convex hull of (length, distortion) with slope >= lambda -- PCRD-opt, T.800 J.14 -- are chosen on the device:
+// k_rate_alloc, j2k_kernels.hip)
 
 struct HostCb {  // host view of one coded block
   int len, npasses, nbps, zbp;
@@ -290,6 +273,8 @@ struct J2kState {
   Pinned<CbOut> res;
   Pinned<int> plen;
   Pinned<long long> pdist;
+  Pinned<uint8_t> lp;                 // [ncb][16] passes per layer from k_rate_alloc
+  DevBuf ra_wgt_d, ra_cbp_d, ra_pl_d, lp_d;
   Pinned<int> h_err;
   std::vector<HostCb> hcb;
   uint64_t st_cb = 0, st_pass = 0, st_sym = 0;
@@ -320,7 +305,7 @@ void j2k_release(qsvc_ctx* c) {
   J2kState* s = c->j2k;
   if (!s) return;
   DevBuf* all[] = {&s->coefA, &s->llA, &s->llB, &s->sbtab_d, &s->planes_d, &s->cbs_d, &s->nbps_d, &s->mags, &s->outbuf, &s->res_d, &s->plen_d,
-                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->mvup_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d, &s->nbeff_d, &s->njobs_d, &s->t1tabs_d, &s->tilemap_d};
+                   &s->pdist_d, &s->offs_d, &s->lens_d, &s->gath_d, &s->err_d, &s->up_d, &s->mvup_d, &s->joboff_d, &s->order_d, &s->segs_d, &s->cnt_d, &s->dist_d, &s->nbeff_d, &s->njobs_d, &s->t1tabs_d, &s->tilemap_d, &s->ra_wgt_d, &s->ra_cbp_d, &s->ra_pl_d, &s->lp_d};
   for (auto* b : all) b->release();
   if (s->gath_h) (void)hipHostFree(s->gath_h);
   for (auto& e : s->copied) if (e) (void)hipEventDestroy(e);
@@ -329,7 +314,7 @@ void j2k_release(qsvc_ctx* c) {
     if (s->mq_done[k]) (void)hipEventDestroy(s->mq_done[k]);
     if (s->mq_st[k]) (void)hipStreamDestroy(s->mq_st[k]);
   }
-  s->h_nbps.release(); s->h_joboff.release(); s->res.release(); s->plen.release(); s->pdist.release(); s->h_err.release();
+  s->h_nbps.release(); s->h_joboff.release(); s->res.release(); s->plen.release(); s->pdist.release(); s->lp.release(); s->h_err.release();
   delete s->pool;
   delete s;
   c->j2k = nullptr;
@@ -603,9 +588,12 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   const int nslots = ((ncb + MQW - 1) / MQW) * MQW;
   const bool mq_sort = c->tune.mq_sort != 0;
   bool devlist = c->tune.t1_devlist && mq_sort && S.jobs_cap > 0 && (!want_dist || S.jobs_cap_dist);
-  if (!S.res.resize(ncb) || !S.h_err.resize(2) || (want_dist && (!S.plen.resize((size_t)ncb * T1_MAXPASS) || !S.pdist.resize((size_t)ncb * T1_MAXPASS))))
+  if (!S.res.resize(ncb) || !S.h_err.resize(2) || (want_dist && (!S.plen.resize((size_t)ncb * T1_MAXPASS) || !S.lp.resize((size_t)ncb * 16))))
     return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc (page-locked tables)");
   int& err = S.h_err[1];
+  std::vector<double> ra_wgt;   // (tables of the device-side rate allocation: they live until the stream has been waited for)
+  std::vector<int> ra_cbp;
+  std::vector<RaPlane> ra_pl;
   for (;;) {
     const int* nbp = (const int*)S.nbps_d.p;   // the bit-plane counts the Tier-1 kernels read
     size_t njobs = 1;
@@ -723,8 +711,34 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     HIPCHK(c, hipMemcpyAsync(S.res.data(), S.res_d.p, (size_t)ncb * sizeof(CbOut), hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipMemcpyAsync(&err, S.err_d.p, 4, hipMemcpyDeviceToHost, c->st));
     if (want_dist) {
+      // rate allocation on the device (k_rate_alloc): per block its subband's distortion weight and its plane, per plane the layers'
+      // thresholds; what comes back is the per-pass lengths (Tier-2 needs them) and 16 bytes per block, not the distortion sums
+      ra_wgt.resize(ncb); ra_cbp.resize(ncb); ra_pl.resize(np);
+      std::vector<double>& wgt = ra_wgt;
+      std::vector<int>& cbp = ra_cbp;
+      std::vector<RaPlane>& rp = ra_pl;
+      for (int p = 0; p < np; p++) {
+        const PlanePlan& pl = plans[plan_of[p]];
+        const qsvc_j2k_params* pprm = src[p].prm;
+        RaPlane& q = rp[p];
+        q.layers = pprm->layers < 1 ? 1 : (pprm->layers > 16 ? 16 : pprm->layers);
+        q.last_all = pprm->slopes[q.layers - 1] <= 0;
+        for (int l = 0; l < 16; l++) q.lam[l] = (l < q.layers && pprm->slopes[l] > 0) ? slope_to_lambda(pprm->slopes[l]) : 0.0;
+        for (auto& sb : pl.sb) {
+          double w = (double)sb.delta * norm_of(rev, sb.orient, sb.dlev);
+          w *= w;
+          for (int i = 0; i < sb.gx * sb.gy; i++) { const int k = first_cb[p] + sb.first_cb + i; wgt[k] = w; cbp[k] = p; }
+        }
+      }
+      if ((r = S.ra_wgt_d.ensure(c, (size_t)ncb * 8)) || (r = S.ra_cbp_d.ensure(c, (size_t)ncb * 4)) || (r = S.ra_pl_d.ensure(c, (size_t)np * sizeof(RaPlane))) ||
+          (r = S.lp_d.ensure(c, (size_t)ncb * 16))) return r;
+      HIPCHK(c, hipMemcpyAsync(S.ra_wgt_d.p, wgt.data(), (size_t)ncb * 8, hipMemcpyHostToDevice, c->st));
+      HIPCHK(c, hipMemcpyAsync(S.ra_cbp_d.p, cbp.data(), (size_t)ncb * 4, hipMemcpyHostToDevice, c->st));
+      HIPCHK(c, hipMemcpyAsync(S.ra_pl_d.p, rp.data(), (size_t)np * sizeof(RaPlane), hipMemcpyHostToDevice, c->st));
+      launch_rate_alloc(c->st, (const CbOut*)S.res_d.p, (const int*)S.plen_d.p, (const long long*)S.pdist_d.p, (const double*)S.ra_wgt_d.p,
+                        (const int*)S.ra_cbp_d.p, (const RaPlane*)S.ra_pl_d.p, ncb, (uint8_t*)S.lp_d.p);
       HIPCHK(c, hipMemcpyAsync(S.plen.data(), S.plen_d.p, (size_t)ncb * T1_MAXPASS * 4, hipMemcpyDeviceToHost, c->st));
-      HIPCHK(c, hipMemcpyAsync(S.pdist.data(), S.pdist_d.p, (size_t)ncb * T1_MAXPASS * 8, hipMemcpyDeviceToHost, c->st));
+      HIPCHK(c, hipMemcpyAsync(S.lp.data(), S.lp_d.p, (size_t)ncb * 16, hipMemcpyDeviceToHost, c->st));
     }
     {
       HostCpu hc(c, "host_cpu_wait_tier1");
@@ -742,15 +756,67 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     }
     break;
   }
-  // The code bytes of every block (all of them: what a layer leaves out is decided on the host meanwhile) are gathered in block
-  // order and start their way to the host; rate allocation and the code-streams' lengths are worked out under that copy.
+  S.hcb.resize(ncb);
+  S.st_cb += ncb;  // the statistics cover every plane group of the call (reset by j2k_encode_planes)
+  // worker count: qsvc_set_tier2_threads, else QSVC_T2_THREADS as it was at this context's first encode (read once: the
+  // environment is not consulted while other contexts' threads may be changing it), else 8; never more than planes
+  if (!c->t2_default) { const char* e = getenv("QSVC_T2_THREADS"); int v = e ? atoi(e) : 8; c->t2_default = v < 1 ? 1 : (v > 64 ? 64 : v); }
+  int t2_want = c->t2_threads > 0 ? c->t2_threads : c->t2_default;
+  if (src[0].s16 && t2_want > 2) t2_want = 2;  // motion planes: kilobytes per stream, their state keeps at most one worker thread
+  if (t2_want > np) t2_want = np;
+  if (t2_want < 1) t2_want = 1;
+  if (S.pool && S.pool->nworkers != t2_want - 1) { delete S.pool; S.pool = nullptr; }  // rebuilt only when the count changes
+  if (!S.pool) { S.pool = new T2Pool(); S.pool->start(t2_want - 1); }
+  const int nthreads = S.pool->nworkers + 1;
   std::vector<unsigned long long> goffs(ncb);
   std::vector<int> glens(ncb);
+  // host, per plane and in parallel: rate allocation (which passes of a block go into which layer), then Tier-2
+  auto rate_alloc = [&](int p, uint64_t& n_pass, uint64_t& n_sym) {
+    const PlanePlan& pl = plans[plan_of[p]];
+    const qsvc_j2k_params* pprm = src[p].prm;
+    const int layers = pprm->layers < 1 ? 1 : pprm->layers;
+    for (auto& sb : pl.sb) {
+      for (int i = 0; i < sb.gx * sb.gy; i++) {
+        int k = first_cb[p] + sb.first_cb + i;
+        const CbOut& ro = S.res[k];
+        HostCb& h = S.hcb[k];
+        h.len = ro.len; h.npasses = ro.npasses; h.nbps = ro.nbps; h.zbp = sb.Mb - ro.nbps; h.lblock = 3; h.included = false;
+        n_pass += ro.npasses; n_sym += ro.nsym;
+        for (int l = 0; l < layers; l++) {
+          int n;
+          if (want_dist) n = l < 16 ? S.lp[(size_t)k * 16 + l] : ro.npasses;   // k_rate_alloc's choice (passes_for_lambda, on the device)
+          else n = l == layers - 1 ? ro.npasses : 0;                            // no slope anywhere: every pass in the last layer
+          if (l > 0 && n < h.layer_passes[l - 1]) n = h.layer_passes[l - 1];
+          h.layer_passes[l] = n;
+        }
+        for (int l = layers; l < 16; l++) h.layer_passes[l] = 0;   // (the records outlive the call: nothing stale beyond this plane's layers)
+        h.first_layer = layers;
+        for (int l = layers - 1; l >= 0; l--) if (h.layer_passes[l] > 0) h.first_layer = l;
+      }
+    }
+  };
+  // Which bytes cross the bus.  Every pass of every block (lossless, or a last layer without a slope): the copy starts at once and the
+  // rate allocation runs under it.  Layers that leave passes out (`want_dist`): the allocation first -- its inputs, the per-pass
+  // lengths and distortions, are already here -- and only the bytes up to each block's last included pass are gathered and copied
+  // (round 4: at 4K with the reference's slope a tenth of the 185 MB; the copy of all of them was 4 of one sequence's 27 ms).
+  std::vector<uint64_t> n_pass(nthreads, 0), n_sym(nthreads, 0);
+  if (want_dist)
+    S.pool->run([&](int tid) { for (int p = tid; p < np; p += nthreads) rate_alloc(p, n_pass[tid], n_sym[tid]); });
   size_t gtotal = 0;
   for (int k = 0; k < ncb; k++) {
     const CbOut& ro = S.res[k];
     if (ro.overflow) return c->fail(QSVC_ERR_NOMEM, "code-block segment exceeds %d bytes", J2K_OUTCAP);
-    goffs[k] = gtotal; glens[k] = ro.len; gtotal += (size_t)ro.len;
+    int take = ro.len;
+    if (want_dist) {
+      const HostCb& h = S.hcb[k];
+      const int layers = 16;
+      int last = 0;
+      for (int l = 0; l < layers; l++) last = h.layer_passes[l] > last ? h.layer_passes[l] : last;   // (non-decreasing; entries beyond the plane's layers are 0)
+      take = last > 0 ? S.plen[(size_t)k * T1_MAXPASS + last - 1] : 0;
+      if (take > ro.len) take = ro.len;
+    }
+    goffs[k] = gtotal; glens[k] = take; gtotal += (size_t)take;
+    S.hcb[k].data_off = goffs[k];
   }
   if ((r = S.gath_d.ensure(c, gtotal ? gtotal : 16))) return r;
   if (S.gath_h_cap < gtotal) {
@@ -784,59 +850,17 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
       p0 = p1;
     }
   }
-  S.hcb.resize(ncb);
-  S.st_cb += ncb;  // the statistics cover every plane group of the call (reset by j2k_encode_planes)
-  // host, per plane and in parallel: rate allocation (which passes of a block go into which layer), then Tier-2
-  auto rate_alloc = [&](int p, uint64_t& n_pass, uint64_t& n_sym) {
-    const PlanePlan& pl = plans[plan_of[p]];
-    const qsvc_j2k_params* pprm = src[p].prm;
-    const int layers = pprm->layers < 1 ? 1 : pprm->layers;
-    for (auto& sb : pl.sb) {
-      double wgt = (double)sb.delta * norm_of(rev, sb.orient, sb.dlev);
-      wgt *= wgt;
-      for (int i = 0; i < sb.gx * sb.gy; i++) {
-        int k = first_cb[p] + sb.first_cb + i;
-        const CbOut& ro = S.res[k];
-        HostCb& h = S.hcb[k];
-        h.len = ro.len; h.npasses = ro.npasses; h.nbps = ro.nbps; h.zbp = sb.Mb - ro.nbps; h.lblock = 3; h.included = false;
-        n_pass += ro.npasses; n_sym += ro.nsym;
-        const int* plen = want_dist ? S.plen.data() + (size_t)k * T1_MAXPASS : nullptr;
-        for (int l = 0; l < layers; l++) {
-          int n;
-          if (l == layers - 1 && pprm->slopes[l] <= 0) n = ro.npasses;
-          else if (pprm->slopes[l] <= 0) n = 0;
-          else n = passes_for_lambda(ro.npasses, plen, S.pdist.data() + (size_t)k * T1_MAXPASS, wgt, slope_to_lambda(pprm->slopes[l]));
-          if (l > 0 && n < h.layer_passes[l - 1]) n = h.layer_passes[l - 1];
-          h.layer_passes[l] = n;
-        }
-        h.first_layer = layers;
-        for (int l = layers - 1; l >= 0; l--) if (h.layer_passes[l] > 0) h.first_layer = l;
-        h.data_off = goffs[k];
-      }
-    }
-  };
   // host: Tier-2, one code-stream per plane; planes are independent.  First every stream's length (packet headers are built, no
   // byte is copied), which fixes the streams' positions in `out`; then, once the code bytes have arrived, the streams themselves.
   {
-    // worker count: qsvc_set_tier2_threads, else QSVC_T2_THREADS as it was at this context's first encode (read once: the
-    // environment is not consulted while other contexts' threads may be changing it), else 8; never more than planes
-    if (!c->t2_default) { const char* e = getenv("QSVC_T2_THREADS"); int v = e ? atoi(e) : 8; c->t2_default = v < 1 ? 1 : (v > 64 ? 64 : v); }
-    int t2_want = c->t2_threads > 0 ? c->t2_threads : c->t2_default;
-    if (src[0].s16 && t2_want > 2) t2_want = 2;  // motion planes: kilobytes per stream, their state keeps at most one worker thread
-    if (t2_want > np) t2_want = np;
-    if (t2_want < 1) t2_want = 1;
-    if (S.pool && S.pool->nworkers != t2_want - 1) { delete S.pool; S.pool = nullptr; }  // rebuilt only when the count changes
-    if (!S.pool) { S.pool = new T2Pool(); S.pool->start(t2_want - 1); }
-    const int nthreads = S.pool->nworkers + 1;
     std::vector<long> rc(np, 0);
     auto stream_of = [&](int p, uint8_t* dst, size_t dcap) {
       return write_codestream(plans[plan_of[p]], *src[p].prm, src[p].prm->layers < 1 ? 1 : src[p].prm->layers, cbw, cbh,
                               S.hcb.data() + first_cb[p], want_dist ? S.plen.data() + (size_t)first_cb[p] * T1_MAXPASS : nullptr, S.gath_h, dst, dcap);
     };
     const auto t2a_begin = std::chrono::steady_clock::now();
-    std::vector<uint64_t> n_pass(nthreads, 0), n_sym(nthreads, 0);
     S.pool->run([&](int tid) {
-      for (int p = tid; p < np; p += nthreads) { rate_alloc(p, n_pass[tid], n_sym[tid]); rc[p] = stream_of(p, nullptr, 0); }
+      for (int p = tid; p < np; p += nthreads) { if (!want_dist) rate_alloc(p, n_pass[tid], n_sym[tid]); rc[p] = stream_of(p, nullptr, 0); }
     });
     for (int k = 0; k < nthreads; k++) { S.st_pass += n_pass[k]; S.st_sym += n_sym[k]; }
     size_t pos = 0;

@@ -30,6 +30,12 @@ struct CbOut {
   unsigned long long nsym;
 };
 
+// Rate allocation on the device (PCRD-opt, T.800 J.14; oracle/j2k_oracle.c holds the same loop): per plane the
+// layers' thresholds, per block its subband's distortion weight and its plane
+struct RaPlane { double lam[16]; int layers; int last_all; };   // lam[l] <= 0: layer l has no slope; last_all: the last layer takes every pass
+void launch_rate_alloc(hipStream_t st, const CbOut* res, const int* plen, const long long* pdist, const double* wgt, const int* cb_plane,
+                       const RaPlane* planes, int ncb, uint8_t* layer_passes /*[ncb][16]*/);
+
 struct DwtSb {       // one subband of one plane as the DWT kernel addresses its code-blocks
   int first_cb;      // index of the subband's first code-block in the batch
   int gx;            // code-blocks per row

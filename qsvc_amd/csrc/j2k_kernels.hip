@@ -829,6 +829,54 @@ void launch_t1_cm2(hipStream_t st, const CbDesc* cbs, int ncb, const int* nbps, 
   if (n > 0) hipLaunchKernelGGL(k_t1_cm2, dim3(n), dim3(64), 0, st, cbs, ncb, nbps, joboff, order, mags, segs, cnt, dist, want_dist, tabs);
 }
 
+// Which passes of a block go into which layer: one thread per block, the restatement's loop (oracle/j2k_oracle.c) in the same double
+// arithmetic (no contraction: the library is built with -ffp-contract=off; IEEE division), so the choice is bit-identical with the
+// restatement's.  Round 4: on the host this was 4 ms of 16 threads per 4K sequence, behind 37 MB of distortion sums over the bus.
+__global__ void __launch_bounds__(256) k_rate_alloc(const CbOut* res, const int* plen_all, const long long* pdist_all, const double* wgt, const int* cb_plane,
+                                                    const RaPlane* planes, int ncb, uint8_t* layer_passes) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= ncb) return;
+  const int npasses = res[k].npasses;
+  const int* plen = plen_all + (size_t)k * T1_MAXPASS;
+  const long long* pdist = pdist_all + (size_t)k * T1_MAXPASS;
+  const RaPlane& pp = planes[cb_plane[k]];
+  const double weight = wgt[k];
+  uint8_t* lp = layer_passes + (size_t)k * 16;
+  int prev = 0;
+  for (int l = 0; l < 16; l++) {
+    int n = 0;
+    if (l < pp.layers) {
+      const double lambda = pp.lam[l];
+      if (l == pp.layers - 1 && pp.last_all) n = npasses;
+      else if (lambda <= 0) n = 0;
+      else {
+        int best = 0, best_l = 0, cur = 0;
+        while (cur < npasses) {
+          double bs = -1; int bi = -1;
+          double cd = 0;
+          for (int i = cur; i < npasses; i++) {
+            cd += (double)pdist[i] * weight;
+            const int dl = plen[i] - best_l;
+            if (dl <= 0) { if (cd > 0) { bs = 1e300; bi = i; } continue; }
+            const double s = cd / dl;
+            if (s >= bs) { bs = s; bi = i; }
+          }
+          if (bi < 0 || bs < lambda) break;
+          best_l = plen[bi]; best = bi + 1; cur = bi + 1;
+        }
+        n = best;
+      }
+      if (l > 0 && n < prev) n = prev;
+      prev = n;
+    }
+    lp[l] = (uint8_t)n;
+  }
+}
+void launch_rate_alloc(hipStream_t st, const CbOut* res, const int* plen, const long long* pdist, const double* wgt, const int* cb_plane,
+                       const RaPlane* planes, int ncb, uint8_t* layer_passes) {
+  if (ncb > 0) hipLaunchKernelGGL(k_rate_alloc, dim3((ncb + 255) / 256), dim3(256), 0, st, res, plen, pdist, wgt, cb_plane, planes, ncb, layer_passes);
+}
+
 // gather: segment of block b (bytes 1..len of its lane buffer) -> dst + offs[b]
 __global__ void __launch_bounds__(256) k_gather(const uint8_t* outbuf, int outcap, const unsigned long long* offs, const int* lens,
                                                  int ncb, uint8_t* dst) {
