@@ -173,6 +173,7 @@ double slope_to_lambda(int slope) { return pow(2.0, slope / 256.0 - 176.0); }
 
 struct HostCb {  // host view of one coded block
   int len, npasses, nbps, zbp;
+  int take;                     // bytes of its segment that any layer uses (what is gathered and copied to the host)
   size_t data_off;              // into the gathered byte buffer
   int layer_passes[16];
   int first_layer, lblock;
@@ -771,10 +772,11 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
   std::vector<unsigned long long> goffs(ncb);
   std::vector<int> glens(ncb);
   // host, per plane and in parallel: rate allocation (which passes of a block go into which layer), then Tier-2
-  auto rate_alloc = [&](int p, uint64_t& n_pass, uint64_t& n_sym) {
+  auto rate_alloc = [&](int p, uint64_t& n_pass_out, uint64_t& n_sym_out) {
     const PlanePlan& pl = plans[plan_of[p]];
     const qsvc_j2k_params* pprm = src[p].prm;
     const int layers = pprm->layers < 1 ? 1 : pprm->layers;
+    uint64_t n_pass = 0, n_sym = 0;   // (local: the callers' counters of different threads share cache lines)
     for (auto& sb : pl.sb) {
       for (int i = 0; i < sb.gx * sb.gy; i++) {
         int k = first_cb[p] + sb.first_cb + i;
@@ -784,7 +786,7 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
         n_pass += ro.npasses; n_sym += ro.nsym;
         for (int l = 0; l < layers; l++) {
           int n;
-          if (want_dist) n = l < 16 ? S.lp[(size_t)k * 16 + l] : ro.npasses;   // k_rate_alloc's choice (passes_for_lambda, on the device)
+          if (want_dist) n = l < 16 ? S.lp[(size_t)k * 16 + l] : ro.npasses;   // k_rate_alloc's choice (the PCRD loop, on the device)
           else n = l == layers - 1 ? ro.npasses : 0;                            // no slope anywhere: every pass in the last layer
           if (l > 0 && n < h.layer_passes[l - 1]) n = h.layer_passes[l - 1];
           h.layer_passes[l] = n;
@@ -792,29 +794,26 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
         for (int l = layers; l < 16; l++) h.layer_passes[l] = 0;   // (the records outlive the call: nothing stale beyond this plane's layers)
         h.first_layer = layers;
         for (int l = layers - 1; l >= 0; l--) if (h.layer_passes[l] > 0) h.first_layer = l;
+        const int last = h.layer_passes[layers - 1];               // (non-decreasing over the layers)
+        h.take = !want_dist ? ro.len : (last > 0 ? std::min(S.plen[(size_t)k * T1_MAXPASS + last - 1], ro.len) : 0);
       }
     }
+    n_pass_out += n_pass; n_sym_out += n_sym;
   };
   // Which bytes cross the bus.  Every pass of every block (lossless, or a last layer without a slope): the copy starts at once and the
   // rate allocation runs under it.  Layers that leave passes out (`want_dist`): the allocation first -- its inputs, the per-pass
   // lengths and distortions, are already here -- and only the bytes up to each block's last included pass are gathered and copied
   // (round 4: at 4K with the reference's slope a tenth of the 185 MB; the copy of all of them was 4 of one sequence's 27 ms).
   std::vector<uint64_t> n_pass(nthreads, 0), n_sym(nthreads, 0);
+  const auto tg0 = std::chrono::steady_clock::now();
   if (want_dist)
     S.pool->run([&](int tid) { for (int p = tid; p < np; p += nthreads) rate_alloc(p, n_pass[tid], n_sym[tid]); });
+  const auto tg1 = std::chrono::steady_clock::now();
   size_t gtotal = 0;
   for (int k = 0; k < ncb; k++) {
     const CbOut& ro = S.res[k];
     if (ro.overflow) return c->fail(QSVC_ERR_NOMEM, "code-block segment exceeds %d bytes", J2K_OUTCAP);
-    int take = ro.len;
-    if (want_dist) {
-      const HostCb& h = S.hcb[k];
-      const int layers = 16;
-      int last = 0;
-      for (int l = 0; l < layers; l++) last = h.layer_passes[l] > last ? h.layer_passes[l] : last;   // (non-decreasing; entries beyond the plane's layers are 0)
-      take = last > 0 ? S.plen[(size_t)k * T1_MAXPASS + last - 1] : 0;
-      if (take > ro.len) take = ro.len;
-    }
+    const int take = want_dist ? S.hcb[k].take : ro.len;
     goffs[k] = gtotal; glens[k] = take; gtotal += (size_t)take;
     S.hcb[k].data_off = goffs[k];
   }
@@ -825,6 +824,10 @@ static int j2k_encode_chunk(qsvc_ctx* c, const std::vector<PlaneSrc>& src, uint8
     size_t want = gtotal + gtotal / 4 + (1 << 20);
     if (hipHostMalloc((void**)&S.gath_h, want, hipHostMallocDefault) != hipSuccess) return c->fail(QSVC_ERR_NOMEM, "hipHostMalloc(%zu)", want);
     S.gath_h_cap = want;
+  }
+  if (!src[0].s16) {
+    c->host_time("host_alloc_fill", std::chrono::duration<double, std::milli>(tg1 - tg0).count());
+    c->host_time("host_gather_plan", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg1).count());
   }
   pf.begin(c, src[0].s16 ? "mv_gather" : "j2k_gather");
   HIPCHK(c, hipMemcpyAsync(S.offs_d.p, goffs.data(), (size_t)ncb * 8, hipMemcpyHostToDevice, c->st));
