@@ -561,6 +561,176 @@ __global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Irreversible 9/7, register-blocked form (round 4; what lossy coding runs -- k_dwt_tile<false> stays for the unit-test plane
+// output, for levels under 8 samples and behind QSVC_DWT_PK=0).  The general kernel's eight read-modify-write sweeps over the
+// staged tile (index arithmetic, three LDS reads and one write per lifted sample and step, a barrier after each) were 80 of its
+// 103 lane-operations per sample.  Here each direction is ONE pass with all four lifting steps in registers:
+//   vertical:   a lane owns 2 adjacent columns and 8 output rows: it loads the 15 rows [8 seg - 4, 8 seg + 11) of its pair
+//               straight from memory (one 2-byte / 8-byte load per row, all in flight; a row or column beyond the signal's
+//               end is read at its mirrored position -- whole-sample symmetric extension IS the restatement's boundary rule
+//               "the missing neighbour is replaced by the one on the other side", for all four steps, because the lifted
+//               extension stays symmetric), lifts them in registers and leaves 8 scaled rows in LDS.  68 pairs x 4 segments =
+//               272 tasks: the workgroup has five waves for this pass (42 VGPRs.  Quads of columns on 136 threads of 256 needed
+//               108 / 151 and left half of the workgroup idle: 1.33 ms per 33-picture 4K batch against 0.96 in this form and
+//               1.54 for k_dwt_tile<false>);
+//   horizontal: a lane owns 2 low and 2 high columns of the 4 rows of one stripe (as in k_dwt53_pk): three float4 reads per row
+//               (12 samples: 4 outputs + halo 4), the steps in registers, then quantiser, sign-magnitude and the Tier-1 words
+//               without any exchange between lanes.
+// One barrier, 17 KB of LDS (all accesses lane-consecutive: no odd stride needed).  Every lifted value is the same chain of
+// separately rounded products and sums as in the restatement (lift97), so the magnitudes are bit-identical.  What is left
+// (builds with one part removed, 4K batch): the atomics of the bit-plane counts 6 %, the correctly rounded divisions of the
+// quantiser 6 %, the LL stores 10 %: no single cost; 388 M vector wave-instructions at level 1 = 0.32 of its 0.66 ms at the issue peak.
+#define RB_Q (DT_NC / 4)            // quads of 4 columns per staged row
+#define RB_P (DT_NC / 2)            // pairs of columns per staged row
+#define RB_THREADS 320              // 4 x 68 (segment, pair) tasks of the vertical pass on five waves; the horizontal pass runs on four
+template <bool FROM_U8>
+__global__ void __launch_bounds__(RB_THREADS) k_dwt97_rb(DwtArgs a) {
+  constexpr int HALO = 4;
+  static_assert(DT_TH == 16 && DT_TW == 64 && DT_CL == 4 && DT_NC == 136, "task maps of k_dwt97_rb");
+  __shared__ float4 sV[2 * DT_TH * RB_Q];   // the tile's 32 output rows after the vertical lifting, columns [gc0, gc0 + 136)
+  const int tid = threadIdx.x;
+  int plane_i, tile_x, tile_y;
+  dwt_tile_of(a, plane_i, tile_x, tile_y);
+  const PlaneDesc pd = a.planes[plane_i];
+  int w = pd.W, h = pd.H;
+  for (int l = 0; l < a.lev; l++) { w = (w + 1) >> 1; h = (h + 1) >> 1; }
+  const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, hw = w >> 1, hh = h >> 1;
+  const int tx0 = tile_x * DT_TW, ty0 = tile_y * DT_TH;
+  if (tx0 >= lw || ty0 >= lh) return;
+  const int gc0 = 2 * tx0 - DT_CL, gr0 = 2 * ty0 - HALO;   // both even: local parity = global parity
+  const float invK = 1.0f / F97_K;
+  // ---- vertical lifting out of registers: thread = (pair of columns, segment of 8 output rows) -------------------------------
+  if (tid < 4 * RB_P) {
+    // A pair that leaves the signal at its left / right end is read at its mirrored position, which is again two adjacent samples
+    // in reverse order: ONE (unaligned) load per row in every case, no second code path.
+    typedef uint16_t __attribute__((aligned(1))) u16a1;
+    typedef unsigned long long __attribute__((aligned(4))) u64a4;
+    typedef const uint8_t __attribute__((address_space(1))) * gu8;
+    typedef const u16a1 __attribute__((address_space(1))) * gu16;
+    typedef const float __attribute__((address_space(1))) * gf1;
+    typedef const u64a4 __attribute__((address_space(1))) * gu64;
+    const gu8 u = (gu8)(uintptr_t)pd.src;
+    const gf1 lin = (gf1)(uintptr_t)((const float*)a.llin + (((a.lev - 1) & 1) ? pd.ll[1] : pd.ll[0]));
+    const int sstr = FROM_U8 ? pd.u8stride : dwt_ll_stride(w);
+    const int p = tid % RB_P, seg = tid / RB_P;
+    const int gc = gc0 + 2 * p, gr = gr0 + 8 * seg;   // rows gr .. gr + 14 feed the output rows gr + 4 .. gr + 11
+    const bool direct = gc >= 0 && gc + 1 < w;
+    int m = direct ? gc : dwt_reflect(gc + 1, w);     // the mirrored pair (gc + 1, gc) starts at the image of gc + 1
+    m = m > w - 2 ? w - 2 : m;                        // (farther out than the lifting reads: any two samples of the row)
+    float v[15][2];
+    if constexpr (FROM_U8) {
+      uint32_t raw[15];
+#pragma unroll
+      for (int j = 0; j < 15; j++) raw[j] = *(gu16)(u + (uint32_t)(dwt_reflect(gr + j, h) * sstr + m));   // (32-bit offsets from a uniform base: one address register per load)
+      __builtin_amdgcn_sched_barrier(0);   // all fifteen requested before the first is unpacked
+#pragma unroll
+      for (int j = 0; j < 15; j++) {
+        const float lo = (float)((int)(raw[j] & 255) - 128), hi = (float)((int)(raw[j] >> 8) - 128);
+        v[j][0] = direct ? lo : hi; v[j][1] = direct ? hi : lo;
+      }
+    } else {
+      unsigned long long raw[15];
+#pragma unroll
+      for (int j = 0; j < 15; j++) raw[j] = *(gu64)(lin + (uint32_t)(dwt_reflect(gr + j, h) * sstr + m));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 15; j++) {
+        const float lo = __uint_as_float((uint32_t)raw[j]), hi = __uint_as_float((uint32_t)(raw[j] >> 32));
+        v[j][0] = direct ? lo : hi; v[j][1] = direct ? hi : lo;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#pragma unroll
+      for (int j = 1; j <= 13; j += 2) v[j][k] = lift97<0>(v[j][k], v[j - 1][k], v[j + 1][k]);
+#pragma unroll
+      for (int j = 2; j <= 12; j += 2) v[j][k] = lift97<1>(v[j][k], v[j - 1][k], v[j + 1][k]);
+#pragma unroll
+      for (int j = 3; j <= 11; j += 2) v[j][k] = lift97<2>(v[j][k], v[j - 1][k], v[j + 1][k]);
+#pragma unroll
+      for (int j = 4; j <= 10; j += 2) v[j][k] = lift97<3>(v[j][k], v[j - 1][k], v[j + 1][k]);
+    }
+    float2* const sV2 = (float2*)sV;
+#pragma unroll
+    for (int j = 4; j < 12; j++) {   // low (even rows) * 1/K, high (odd rows) * K
+      const float s = (j & 1) ? F97_K : invK;
+      sV2[(8 * seg + j - 4) * RB_P + p] = make_float2(__fmul_rn(v[j][0], s), __fmul_rn(v[j][1], s));
+    }
+  }
+  __syncthreads();
+  if (tid >= 256) return;   // (after the only barrier)
+  // ---- horizontal lifting + output: lane = (row parity ry, stripe sidx of the tile, subband columns 2 cq and 2 cq + 1) ---------
+  const bool last = a.lev == a.L - 1;
+  const int cq = tid & 31, sidx = (tid >> 5) & 3, ry = __builtin_amdgcn_readfirstlane(tid >> 7);   // (uniform per wave: the subband records come by scalar loads)
+  const DwtSb* sbp = a.sbtab + (size_t)plane_i * a.nsb;
+  const int sbi = 1 + 3 * (a.L - 1 - a.lev);   // code-stream order: LL_L, then HL, LH, HH for d = L .. 1; this level is d = lev + 1
+  const DwtSb sbLo = sbp[ry ? sbi + 1 : 0], sbHi = sbp[ry ? sbi + 2 : sbi];   // low band of this row parity (LL / LH), high band (HL / HH): fetched before the stores below
+  float Lf[4][2], Hf[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const float4* row = sV + (2 * (4 * sidx + r) + ry) * RB_Q + cq;   // tile columns 4 cq .. 4 cq + 11; the outputs are 4 cq + 4 .. + 7
+    const float4 A = row[0], B = row[1], C = row[2];
+    float x[11] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z};
+#pragma unroll
+    for (int i = 1; i <= 9; i += 2) x[i] = lift97<0>(x[i], x[i - 1], x[i + 1]);
+#pragma unroll
+    for (int i = 2; i <= 8; i += 2) x[i] = lift97<1>(x[i], x[i - 1], x[i + 1]);
+#pragma unroll
+    for (int i = 3; i <= 7; i += 2) x[i] = lift97<2>(x[i], x[i - 1], x[i + 1]);
+#pragma unroll
+    for (int i = 4; i <= 6; i += 2) x[i] = lift97<3>(x[i], x[i - 1], x[i + 1]);
+    Lf[r][0] = __fmul_rn(x[4], invK); Hf[r][0] = __fmul_rn(x[5], F97_K);
+    Lf[r][1] = __fmul_rn(x[6], invK); Hf[r][1] = __fmul_rn(x[7], F97_K);
+  }
+  const int y = ty0 + 4 * sidx, x = tx0 + 2 * cq;
+  const int lane = tid & 63;
+  const int span2 = a.cbwl >= 6 ? 32 : (1 << (a.cbwl - 1));   // lanes (of 2 columns) per code-block
+#pragma unroll
+  for (int band = 0; band < 2; band++) {       // 0: the low band of this row parity (LL / LH), 1: the high band (HL / HH)
+    const int sub = 2 * ry + band;
+    if (sub == 0 && !last) continue;
+    const int sbh = ry ? hh : lh, sbw = band ? hw : lw;
+    const DwtSb sb = band ? sbHi : sbLo;
+    int acc = 0;
+    if (y < sbh && x < sbw) {
+      const bool two = x + 1 < sbw;            // else the second column lies beyond the subband
+      uint32_t q0[4], q1[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        q0[r] = q1[r] = 0u;
+        if (y + r < sbh) {
+          const float f0 = band ? Hf[r][0] : Lf[r][0], f1 = band ? Hf[r][1] : Lf[r][1];
+          const int m0 = (int)floorf(__fdiv_rn(fabsf(f0), sb.delta)), m1 = (int)floorf(__fdiv_rn(fabsf(f1), sb.delta));   // T.800 E.1
+          acc |= m0 | (two ? m1 : 0);
+          q0[r] = (uint32_t)(m0 & 0x7FFF) | ((f0 < 0.0f && m0) ? 0x8000u : 0u);
+          q1[r] = (uint32_t)(m1 & 0x7FFF) | ((f1 < 0.0f && m1) ? 0x8000u : 0u);
+        }
+      }
+      const int bx = x >> a.cbwl, by = y >> a.cbhl;
+      const size_t b = (size_t)sb.first_cb + (size_t)by * sb.gx + bx;
+      unsigned long long* m = a.mags + b * 1024 + (size_t)(((y & ((1 << a.cbhl) - 1)) >> 2) * 64 + (x & ((1 << a.cbwl) - 1)));
+      if (two) *(uint4*)m = make_uint4(q0[0] | q0[1] << 16, q0[2] | q0[3] << 16, q1[0] | q1[1] << 16, q1[2] | q1[3] << 16);
+      else *(uint2*)m = make_uint2(q0[0] | q0[1] << 16, q0[2] | q0[3] << 16);
+    }
+    // OR over the lanes of each code-block (DPP row shifts), one atomic per (block, stripe): the group's last lane speaks.  The OR
+    // keeps every bit of the magnitudes: a step size that needs more than 15 bit-planes is reported by the host, not truncated here.
+    const int v = wave_or_segments(acc, span2);
+    if ((lane & (span2 - 1)) == span2 - 1 && v && y < sbh) {
+      const int xl = tx0 + 2 * (cq | (span2 - 1));   // a column of this lane group's block (may lie beyond the subband: same block index)
+      atomicOr(&a.maxmag[sb.first_cb + (y >> a.cbhl) * sb.gx + ((xl < sbw ? xl : sbw - 1) >> a.cbwl)], v);
+    }
+  }
+  if (!last && ry == 0) {   // LL -> next level's input
+    float* lout = (float*)a.llout + ((a.lev & 1) ? pd.ll[1] : pd.ll[0]);
+    const int ostr = dwt_ll_stride(lw);
+    if (x < ostr)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (y + r < lh) *(float2*)(lout + (size_t)(y + r) * ostr + x) = make_float2(Lf[r][0], Lf[r][1]);   // columns in [lw, ostr) are padding, never read back
+  }
+}
+
 // Forward DWT of a batch of planes sharing L >= 1 levels.  mode 0: Tier-1 magnitudes; mode 1: Mallat plane (unit tests).
 // Workgroup list of every level of a batch (dwt_tile_of): host side.  first[l] .. first[l + 1] = level l's entries.
 void dwt_build_tilemap(const PlaneDesc* planes, int nplanes, int L, std::vector<uint32_t>& map, std::vector<int>& first) {
@@ -601,7 +771,10 @@ void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, in
     } else {
       // the packed 5/3 kernel: levels of at least 4 x 4 samples, code-blocks at least 8 wide (QSVC_DWT_PK=0: the general kernel)
       const bool pk = reversible && tuning().dwt_pk && minW >= 4 && minH >= 4 && cbw_log2 >= 3 && cbh_log2 >= 2;
+      // the register-blocked 9/7 kernel: levels of at least 8 x 8 samples (its mirrored reads reach 4 samples beyond either end)
+      const bool rb = !reversible && tuning().dwt_pk && minW >= 8 && minH >= 8 && cbw_log2 >= 3 && cbh_log2 >= 2;
       if (pk) { if (l == 0) hipLaunchKernelGGL(k_dwt53_pk<true>, grid, block, 0, st, a); else hipLaunchKernelGGL(k_dwt53_pk<false>, grid, block, 0, st, a); }
+      else if (rb) { if (l == 0) hipLaunchKernelGGL(k_dwt97_rb<true>, grid, dim3(RB_THREADS), 0, st, a); else hipLaunchKernelGGL(k_dwt97_rb<false>, grid, dim3(RB_THREADS), 0, st, a); }
       else if (reversible) { if (l == 0) DWT_LAUNCH(true, true, false); else DWT_LAUNCH(true, false, false); }
       else { if (l == 0) DWT_LAUNCH(false, true, false); else DWT_LAUNCH(false, false, false); }
     }

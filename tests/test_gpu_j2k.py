@@ -62,6 +62,28 @@ def test_codestream_equals_restatement_and_decodes(eng, kind, W, H, levels, reve
         assert J.psnr(d, y) > 50
 
 
+RB97_CASES = [("noise", 250, 190, 3, 64), ("pan_noise", 641, 363, 4, 64), ("edge", 133, 517, 3, 32), ("noise", 16, 16, 1, 16),
+              ("saturating", 1000, 72, 5, 64), ("pan_noise", 1920, 1080, 5, 64)]
+
+
+@pytest.mark.parametrize("kind,W,H,levels,cblk", RB97_CASES)
+def test_irreversible_streams_register_blocked_dwt(eng, kind, W, H, levels, cblk):
+    """The 9/7 path to Tier-1 runs k_dwt97_rb (one pass per direction, lifting in registers, the signal's ends mirrored) on every
+    level of at least 8 x 8 samples and the general tile kernel below that: odd widths and heights, picture ends inside a tile in
+    both directions, levels that switch kernels, narrow code-blocks, a 1080p plane.  Byte-identical to the restatement, and to the
+    general kernel alone (dwt_pk = 0)."""
+    from qsvc_amd import hip
+    y = _luma(kind, W, H, 11)
+    prm = hip.j2k_params(reversible=False, levels=levels, cblk=cblk)
+    cs = eng.j2k_encode_plane(y, prm)
+    assert cs == J.encode_plane(y, reversible=False, levels=levels, cblk=cblk)
+    try:
+        eng.set_tuning("dwt_pk", 0)
+        assert eng.j2k_encode_plane(y, prm) == cs
+    finally:
+        eng.set_tuning("dwt_pk", 1)
+
+
 def test_layers_slopes_and_options(eng):
     from qsvc_amd import hip
     y = _luma("pan", 352, 288, 42)
