@@ -377,6 +377,73 @@ __device__ __forceinline__ int dwt_reflect(int i, int n) {  // whole-sample symm
 }
 #define DP_NP (DT_NC / 2)           // column pairs per staged row
 #define DP_STR (DP_NP + 1)          // odd row stride (words)
+// The two subband records a wave of the packed / register-blocked kernels needs -- low band (LL / LH) and high band (HL / HH) of its
+// row parity -- fetched at kernel entry with a wave-uniform index: scalar loads, which do not count in vmcnt.  Loaded where they are
+// used (after the LL stores, between the bands' stores) they were vector loads whose `s_waitcnt vmcnt(0)` also waited for every
+// store issued before them: three store round trips in a row at the end of every wave.
+struct DwtSb2 { DwtSb lo, hi; };
+__device__ __forceinline__ DwtSb2 dwt_sb_pair(const DwtArgs& a, int plane_i, int tid) {
+  const int ry = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const DwtSb* sbp = a.sbtab + (size_t)plane_i * a.nsb;
+  const int sbi = 1 + 3 * (a.L - 1 - a.lev);   // code-stream order: LL_L, then HL, LH, HH for d = L .. 1; this level is d = lev + 1
+  DwtSb2 r;
+  r.lo = sbp[ry ? sbi + 1 : 0]; r.hi = sbp[ry ? sbi + 2 : sbi];
+  return r;
+}
+// Output of the packed 5/3 kernels: the lane holds, for the 4 rows of stripe sidx of row parity ry, the low (Lw) and high (Hw) band's
+// columns 2 cq, 2 cq + 1 of the tile as 16-bit pairs.
+__device__ __forceinline__ void dwt53_pk_output(const DwtArgs& a, const PlaneDesc& pd, int plane_i, int tid, bool last, int ry, int sidx, int cq, int tx0, int ty0,
+                                                int lw, int lh, int hw, int hh, const uint32_t (&Lw)[4], const uint32_t (&Hw)[4], const DwtSb2& sb2) {
+  const int kx = 2 * cq;
+  const int ky0 = 4 * sidx, y = ty0 + ky0, x = tx0 + kx;
+  // LL -> next level's input (int16 pairs)
+  if (!last && ry == 0) {
+    int16_t* lout = (int16_t*)a.llout + ((a.lev & 1) ? pd.ll[1] : pd.ll[0]);
+    const int ostr = dwt_ll_stride(lw);
+    if (x < ostr)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (y + r < lh) *(uint32_t*)(lout + (size_t)(y + r) * ostr + x) = Lw[r];   // columns in [lw, ostr) are padding, never read back
+  }
+  // HL / LH / HH (and LL of the last level): sign-magnitude, 4 rows of a stripe column per u64, into the block's Tier-1 words
+  const int lane = tid & 63;
+  const int span2 = a.cbwl >= 6 ? 32 : (1 << (a.cbwl - 1));   // lanes (of 2 columns) per code-block
+#pragma unroll
+  for (int band = 0; band < 2; band++) {       // 0: the low band of this row parity (LL / LH), 1: the high band (HL / HH)
+    const int sub = 2 * ry + band;
+    if (sub == 0 && !last) continue;
+    const int sbh = ry ? hh : lh, sbw = band ? hw : lw;
+    const DwtSb sb = band ? sb2.hi : sb2.lo;
+    int acc = 0;
+    if (y < sbh && x < sbw) {
+      uint32_t q[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        q[r] = y + r < sbh ? dp_signmag(band ? Hw[r] : Lw[r]) : 0u;
+        acc |= (int)(q[r] & 0x7FFF7FFFu);
+      }
+      if (x + 1 >= sbw) acc &= 0xFFFF;         // the second column lies beyond the subband
+      // column x: low halves of the four rows; column x + 1: high halves
+      const uint32_t c0lo = __builtin_amdgcn_perm(q[1], q[0], 0x05040100u), c0hi = __builtin_amdgcn_perm(q[3], q[2], 0x05040100u);
+      const uint32_t c1lo = __builtin_amdgcn_perm(q[1], q[0], 0x07060302u), c1hi = __builtin_amdgcn_perm(q[3], q[2], 0x07060302u);
+      const int bx = x >> a.cbwl, by = y >> a.cbhl;
+      const size_t b = (size_t)sb.first_cb + (size_t)by * sb.gx + bx;
+      unsigned long long* m = a.mags + b * 1024 + (size_t)(((y & ((1 << a.cbhl) - 1)) >> 2) * 64 + (x & ((1 << a.cbwl) - 1)));
+      // (one 16-byte store in every case: x is even, so the word of column x + 1 lies in the same block's row even where the subband ends
+      // at x -- a slot nobody reads, written as zero; two forms of the store cost three store instructions)
+      const bool two = x + 1 < sbw;
+      *(uint4*)m = make_uint4(c0lo, c0hi, two ? c1lo : 0u, two ? c1hi : 0u);
+    }
+    acc = (acc | (acc >> 16)) & 0x7FFF;
+    // OR over the lanes of each code-block (DPP row shifts), one atomic per (block, stripe): the group's last lane speaks
+    const int v = wave_or_segments(acc, span2);
+    if ((lane & (span2 - 1)) == span2 - 1 && v && y < sbh) {
+      const int xl = tx0 + 2 * (cq | (span2 - 1)) ;   // a column of this lane group's block (may lie beyond the subband: same block index)
+      atomicOr(&a.maxmag[sb.first_cb + (y >> a.cbhl) * sb.gx + ((xl < sbw ? xl : sbw - 1) >> a.cbwl)], v);
+    }
+  }
+}
+
 template <bool FROM_U8>
 __global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
   constexpr int HALO = 2, NR = 2 * DT_TH + 2 * HALO;   // 36 rows: [2 ty0 - 2, 2 ty0 + 34)
@@ -392,6 +459,7 @@ __global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
   const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, hw = w >> 1, hh = h >> 1;
   const int tx0 = tile_x * DT_TW, ty0 = tile_y * DT_TH;
   if (tx0 >= lw || ty0 >= lh) return;
+  const DwtSb2 sb2 = dwt_sb_pair(a, plane_i, tid);
   const int gc0 = 2 * tx0 - DT_CL, gr0 = 2 * ty0 - HALO;
   // ---- stage: 4 samples per thread-load; the signal's ends mirrored ----------------------------------------------------------
   {
@@ -513,52 +581,107 @@ __global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
     Lw[r] = dp_low(Es0, H0, Hs);
     Hw[r] = Hs;
   }
-  const int ky0 = 4 * sidx, y = ty0 + ky0, x = tx0 + kx;
-  // LL -> next level's input (int16 pairs)
-  if (!last && ry == 0) {
-    int16_t* lout = (int16_t*)a.llout + ((a.lev & 1) ? pd.ll[1] : pd.ll[0]);
-    const int ostr = dwt_ll_stride(lw);
-    if (x < ostr)
+  dwt53_pk_output(a, pd, plane_i, tid, last, ry, sidx, cq, tx0, ty0, lw, lh, hw, hh, Lw, Hw, sb2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Reversible 5/3, packed AND register-blocked (round 4, after k_dwt97_rb below showed what the staging pass costs): the vertical
+// lifting no longer reads a staged tile.  A lane owns one pair of columns (one packed word per row) and 8 output rows; it loads
+// the 11 rows [8 seg, 8 seg + 11) of its pair straight from memory -- one 2-byte (pictures) / 4-byte (int16 low bands) load per
+// row, all in flight, a row or pair beyond the signal's end at its mirrored position (the image of a pair is a pair in reverse
+// order) -- lifts them with the packed 16-bit operations and leaves 8 rows in LDS.  272 tasks on 256 threads: the first 16
+// threads also take the 16 tasks of the tile's last four column pairs, both tasks' loads requested together.  The horizontal
+// pass and the output are k_dwt53_pk's.  One barrier instead of two, 8.8 instead of 19.9 KB of LDS.
+template <bool FROM_U8>
+__global__ void __launch_bounds__(256) k_dwt53_rb(DwtArgs a) {
+  constexpr int HALO = 2;
+  static_assert(DT_TH == 16 && DT_TW == 64 && DT_CL == 4 && DT_NC == 136, "task maps of k_dwt53_rb");
+  __shared__ uint32_t sV[2 * DT_TH * DP_STR];   // the tile's 32 output rows after the vertical lifting (row t = tile row t + 2)
+  const int tid = threadIdx.x;
+  int plane_i, tile_x, tile_y;
+  dwt_tile_of(a, plane_i, tile_x, tile_y);
+  const PlaneDesc pd = a.planes[plane_i];
+  int w = pd.W, h = pd.H;
+  for (int l = 0; l < a.lev; l++) { w = (w + 1) >> 1; h = (h + 1) >> 1; }
+  const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, hw = w >> 1, hh = h >> 1;
+  const int tx0 = tile_x * DT_TW, ty0 = tile_y * DT_TH;
+  if (tx0 >= lw || ty0 >= lh) return;
+  const DwtSb2 sb2 = dwt_sb_pair(a, plane_i, tid);
+  const int gc0 = 2 * tx0 - DT_CL, gr0 = 2 * ty0 - HALO;
+  // ---- vertical lifting out of registers ---------------------------------------------------------------------------------------
+  {
+    typedef uint16_t __attribute__((aligned(1))) u16a1;
+    typedef uint32_t __attribute__((aligned(2))) u32a2;
+    typedef const uint8_t __attribute__((address_space(1))) * gu8;
+    typedef const u16a1 __attribute__((address_space(1))) * gu16;
+    typedef const int16_t __attribute__((address_space(1))) * gs16;
+    typedef const u32a2 __attribute__((address_space(1))) * gu32;
+    const gu8 u = (gu8)(uintptr_t)pd.src;
+    const gs16 lin = (gs16)(uintptr_t)((const int16_t*)a.llin + (((a.lev - 1) & 1) ? pd.ll[1] : pd.ll[0]));
+    const int sstr = FROM_U8 ? pd.u8stride : dwt_ll_stride(w);
+    const bool second = tid < 4 * DP_NP - 256;   // 16 threads
+    uint32_t raw[2][11];
+    bool direct[2];
+    int cp[2], sg[2];
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (y + r < lh) *(uint32_t*)(lout + (size_t)(y + r) * ostr + x) = Lw[r];   // columns in [lw, ostr) are padding, never read back
-  }
-  // HL / LH / HH (and LL of the last level): sign-magnitude, 4 rows of a stripe column per u64, into the block's Tier-1 words
-  const DwtSb* sbp = a.sbtab + (size_t)plane_i * a.nsb;
-  const int lane = tid & 63;
-  const int span2 = a.cbwl >= 6 ? 32 : (1 << (a.cbwl - 1));   // lanes (of 2 columns) per code-block
+    for (int t = 0; t < 2; t++) {
+      const int id = t ? 256 + (second ? tid : 0) : tid;
+      cp[t] = id % DP_NP; sg[t] = id / DP_NP;
+      const int gc = gc0 + 2 * cp[t], gr = gr0 + 8 * sg[t];
+      direct[t] = gc >= 0 && gc + 1 < w;
+      int m = direct[t] ? gc : dwt_reflect(gc + 1, w);   // the mirrored pair (gc + 1, gc) starts at the image of gc + 1
+      m = m > w - 2 ? w - 2 : m;                         // (farther out than the lifting reads: any two samples of the row)
+      if (t == 0 || second) {
 #pragma unroll
-  for (int band = 0; band < 2; band++) {       // 0: the low band of this row parity (LL / LH), 1: the high band (HL / HH)
-    const int sub = 2 * ry + band;
-    if (sub == 0 && !last) continue;
-    const int sbh = ry ? hh : lh, sbw = band ? hw : lw;
-    const DwtSb sb = sbp[sub == 0 ? 0 : 1 + 3 * (a.L - 1 - a.lev) + (sub == 1 ? 0 : (sub == 2 ? 1 : 2))];
-    int acc = 0;
-    if (y < sbh && x < sbw) {
-      uint32_t q[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        q[r] = y + r < sbh ? dp_signmag(band ? Hw[r] : Lw[r]) : 0u;
-        acc |= (int)(q[r] & 0x7FFF7FFFu);
+        for (int j = 0; j < 11; j++) {
+          const uint32_t o = (__umul24((unsigned)dwt_reflect(gr + j, h), (unsigned)sstr) + (unsigned)m);
+          if constexpr (FROM_U8) raw[t][j] = *(gu16)(u + o); else raw[t][j] = *(gu32)(lin + o);
+        }
       }
-      if (x + 1 >= sbw) acc &= 0xFFFF;         // the second column lies beyond the subband
-      // column x: low halves of the four rows; column x + 1: high halves
-      const uint32_t c0lo = __builtin_amdgcn_perm(q[1], q[0], 0x05040100u), c0hi = __builtin_amdgcn_perm(q[3], q[2], 0x05040100u);
-      const uint32_t c1lo = __builtin_amdgcn_perm(q[1], q[0], 0x07060302u), c1hi = __builtin_amdgcn_perm(q[3], q[2], 0x07060302u);
-      const int bx = x >> a.cbwl, by = y >> a.cbhl;
-      const size_t b = (size_t)sb.first_cb + (size_t)by * sb.gx + bx;
-      unsigned long long* m = a.mags + b * 1024 + (size_t)(((y & ((1 << a.cbhl) - 1)) >> 2) * 64 + (x & ((1 << a.cbwl) - 1)));
-      if (x + 1 < sbw) *(uint4*)m = make_uint4(c0lo, c0hi, c1lo, c1hi);
-      else *(uint2*)m = make_uint2(c0lo, c0hi);
     }
-    acc = (acc | (acc >> 16)) & 0x7FFF;
-    // OR over the lanes of each code-block (DPP row shifts), one atomic per (block, stripe): the group's last lane speaks
-    const int v = wave_or_segments(acc, span2);
-    if ((lane & (span2 - 1)) == span2 - 1 && v && y < sbh) {
-      const int xl = tx0 + 2 * (cq | (span2 - 1)) ;   // a column of this lane group's block (may lie beyond the subband: same block index)
-      atomicOr(&a.maxmag[sb.first_cb + (y >> a.cbhl) * sb.gx + ((xl < sbw ? xl : sbw - 1) >> a.cbwl)], v);
+    __builtin_amdgcn_sched_barrier(0);   // every load requested before the first is unpacked
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      if (t == 1 && !second) break;
+      uint32_t x[11];
+#pragma unroll
+      for (int j = 0; j < 11; j++) {
+        const uint32_t d = raw[t][j];
+        if constexpr (FROM_U8) x[j] = dp_sub(direct[t] ? __builtin_amdgcn_perm(0u, d, 0x0c010c00u) : __builtin_amdgcn_perm(0u, d, 0x0c000c01u), 0x00800080u);   // level shift
+        else x[j] = direct[t] ? d : __builtin_amdgcn_alignbit(d, d, 16);
+      }
+      uint32_t hv[5];
+#pragma unroll
+      for (int j = 0; j < 5; j++) hv[j] = dp_high(x[2 * j + 1], x[2 * j], x[2 * j + 2]);   // tile rows 8 seg + 1, 3, 5, 7, 9
+      uint32_t* o = sV + (8 * sg[t]) * DP_STR + cp[t];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        o[(2 * j) * DP_STR] = dp_low(x[2 * j + 2], hv[j], hv[j + 1]);   // tile rows 8 seg + 2, 4, 6, 8 (lows)
+        o[(2 * j + 1) * DP_STR] = hv[j + 1];                            // tile rows 8 seg + 3, 5, 7, 9 (highs)
+      }
     }
   }
+  __syncthreads();
+  // ---- horizontal lifting + output: lane = (parity ry, stripe s of the tile, 2 subband columns 2 cq, 2 cq + 1) -----------------
+  const bool last = a.lev == a.L - 1;
+  const int cq = tid & 31, sidx = (tid >> 5) & 3, ry = tid >> 7;
+  const int kx = 2 * cq;
+  uint32_t Lw[4], Hw[4];                       // per row: {col kx, col kx + 1} of the low / high band
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t* row = sV + (2 * (4 * sidx + r) + ry) * DP_STR + (1 + kx);   // pairs holding tile columns 2 + 2 kx .. 9 + 2 kx
+    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];
+    const uint32_t E0 = __builtin_amdgcn_perm(d1, d0, 0x05040100u), E1 = __builtin_amdgcn_perm(d3, d2, 0x05040100u);  // evens e-1, e | e+1, e+2
+    const uint32_t O0 = __builtin_amdgcn_perm(d1, d0, 0x07060302u), O1 = __builtin_amdgcn_perm(d3, d2, 0x07060302u);  // odds between them
+    const uint32_t Es0 = __builtin_amdgcn_alignbit(E1, E0, 16);            // evens e, e + 1 (the lows' centres)
+    const uint32_t Es1 = __builtin_amdgcn_alignbit(0u, E1, 16);            // even e + 2, -
+    const uint32_t H0 = dp_high(O0, E0, Es0);                              // highs right of evens e - 1, e
+    const uint32_t H1 = dp_high(O1, E1, Es1);                              // high right of even e + 1 (second lane unused)
+    const uint32_t Hs = __builtin_amdgcn_alignbit(H1, H0, 16);             // highs right of evens e, e + 1 = subband columns kx, kx + 1
+    Lw[r] = dp_low(Es0, H0, Hs);
+    Hw[r] = Hs;
+  }
+  dwt53_pk_output(a, pd, plane_i, tid, last, ry, sidx, cq, tx0, ty0, lw, lh, hw, hh, Lw, Hw, sb2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -598,6 +721,7 @@ __global__ void __launch_bounds__(RB_THREADS) k_dwt97_rb(DwtArgs a) {
   const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, hw = w >> 1, hh = h >> 1;
   const int tx0 = tile_x * DT_TW, ty0 = tile_y * DT_TH;
   if (tx0 >= lw || ty0 >= lh) return;
+  const DwtSb2 sb2 = dwt_sb_pair(a, plane_i, tid);
   const int gc0 = 2 * tx0 - DT_CL, gr0 = 2 * ty0 - HALO;   // both even: local parity = global parity
   const float invK = 1.0f / F97_K;
   // ---- vertical lifting out of registers: thread = (pair of columns, segment of 8 output rows) -------------------------------
@@ -622,7 +746,7 @@ __global__ void __launch_bounds__(RB_THREADS) k_dwt97_rb(DwtArgs a) {
     if constexpr (FROM_U8) {
       uint32_t raw[15];
 #pragma unroll
-      for (int j = 0; j < 15; j++) raw[j] = *(gu16)(u + (uint32_t)(dwt_reflect(gr + j, h) * sstr + m));   // (32-bit offsets from a uniform base: one address register per load)
+      for (int j = 0; j < 15; j++) raw[j] = *(gu16)(u + (__umul24((unsigned)dwt_reflect(gr + j, h), (unsigned)sstr) + (unsigned)m));   // (32-bit offsets from a uniform base: one address register per load)
       __builtin_amdgcn_sched_barrier(0);   // all fifteen requested before the first is unpacked
 #pragma unroll
       for (int j = 0; j < 15; j++) {
@@ -632,7 +756,7 @@ __global__ void __launch_bounds__(RB_THREADS) k_dwt97_rb(DwtArgs a) {
     } else {
       unsigned long long raw[15];
 #pragma unroll
-      for (int j = 0; j < 15; j++) raw[j] = *(gu64)(lin + (uint32_t)(dwt_reflect(gr + j, h) * sstr + m));
+      for (int j = 0; j < 15; j++) raw[j] = *(gu64)(lin + (__umul24((unsigned)dwt_reflect(gr + j, h), (unsigned)sstr) + (unsigned)m));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 15; j++) {
@@ -662,10 +786,7 @@ __global__ void __launch_bounds__(RB_THREADS) k_dwt97_rb(DwtArgs a) {
   if (tid >= 256) return;   // (after the only barrier)
   // ---- horizontal lifting + output: lane = (row parity ry, stripe sidx of the tile, subband columns 2 cq and 2 cq + 1) ---------
   const bool last = a.lev == a.L - 1;
-  const int cq = tid & 31, sidx = (tid >> 5) & 3, ry = __builtin_amdgcn_readfirstlane(tid >> 7);   // (uniform per wave: the subband records come by scalar loads)
-  const DwtSb* sbp = a.sbtab + (size_t)plane_i * a.nsb;
-  const int sbi = 1 + 3 * (a.L - 1 - a.lev);   // code-stream order: LL_L, then HL, LH, HH for d = L .. 1; this level is d = lev + 1
-  const DwtSb sbLo = sbp[ry ? sbi + 1 : 0], sbHi = sbp[ry ? sbi + 2 : sbi];   // low band of this row parity (LL / LH), high band (HL / HH): fetched before the stores below
+  const int cq = tid & 31, sidx = (tid >> 5) & 3, ry = __builtin_amdgcn_readfirstlane(tid >> 7);   // (uniform per wave)
   float Lf[4][2], Hf[4][2];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -691,7 +812,7 @@ __global__ void __launch_bounds__(RB_THREADS) k_dwt97_rb(DwtArgs a) {
     const int sub = 2 * ry + band;
     if (sub == 0 && !last) continue;
     const int sbh = ry ? hh : lh, sbw = band ? hw : lw;
-    const DwtSb sb = band ? sbHi : sbLo;
+    const DwtSb sb = band ? sb2.hi : sb2.lo;
     int acc = 0;
     if (y < sbh && x < sbw) {
       const bool two = x + 1 < sbw;            // else the second column lies beyond the subband
@@ -710,8 +831,7 @@ __global__ void __launch_bounds__(RB_THREADS) k_dwt97_rb(DwtArgs a) {
       const int bx = x >> a.cbwl, by = y >> a.cbhl;
       const size_t b = (size_t)sb.first_cb + (size_t)by * sb.gx + bx;
       unsigned long long* m = a.mags + b * 1024 + (size_t)(((y & ((1 << a.cbhl) - 1)) >> 2) * 64 + (x & ((1 << a.cbwl) - 1)));
-      if (two) *(uint4*)m = make_uint4(q0[0] | q0[1] << 16, q0[2] | q0[3] << 16, q1[0] | q1[1] << 16, q1[2] | q1[3] << 16);
-      else *(uint2*)m = make_uint2(q0[0] | q0[1] << 16, q0[2] | q0[3] << 16);
+      *(uint4*)m = make_uint4(q0[0] | q0[1] << 16, q0[2] | q0[3] << 16, two ? q1[0] | q1[1] << 16 : 0u, two ? q1[2] | q1[3] << 16 : 0u);   // (one store: see dwt53_pk_output)
     }
     // OR over the lanes of each code-block (DPP row shifts), one atomic per (block, stripe): the group's last lane speaks.  The OR
     // keeps every bit of the magnitudes: a step size that needs more than 15 bit-planes is reported by the host, not truncated here.
@@ -769,11 +889,12 @@ void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, in
       if (reversible) { if (l == 0) DWT_LAUNCH(true, true, true); else DWT_LAUNCH(true, false, true); }
       else { if (l == 0) DWT_LAUNCH(false, true, true); else DWT_LAUNCH(false, false, true); }
     } else {
-      // the packed 5/3 kernel: levels of at least 4 x 4 samples, code-blocks at least 8 wide (QSVC_DWT_PK=0: the general kernel)
+      // the packed 5/3 kernels: levels of at least 4 x 4 samples, code-blocks at least 8 wide (QSVC_DWT_PK=0: the general kernel, 2: the staged packed kernel)
       const bool pk = reversible && tuning().dwt_pk && minW >= 4 && minH >= 4 && cbw_log2 >= 3 && cbh_log2 >= 2;
       // the register-blocked 9/7 kernel: levels of at least 8 x 8 samples (its mirrored reads reach 4 samples beyond either end)
       const bool rb = !reversible && tuning().dwt_pk && minW >= 8 && minH >= 8 && cbw_log2 >= 3 && cbh_log2 >= 2;
-      if (pk) { if (l == 0) hipLaunchKernelGGL(k_dwt53_pk<true>, grid, block, 0, st, a); else hipLaunchKernelGGL(k_dwt53_pk<false>, grid, block, 0, st, a); }
+      if (pk && tuning().dwt_pk == 2) { if (l == 0) hipLaunchKernelGGL(k_dwt53_pk<true>, grid, block, 0, st, a); else hipLaunchKernelGGL(k_dwt53_pk<false>, grid, block, 0, st, a); }   // (the staged form, for comparison)
+      else if (pk) { if (l == 0) hipLaunchKernelGGL(k_dwt53_rb<true>, grid, block, 0, st, a); else hipLaunchKernelGGL(k_dwt53_rb<false>, grid, block, 0, st, a); }
       else if (rb) { if (l == 0) hipLaunchKernelGGL(k_dwt97_rb<true>, grid, dim3(RB_THREADS), 0, st, a); else hipLaunchKernelGGL(k_dwt97_rb<false>, grid, dim3(RB_THREADS), 0, st, a); }
       else if (reversible) { if (l == 0) DWT_LAUNCH(true, true, false); else DWT_LAUNCH(true, false, false); }
       else { if (l == 0) DWT_LAUNCH(false, true, false); else DWT_LAUNCH(false, false, false); }
