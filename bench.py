@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--host-cores", type=int, default=0,
                     help="pin this rank to K host cores (cores [local_rank*K, local_rank*K + K)) before any GPU call: what one rank of an "
                          "8-rank node gets of the host (Tier-2, launches) -- e.g. --gpus 1 --host-cores 32 on a 256-core host")
+    ap.add_argument("--gops", type=int, default=None,
+                    help="GOPs per sequence (the reference's --GOPs: pictures = GOPs * 2^(TRLs-1) + 1; default 2 = the 16-picture window of "
+                         "BASELINE config 3); longer sequences make every temporal level's launch and the texture batch fatter")
     ap.add_argument("--sessions", type=int, default=None,
                     help="17-picture sequences encoded concurrently per GPU (one encoder context + host thread each); "
                          "a step = every session finishing one whole encode")
@@ -229,6 +232,8 @@ def main():
     global W, H, TRLS, GOPS, BS, S0, SRLS, PMC_FILE
     cfg = CONFIGS[args.config]
     W, H, TRLS, GOPS, BS, S0, SRLS, PMC_FILE = cfg["W"], cfg["H"], cfg["TRLS"], cfg["GOPS"], cfg["BS"], cfg["S0"], cfg["SRLS"], cfg["pmc"]
+    if args.gops:
+        GOPS = args.gops
     if args.reversible is None:
         args.reversible = cfg["reversible"]
     if args.sessions is None:
@@ -745,7 +750,7 @@ def main():
         streaming = None
         if iso:
             groups = {
-                dwt_key: ["k_dwt_tile", "k_dwt53_pk", "k_t1_nbps"],
+                dwt_key: ["k_dwt_tile", "k_dwt53_pk", "k_dwt53_rb", "k_dwt97_rb", "k_t1_nbps"],
                 "predict": ["k_pred_", "k_mv_hist", "k_chroma_up"],
                 "update": ["k_upd_"],
                 "me_search_l0": ["k_me_piece<unsigned char", "k_me_search8<unsigned char", "k_me_search<unsigned char"],
