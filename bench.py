@@ -329,7 +329,7 @@ def main():
     comp = comps[0]
     P = comp.pictures
     # weak scaling: rank r holds pictures [16r, 16r+16] of one long synthetic sequence (boundary picture shared)
-    G = cfg["G"]
+    G = GOPS * 2 ** (TRLS - 1)   # pictures a rank's window advances by (cfg["G"] at the default --gops)
     assert P == G + 1
     seq_local = make_clip(args.clip, G * world + 1, W, H, 43)[G * rank:G * rank + P].copy()
 
@@ -607,7 +607,7 @@ def main():
             decode_extra = {"error": repr(ex)}
 
     # ---- extras of the default line (rank 0, one GPU, config 3): the drop-in executable including disk I/O, and BASELINE's configs[3] ----
-    cli_wall, config4 = None, None
+    cli_wall, config4, longer = None, None, None
     if rank == 0 and world == 1 and args.config == 3 and not args.no_cli:
         # SURVEY.md 8d(1) "including disk I/O": `bin/mcj2k compress` on this very configuration, from low_0 on disk to the code-stream
         # files, as a fresh process each time (interpreter start, library load and GPU initialisation included, as for the reference's
@@ -656,6 +656,18 @@ def main():
             config4["sequences_in_flight"] = 1
         except Exception as ex:
             config4 = {"error": repr(ex)}
+        # The same configuration on longer sequences (the reference's --GOPs: one video of several GOPs instead of many two-GOP
+        # clips): every temporal level's launch and the texture batch are three times fatter, so the launches that are one round of
+        # workgroups long (levels 2-3 of the MCTF, levels 2-4 of the DWT) weigh less.  Reported beside `value`, never in it.
+        try:
+            rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "3", "--sessions", "4", "--gops", "6", "--steps", "10", "--warmup", "3",
+                                 "--no-cpu-baseline", "--no-decode", "--no-cli", "--no-config4", "--no-iso"], capture_output=True, text=True, timeout=600)
+            lg = json.loads(rr.stdout.strip().splitlines()[-1])
+            longer = {"value": lg["value"], "unit": lg["unit"], "ms_per_step": lg["ms_per_step"], "steps": lg["steps"], "warmup": lg["warmup"],
+                      "sequences_in_flight_per_gpu": 4, "gops_per_sequence": 6, "pictures_per_step_total": lg["config"]["pictures_per_step_total"],
+                      "workload": lg["config"]["workload"]}
+        except Exception as ex:
+            longer = {"error": repr(ex)}
 
     if rank == 0:
         pics_total = (G * world + 1) * S   # unique pictures per step: S independent sequences of G*N+1 pictures
@@ -812,6 +824,8 @@ def main():
             line["cli_wall_s"] = cli_wall
         if config4 is not None:
             line["config4"] = config4
+        if longer is not None:
+            line["longer_sequences"] = longer
         line["kernels_note"] = ("kernels{} are HIP-event durations on session 0's stream inside the timed region; with several sessions in "
                                 "flight kernels of different sessions overlap, so they do not sum to ms_per_step; host_stages{} are wall-clock "
                                 "milliseconds of the CPU stages of session 0 (rate allocation, Tier-2)")

@@ -514,13 +514,15 @@ __global__ void __launch_bounds__(256) k_upd_level_sc(UpdArgs a, int ncxa, int n
   const int np = a.g.nB + 1;
   int b = blockIdx.x;
   const int nchroma = ncxa * ncya * np * 2, nluma = nlx * nly * np;
+  // the border cells first: a cell's ordered gather over every block within reach is the launch's longest chain of dependent loads;
+  // started first it runs beside the tiles, at the end of the grid it was the launch's tail
+  const int nbb = (2 * a.g.W + 2 * (a.g.H - 2) + 255) / 256;
+  if (b < nbb * np) { upd_border_body(a, (b % nbb) * 256 + threadIdx.x, b / nbb); return; }
+  b -= nbb * np;
   if (b < nchroma) { upd_chroma_body<0, true>(a, smem, b % ncxa, (b / ncxa) % ncya, b / (ncxa * ncya), threadIdx.x); return; }
   b -= nchroma;
   if (b < nluma) { upd_luma_tile(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x); return; }
   b -= nluma;
-  const int nbb = (2 * a.g.W + 2 * (a.g.H - 2) + 255) / 256;
-  if (b < nbb * np) { upd_border_body(a, (b % nbb) * 256 + threadIdx.x, b / nbb); return; }
-  b -= nbb * np;
   const int ncopy = cg.nWA + cg.nWB;
   upd_chroma_copy(a, cg, b % ncopy, b / ncopy, threadIdx.x);
 }

@@ -6,7 +6,13 @@ from qsvc_amd.synth import make_clip
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 W, H, bs, P, TRLs = (1920, 1080, 8, 17, 4) if cfg == "cfg3" else (3840, 2160, 16, 33, 5)
-clip = make_clip("pan_noise", P, W, H, 43)
+kind = sys.argv[3] if len(sys.argv) > 3 else "pan_noise"
+if kind == "static":   # one picture + fresh noise per picture: zero motion, no displaced run leaves the picture
+    base = make_clip("pan_noise", 1, W, H, 43)[0].astype(np.int16)
+    rng = np.random.default_rng(1)
+    clip = np.stack([np.clip(base + rng.integers(-2, 3, size=base.shape), 0, 255).astype(np.uint8) for _ in range(P)])
+else:
+    clip = make_clip(kind, P, W, H, 43)
 e = hip.Engine(0)
 e.seq_config(W, H)
 e.put_frames(hip.LOW, 0, clip)
