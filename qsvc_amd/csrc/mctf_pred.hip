@@ -187,43 +187,32 @@ bool pred_run_applies(const PredArgs& a) {
   return !a.odd_out && !a.margin && g.ov < 2 && g.bs % 8 == 0 && (g.bs & (g.bs - 1)) == 0 && g.W % 8 == 0 && g.H % 2 == 0 && g.H % g.bs == 0 && g.W % g.bs == 0 &&
          g.H >= 8 && g.W >= 16;
 }
-// One launch per level: the motion role, then the chroma tiles (the longer workgroups), then the luma strips; a workgroup's role
-// follows from its index.  256 threads, 32 KB of LDS (the luma histograms; a chroma tile needs 8.4 KB of it).
+// One launch per level: the chroma tiles (the longer workgroups) first, then the luma strips; a workgroup's role follows from
+// its index.  256 threads, 32 KB of LDS (the luma histograms; a chroma tile needs 8.4 KB of it).
 __global__ void __launch_bounds__(256) k_pred_level(PredArgs a, int ncx, int ncy, int nlx, int nly, int nmh) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 256 * PL_K * 4];
   static_assert(sizeof(smem) >= PCT_SMEM_BYTES, "chroma tile fits");
   int b = blockIdx.x;
-  const int nchroma = ncx * ncy * a.g.nB * 2, nluma = nlx * nly * a.g.nB, nmotion = nmh * a.g.nB;
-  // FIRST role (its workgroups are the launch's longest chains of dependent round trips, so they start first and the tiles run beside
-  // them -- at the end of the grid they were the launch's tail): the histogram of the motion components + 128 (decorrelate.cpp:805-812),
-  // nmh workgroups per picture, which also copy their share of motion_t into motion_filtered_t.  A thread's elements are requested
-  // together, eight at a time.
-  if (b < nmotion) {
-    const int i = b / nmh, part = b % nmh, tid = threadIdx.x;
-    unsigned* h = (unsigned*)smem;
-    h[tid] = 0;
-    __syncthreads();
-    const size_t per_pic = (size_t)4 * a.g.BY * a.g.BX, step = (size_t)nmh * 256;
-    const int16_t* m = a.mv + (size_t)i * per_pic;
-    for (size_t k0 = (size_t)part * 256 + tid; k0 < per_pic; k0 += 8 * step) {
-      int16_t v[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) v[q] = k0 + q * step < per_pic ? m[k0 + q * step] : (int16_t)0;
-#pragma unroll
-      for (int q = 0; q < 8; q++)
-        if (k0 + q * step < per_pic) {
-          atomicAdd(&h[(v[q] + 128) & 255], 1u);
-          if (a.mv_copy) a.mv_copy[(size_t)i * per_pic + k0 + q * step] = v[q];
-        }
-    }
-    __syncthreads();
-    if (h[tid]) atomicAdd(&a.hist[((size_t)i * 3 + 2) * 256 + tid], h[tid]);
-    return;
-  }
-  b -= nmotion;
+  const int nchroma = ncx * ncy * a.g.nB * 2, nluma = nlx * nly * a.g.nB;
   if (b < nchroma) { pred_chroma_body(a, smem, b % ncx, (b / ncx) % ncy, b / (ncx * ncy), threadIdx.x); return; }
   b -= nchroma;
-  pred_luma_body(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x & 63, threadIdx.x >> 6);
+  if (b < nluma) { pred_luma_body(a, smem, b % nlx, (b / nlx) % nly, b / (nlx * nly), threadIdx.x & 63, threadIdx.x >> 6); return; }
+  b -= nluma;
+  // last role: the histogram of the motion components + 128 (decorrelate.cpp:805-812), nmh workgroups per picture, which also
+  // copy their share of motion_t into motion_filtered_t
+  const int i = b / nmh, part = b % nmh, tid = threadIdx.x;
+  unsigned* h = (unsigned*)smem;
+  h[tid] = 0;
+  __syncthreads();
+  const size_t per_pic = (size_t)4 * a.g.BY * a.g.BX;
+  const int16_t* m = a.mv + (size_t)i * per_pic;
+  for (size_t k = (size_t)part * 256 + tid; k < per_pic; k += (size_t)nmh * 256) {
+    const int16_t v = m[k];
+    atomicAdd(&h[(v + 128) & 255], 1u);
+    if (a.mv_copy) a.mv_copy[(size_t)i * per_pic + k] = v;
+  }
+  __syncthreads();
+  if (h[tid]) atomicAdd(&a.hist[((size_t)i * 3 + 2) * 256 + tid], h[tid]);
 }
 void launch_predict_run(hipStream_t st, const PredArgs& a) {
   const LevelGeom& g = a.g;
