@@ -87,7 +87,7 @@ __device__ __forceinline__ void pred_luma_body(const PredArgs& a, uint8_t* smem,
 }
 
 // ---------------------------------------------------------------------------------------------
-// chroma: a workgroup produces a 64 x 14 tile of one half-resolution component.
+// chroma: a workgroup produces a 64 x 16 tile of one half-resolution component.
 __device__ __forceinline__ void pred_chroma_body(const PredArgs& a, uint8_t* smem, const int bx_, const int by_, const int bz_, const int tid) {
   uint8_t (*sP)[PCT_FW] = (uint8_t (*)[PCT_FW])smem;
   uint32_t (*sL)[PCT_W / 2] = (uint32_t (*)[PCT_W / 2])(smem + PCT_SP_BYTES);  // row-pass lows, two columns per word

@@ -89,11 +89,13 @@ __device__ __forceinline__ uint32_t residue4(uint32_t o, uint32_t p) {
 
 
 // ---------------------------------------------------------------------------------------------
-// chroma tile: a workgroup of PCT_T threads produces 64 x 14 half-resolution samples out of their full-resolution footprint
+// chroma tile: a workgroup of PCT_T threads produces 64 x 16 half-resolution samples out of their full-resolution footprint
 #define PCT_W 64                      // outputs per tile row
 #ifndef PCT_H
-#define PCT_H 14                      // output rows per tile
+#define PCT_H 16                      // output rows per tile (14 until round 4: 1080p chroma then needed 585 tiles per plane, 9.1 per CU at the deepest
+                                      // level where 8 fit; 510 tiles are one round: predict -4 %, at 4K predict -7 %, update -5 %).  At most 16: a thread per 4 outputs
 #endif
+static_assert(PCT_H * 16 <= 256 && (2 * PCT_H) % 4 == 0, "a thread per 4 outputs of the tile; the footprint starts two rows above a multiple of 4");
 #define PCT_FH (2 * PCT_H + 3)        // full-resolution rows 2 j0 - 2 .. 2 j0 + 2 PCT_H
 #define PCT_FW (2 * PCT_W + 16)       // full-resolution columns 2 i0 - 8 .. 2 i0 + 2 PCT_W + 7, in runs of 8
 #define PCT_SP_BYTES (((PCT_FH * PCT_FW) + 15) & ~15)          // the footprint (bytes) ...

@@ -291,7 +291,7 @@ __device__ __forceinline__ void upd_zero(uint8_t* p, int bytes, int tid) {   // 
 }
 
 // ---------------------------------------------------------------------------------------------
-// chroma: one 64 x 14 tile of one stored component per workgroup.  Tiles no update can reach (Q3: sources exist in the top-left
+// chroma: one 64 x 16 tile of one stored component per workgroup.  Tiles no update can reach (Q3: sources exist in the top-left
 // quadrant only) and pictures without a contributing B picture keep the stored chroma: analysis(synthesis(u)) == u exactly.
 template <int NX, bool SC>
 __device__ __forceinline__ void upd_chroma_body(const UpdArgs& a, uint8_t* smem, const int bx_, const int by_, const int bz_, const int tid) {
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(256) k_upd_level(UpdArgs a, int ncx, int ncy, 
   upd_border_body(a, (b % nbb) * 256 + threadIdx.x, b / nbb);
 }
 
-// The stored chroma no update can reach (Q3: three quarters of every plane) is a plain copy; one workgroup per 64 x 14 tile made
+// The stored chroma no update can reach (Q3: three quarters of every plane) is a plain copy; one workgroup per tile made
 // that copy cost its workgroup dispatches (about a nanosecond each, 8 000 per launch at 1080p).  Here the plane outside the
 // rectangle of active tiles [0, ya) x [0, xa) is two regions -- A: rows ya.., contiguous; B: rows 0..ya, columns xa.. -- copied 16 KB
 // per workgroup.
