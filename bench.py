@@ -640,14 +640,14 @@ def main():
             cli_wall = {"error": repr(ex)}
     if rank == 0 and world == 1 and args.config == 3 and not args.no_config4:
         # BASELINE.json configs[3] ("4K 32-frame GOP, 9/7 irreversible, 4 temporal + 5 spatial levels, HBM roofline run"): ONE 33-picture
-        # sequence alone on the chip, 1 warm-up + 3 timed encodes, with its isolated streaming-kernel table -- in a child process (the
+        # sequence alone on the chip, 2 warm-up + 4 timed encodes (with one warm-up the first timed encode still ran 15 % long), with its isolated streaming-kernel table -- in a child process (the
         # globals of this one describe config 3), after this one has released its contexts
         import subprocess
         for e in engs + [m for m in mv_engs if m is not None]:
             e.close()
         engs, mv_engs = [], []
         try:
-            rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "4", "--sessions", "1", "--steps", "3", "--warmup", "1",
+            rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "4", "--sessions", "1", "--steps", "4", "--warmup", "2",
                                  "--no-cpu-baseline", "--no-decode", "--no-cli", "--no-config4"], capture_output=True, text=True, timeout=900)
             c4 = json.loads(rr.stdout.strip().splitlines()[-1])
             config4 = {k: c4[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "codeblocks_per_s", "roofline",
