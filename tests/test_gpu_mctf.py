@@ -280,6 +280,40 @@ def test_halo_split_equals_whole_sequence(eng):
         e2.close()
 
 
+def test_halo_three_shards_the_middle_one_imports_on_both_sides(eng):
+    """Six of the eight ranks of a node have a neighbour on either side: a middle shard exports its first and its last B picture's
+    record and takes in one from each side before its update.  Three shards of one GPU, two temporal levels == the whole sequence."""
+    from qsvc_amd import hip
+    W, H, bs, S = 192, 128, 16, 4
+    clip = make_clip("pan_noise", 25, W, H, 78)
+    whole = run_levels(eng, clip, W, H, 3, bs, S, keep_prediction=False)
+    es = [eng, hip.Engine(0), hip.Engine(0)]
+    try:
+        for k, e in enumerate(es):
+            e.seq_config(W, H)
+            e.put_frames(hip.LOW, 0, clip[8 * k:8 * k + 9])
+        for t, n in ((1, 9), (2, 5)):                # level t analyses n pictures of every shard
+            for e in es:
+                e.motion_estimate(t, n, bs, S << (t - 1))
+                e.decorrelate(t, n, bs, S << (t - 1))
+            rec = [(e.halo_export(t, 0, bs), e.halo_export(t, 1, bs)) for e in es]   # (to the left, to the right)
+            for k, e in enumerate(es):
+                e.halo_import(t, 0, rec[k - 1][1] if k > 0 else None)
+                e.halo_import(t, 1, rec[k + 1][0] if k < 2 else None)
+                e.update(t, n, bs, 0.25)
+            lows = [e.get_frames(hip.LOW, t, 0, (n + 1) // 2) for e in es]
+            highs = [e.get_frames(hip.HIGH, t, 0, n // 2) for e in es]
+            np.testing.assert_array_equal(lows[0][-1], lows[1][0], err_msg=f"level {t}: boundary picture 0 | 1")
+            np.testing.assert_array_equal(lows[1][-1], lows[2][0], err_msg=f"level {t}: boundary picture 1 | 2")
+            np.testing.assert_array_equal(np.concatenate([lows[0], lows[1][1:], lows[2][1:]]), whole[t - 1]["low"])
+            np.testing.assert_array_equal(np.concatenate(highs), whole[t - 1]["high"])
+        for e in es:
+            e.halo_import(1, 0, None); e.halo_import(1, 1, None); e.halo_import(2, 0, None); e.halo_import(2, 1, None)
+    finally:
+        for e in es[1:]:
+            e.close()
+
+
 def test_degenerate_picture_counts(eng, oracle):
     """pictures = 1 (no B picture: low_t is a copy), an even count (the last even picture is missing: refused, never
     read out of bounds), and the minimum 3."""

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the host-side GOP sharding (qsvc_amd/sharding.py + pipeline.Compressor.analyze)
+"""CPU, world_size 2 (and 4: ranks with two neighbours) over gloo: the host-side GOP sharding (qsvc_amd/sharding.py + pipeline.Compressor.analyze)
 with a CPU test double as the engine.  Two shards with exchanged boundary records must reproduce the
 single-piece analysis of the whole sequence, and agree on the shared boundary picture."""
 import os
@@ -35,24 +35,27 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_two_shards_equal_whole_sequence(oracle, tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_shards_equal_whole_sequence(oracle, tmp_path, world):
+    """world 4: ranks 1 and 2 have a neighbour on either side (two sends and two receives per level in one batch), which is what six
+    of the eight ranks of a node do."""
     from qsvc_amd.synth import make_clip
     worker = tmp_path / "worker.py"
     worker.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(worker), ROOT, str(tmp_path)], env=dict(env, RANK=str(r))) for r in range(2)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29541 + 10 * world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(worker), ROOT, str(tmp_path)], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     W, H = 96, 64
-    clip = make_clip("pan_noise", 9, W, H, 9)
-    whole = oracle.analyze(clip, W, H, 3, 16, 4)   # 9 pictures: levels of 9 and 5 pictures
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    np.testing.assert_array_equal(r0["low1"][-1], r1["low1"][0], err_msg="level-1 boundary picture differs")
-    np.testing.assert_array_equal(r0["low2"][-1], r1["low2"][0], err_msg="level-2 boundary picture differs")
-    np.testing.assert_array_equal(np.concatenate([r0["low1"], r1["low1"][1:]]), whole[0]["low"])
-    np.testing.assert_array_equal(np.concatenate([r0["high1"], r1["high1"]]), whole[0]["high"])
-    np.testing.assert_array_equal(np.concatenate([r0["low2"], r1["low2"][1:]]), whole[1]["low"])
-    np.testing.assert_array_equal(np.concatenate([r0["high2"], r1["high2"]]), whole[1]["high"])
+    clip = make_clip("pan_noise", 4 * world + 1, W, H, 9)
+    whole = oracle.analyze(clip, W, H, 3, 16, 4)   # world 2: 9 pictures, levels of 9 and 5 pictures
+    rk = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in range(world - 1):
+        np.testing.assert_array_equal(rk[r]["low1"][-1], rk[r + 1]["low1"][0], err_msg=f"level-1 boundary picture {r} | {r + 1} differs")
+        np.testing.assert_array_equal(rk[r]["low2"][-1], rk[r + 1]["low2"][0], err_msg=f"level-2 boundary picture {r} | {r + 1} differs")
+    for lv, key in ((0, "1"), (1, "2")):
+        np.testing.assert_array_equal(np.concatenate([rk[0]["low" + key]] + [z["low" + key][1:] for z in rk[1:]]), whole[lv]["low"])
+        np.testing.assert_array_equal(np.concatenate([z["high" + key] for z in rk]), whole[lv]["high"])
 
 
 WORKER_BATCH = r'''
