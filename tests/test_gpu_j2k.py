@@ -63,7 +63,7 @@ def test_codestream_equals_restatement_and_decodes(eng, kind, W, H, levels, reve
 
 
 RB97_CASES = [("noise", 250, 190, 3, 64), ("pan_noise", 641, 363, 4, 64), ("edge", 133, 517, 3, 32), ("noise", 16, 16, 1, 16),
-              ("saturating", 1000, 72, 5, 64), ("pan_noise", 1920, 1080, 5, 64)]
+              ("saturating", 1000, 72, 5, 64), ("pan_noise", 1920, 1080, 5, 64), ("pan_noise", 3840, 2160, 5, 64)]   # the last: a luma plane of BASELINE config 4
 
 
 @pytest.mark.parametrize("kind,W,H,levels,cblk", RB97_CASES)
