@@ -592,22 +592,44 @@ __global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
 // order) -- lifts them with the packed 16-bit operations and leaves 8 rows in LDS.  272 tasks on 256 threads: the first 16
 // threads also take the 16 tasks of the tile's last four column pairs, both tasks' loads requested together.  The horizontal
 // pass and the output are k_dwt53_pk's.  One barrier instead of two, 8.8 instead of 19.9 KB of LDS.
-template <bool FROM_U8>
-__global__ void __launch_bounds__(256) k_dwt53_rb(DwtArgs a) {
+// NT tiles per workgroup (round 4, last step): the two tiles' loads are requested together, so a wave has twice the bytes in flight for
+// the same fixed latencies (its scalar set-up, one memory round trip, one barrier, the stores' issue) -- these kernels wait on round
+// trips at full occupancy, not on issue slots.  NT = 2 on levels of at least DWT_RB2_MIN_TILES tiles (below that a launch is one or two
+// rounds of workgroups and fewer, longer workgroups only lengthen it); the tiles are consecutive entries of the level's tile list and
+// need not be neighbours.
+#define DWT_RB2_MIN_TILES 6144
+struct Rb53Tile {
+  PlaneDesc pd;
+  DwtSb2 sb2;
+  int plane_i, w, h, lw, lh, hw, hh, tx0, ty0;
+};
+template <bool FROM_U8, int NT>
+__global__ void __launch_bounds__(256) k_dwt53_rb(DwtArgs a, int ntiles) {
   constexpr int HALO = 2;
   static_assert(DT_TH == 16 && DT_TW == 64 && DT_CL == 4 && DT_NC == 136, "task maps of k_dwt53_rb");
-  __shared__ uint32_t sV[2 * DT_TH * DP_STR];   // the tile's 32 output rows after the vertical lifting (row t = tile row t + 2)
+  static_assert(NT == 1 || NT == 2, "tiles per workgroup");
+  __shared__ uint32_t sV[NT][2 * DT_TH * DP_STR];   // per tile: its 32 output rows after the vertical lifting (row t = tile row t + 2)
   const int tid = threadIdx.x;
-  int plane_i, tile_x, tile_y;
-  dwt_tile_of(a, plane_i, tile_x, tile_y);
-  const PlaneDesc pd = a.planes[plane_i];
-  int w = pd.W, h = pd.H;
-  for (int l = 0; l < a.lev; l++) { w = (w + 1) >> 1; h = (h + 1) >> 1; }
-  const int lw = (w + 1) >> 1, lh = (h + 1) >> 1, hw = w >> 1, hh = h >> 1;
-  const int tx0 = tile_x * DT_TW, ty0 = tile_y * DT_TH;
-  if (tx0 >= lw || ty0 >= lh) return;
-  const DwtSb2 sb2 = dwt_sb_pair(a, plane_i, tid);
-  const int gc0 = 2 * tx0 - DT_CL, gr0 = 2 * ty0 - HALO;
+  Rb53Tile T[NT];
+  bool valid[NT];
+#pragma unroll
+  for (int u = 0; u < NT; u++) {
+    int tile_x, tile_y;
+    if (NT == 1) { dwt_tile_of(a, T[u].plane_i, tile_x, tile_y); valid[u] = true; }
+    else {
+      const int b = (int)blockIdx.x * NT + u;
+      valid[u] = b < ntiles;
+      const uint32_t t = a.tilemap[valid[u] ? b : ntiles - 1];
+      T[u].plane_i = (int)(t >> 20); tile_y = (int)((t >> 10) & 1023u); tile_x = (int)(t & 1023u);
+    }
+    T[u].pd = a.planes[T[u].plane_i];
+    int w = T[u].pd.W, h = T[u].pd.H;
+    for (int l = 0; l < a.lev; l++) { w = (w + 1) >> 1; h = (h + 1) >> 1; }
+    T[u].w = w; T[u].h = h; T[u].lw = (w + 1) >> 1; T[u].lh = (h + 1) >> 1; T[u].hw = w >> 1; T[u].hh = h >> 1;
+    T[u].tx0 = tile_x * DT_TW; T[u].ty0 = tile_y * DT_TH;
+    if (NT == 1 && (T[u].tx0 >= T[u].lw || T[u].ty0 >= T[u].lh)) return;   // (3-D grid: planes of one batch may differ in size)
+    T[u].sb2 = dwt_sb_pair(a, T[u].plane_i, tid);
+  }
   // ---- vertical lifting out of registers ---------------------------------------------------------------------------------------
   {
     typedef uint16_t __attribute__((aligned(1))) u16a1;
@@ -616,22 +638,37 @@ __global__ void __launch_bounds__(256) k_dwt53_rb(DwtArgs a) {
     typedef const u16a1 __attribute__((address_space(1))) * gu16;
     typedef const int16_t __attribute__((address_space(1))) * gs16;
     typedef const u32a2 __attribute__((address_space(1))) * gu32;
-    const gu8 u = (gu8)(uintptr_t)pd.src;
-    const gs16 lin = (gs16)(uintptr_t)((const int16_t*)a.llin + (((a.lev - 1) & 1) ? pd.ll[1] : pd.ll[0]));
-    const int sstr = FROM_U8 ? pd.u8stride : dwt_ll_stride(w);
-    const bool second = tid < 4 * DP_NP - 256;   // 16 threads
-    uint32_t raw[2][11];
-    bool direct[2];
-    int cp[2], sg[2];
+    // slots 0 .. NT - 1: the thread's task `tid` of tile 0 .. NT - 1 (no branch around them: a workgroup's missing second tile is a copy
+    // of the level's last one, computed and thrown away); slot NT: one of the 16 tasks 256 .. 271 of tile tid / 16, by 16 NT threads.
+    // The extra slot's loads are issued FIRST: behind its branch the wait counts of the main slots' loads stay exact.
+    constexpr int NS = NT + 1;
+    typename std::conditional<FROM_U8, uint16_t, uint32_t>::type raw[NS][11];   // (as 16-bit values: the zero extension of a 32-bit array is an instruction behind every load, and its wait comes before the next slot's loads)
+    bool direct[NS];
+    int cp[NS], sg[NS], ut[NS];
+    const bool has_extra = tid < 16 * NT;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-      const int id = t ? 256 + (second ? tid : 0) : tid;
+    for (int tt = 0; tt < NS; tt++) {
+      const int t = tt == 0 ? NT : tt - 1;
+      const bool extra = t == NT;
+      ut[t] = extra ? (NT == 2 && tid >= 16 ? 1 : 0) : t;
+      const int id = extra ? 256 + (tid & 15) : tid;
       cp[t] = id % DP_NP; sg[t] = id / DP_NP;
+      const bool second = NT == 2 && ut[t] == 1;   // the slot's tile: uniform for the main slots, per thread for the extra one
+      const int w = second ? T[NT - 1].w : T[0].w, h = second ? T[NT - 1].h : T[0].h;
+      const int gc0 = 2 * (second ? T[NT - 1].tx0 : T[0].tx0) - DT_CL, gr0 = 2 * (second ? T[NT - 1].ty0 : T[0].ty0) - HALO;
+      const int sstr = FROM_U8 ? (second ? T[NT - 1].pd.u8stride : T[0].pd.u8stride) : dwt_ll_stride(w);
+      const gu8 u = (gu8)(uintptr_t)(second ? T[NT - 1].pd.src : T[0].pd.src);
+      const size_t llo = ((a.lev - 1) & 1) ? (second ? T[NT - 1].pd.ll[1] : T[0].pd.ll[1]) : (second ? T[NT - 1].pd.ll[0] : T[0].pd.ll[0]);
+      const gs16 lin = (gs16)(uintptr_t)((const int16_t*)a.llin + llo);
       const int gc = gc0 + 2 * cp[t], gr = gr0 + 8 * sg[t];
       direct[t] = gc >= 0 && gc + 1 < w;
-      int m = direct[t] ? gc : dwt_reflect(gc + 1, w);   // the mirrored pair (gc + 1, gc) starts at the image of gc + 1
+      // the mirrored pair (gc + 1, gc) starts at the image of gc + 1.  Without a branch (mask arithmetic, not ?:): a branch here splits
+      // the block, every 16-bit value loaded for an earlier slot is then widened where it crosses the boundary, and the waits of those
+      // eleven `v_and` come before this slot's loads are issued -- the slots' round trips in a row instead of side by side
+      const int dm = -(int)direct[t];
+      int m = (gc & dm) | (dwt_reflect(gc + 1, w) & ~dm);
       m = m > w - 2 ? w - 2 : m;                         // (farther out than the lifting reads: any two samples of the row)
-      if (t == 0 || second) {
+      if (!extra || has_extra) {
 #pragma unroll
         for (int j = 0; j < 11; j++) {
           const uint32_t o = (__umul24((unsigned)dwt_reflect(gr + j, h), (unsigned)sstr) + (unsigned)m);
@@ -641,8 +678,8 @@ __global__ void __launch_bounds__(256) k_dwt53_rb(DwtArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);   // every load requested before the first is unpacked
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-      if (t == 1 && !second) break;
+    for (int t = 0; t < NS; t++) {
+      if (t == NT && !has_extra) continue;
       uint32_t x[11];
 #pragma unroll
       for (int j = 0; j < 11; j++) {
@@ -653,7 +690,7 @@ __global__ void __launch_bounds__(256) k_dwt53_rb(DwtArgs a) {
       uint32_t hv[5];
 #pragma unroll
       for (int j = 0; j < 5; j++) hv[j] = dp_high(x[2 * j + 1], x[2 * j], x[2 * j + 2]);   // tile rows 8 seg + 1, 3, 5, 7, 9
-      uint32_t* o = sV + (8 * sg[t]) * DP_STR + cp[t];
+      uint32_t* o = &sV[0][0] + ut[t] * (2 * DT_TH * DP_STR) + (8 * sg[t]) * DP_STR + cp[t];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         o[(2 * j) * DP_STR] = dp_low(x[2 * j + 2], hv[j], hv[j + 1]);   // tile rows 8 seg + 2, 4, 6, 8 (lows)
@@ -666,22 +703,26 @@ __global__ void __launch_bounds__(256) k_dwt53_rb(DwtArgs a) {
   const bool last = a.lev == a.L - 1;
   const int cq = tid & 31, sidx = (tid >> 5) & 3, ry = tid >> 7;
   const int kx = 2 * cq;
-  uint32_t Lw[4], Hw[4];                       // per row: {col kx, col kx + 1} of the low / high band
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const uint32_t* row = sV + (2 * (4 * sidx + r) + ry) * DP_STR + (1 + kx);   // pairs holding tile columns 2 + 2 kx .. 9 + 2 kx
-    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];
-    const uint32_t E0 = __builtin_amdgcn_perm(d1, d0, 0x05040100u), E1 = __builtin_amdgcn_perm(d3, d2, 0x05040100u);  // evens e-1, e | e+1, e+2
-    const uint32_t O0 = __builtin_amdgcn_perm(d1, d0, 0x07060302u), O1 = __builtin_amdgcn_perm(d3, d2, 0x07060302u);  // odds between them
-    const uint32_t Es0 = __builtin_amdgcn_alignbit(E1, E0, 16);            // evens e, e + 1 (the lows' centres)
-    const uint32_t Es1 = __builtin_amdgcn_alignbit(0u, E1, 16);            // even e + 2, -
-    const uint32_t H0 = dp_high(O0, E0, Es0);                              // highs right of evens e - 1, e
-    const uint32_t H1 = dp_high(O1, E1, Es1);                              // high right of even e + 1 (second lane unused)
-    const uint32_t Hs = __builtin_amdgcn_alignbit(H1, H0, 16);             // highs right of evens e, e + 1 = subband columns kx, kx + 1
-    Lw[r] = dp_low(Es0, H0, Hs);
-    Hw[r] = Hs;
+  for (int u = 0; u < NT; u++) {
+    if (!valid[u]) continue;   // (uniform)
+    uint32_t Lw[4], Hw[4];                       // per row: {col kx, col kx + 1} of the low / high band
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t* row = &sV[u][0] + (2 * (4 * sidx + r) + ry) * DP_STR + (1 + kx);   // pairs holding tile columns 2 + 2 kx .. 9 + 2 kx
+      const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];
+      const uint32_t E0 = __builtin_amdgcn_perm(d1, d0, 0x05040100u), E1 = __builtin_amdgcn_perm(d3, d2, 0x05040100u);  // evens e-1, e | e+1, e+2
+      const uint32_t O0 = __builtin_amdgcn_perm(d1, d0, 0x07060302u), O1 = __builtin_amdgcn_perm(d3, d2, 0x07060302u);  // odds between them
+      const uint32_t Es0 = __builtin_amdgcn_alignbit(E1, E0, 16);            // evens e, e + 1 (the lows' centres)
+      const uint32_t Es1 = __builtin_amdgcn_alignbit(0u, E1, 16);            // even e + 2, -
+      const uint32_t H0 = dp_high(O0, E0, Es0);                              // highs right of evens e - 1, e
+      const uint32_t H1 = dp_high(O1, E1, Es1);                              // high right of even e + 1 (second lane unused)
+      const uint32_t Hs = __builtin_amdgcn_alignbit(H1, H0, 16);             // highs right of evens e, e + 1 = subband columns kx, kx + 1
+      Lw[r] = dp_low(Es0, H0, Hs);
+      Hw[r] = Hs;
+    }
+    dwt53_pk_output(a, T[u].pd, T[u].plane_i, tid, last, ry, sidx, cq, T[u].tx0, T[u].ty0, T[u].lw, T[u].lh, T[u].hw, T[u].hh, Lw, Hw, T[u].sb2);
   }
-  dwt53_pk_output(a, pd, plane_i, tid, last, ry, sidx, cq, tx0, ty0, lw, lh, hw, hh, Lw, Hw, sb2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -894,7 +935,15 @@ void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, in
       // the register-blocked 9/7 kernel: levels of at least 8 x 8 samples (its mirrored reads reach 4 samples beyond either end)
       const bool rb = !reversible && tuning().dwt_pk && minW >= 8 && minH >= 8 && cbw_log2 >= 3 && cbh_log2 >= 2;
       if (pk && tuning().dwt_pk == 2) { if (l == 0) hipLaunchKernelGGL(k_dwt53_pk<true>, grid, block, 0, st, a); else hipLaunchKernelGGL(k_dwt53_pk<false>, grid, block, 0, st, a); }   // (the staged form, for comparison)
-      else if (pk) { if (l == 0) hipLaunchKernelGGL(k_dwt53_rb<true>, grid, block, 0, st, a); else hipLaunchKernelGGL(k_dwt53_rb<false>, grid, block, 0, st, a); }
+      else if (pk) {
+        const int nt = d_tilemap ? first[l + 1] - first[l] : 0;
+        if (nt >= DWT_RB2_MIN_TILES && tuning().dwt_pk != 3) {   // two tiles per workgroup (QSVC_DWT_PK=3: always one)
+          const dim3 g2((nt + 1) / 2);
+          if (l == 0) hipLaunchKernelGGL((k_dwt53_rb<true, 2>), g2, block, 0, st, a, nt); else hipLaunchKernelGGL((k_dwt53_rb<false, 2>), g2, block, 0, st, a, nt);
+        } else {
+          if (l == 0) hipLaunchKernelGGL((k_dwt53_rb<true, 1>), grid, block, 0, st, a, nt); else hipLaunchKernelGGL((k_dwt53_rb<false, 1>), grid, block, 0, st, a, nt);
+        }
+      }
       else if (rb) { if (l == 0) hipLaunchKernelGGL(k_dwt97_rb<true>, grid, dim3(RB_THREADS), 0, st, a); else hipLaunchKernelGGL(k_dwt97_rb<false>, grid, dim3(RB_THREADS), 0, st, a); }
       else if (reversible) { if (l == 0) DWT_LAUNCH(true, true, false); else DWT_LAUNCH(true, false, false); }
       else { if (l == 0) DWT_LAUNCH(false, true, false); else DWT_LAUNCH(false, false, false); }
