@@ -232,7 +232,7 @@ int qsvc_j2k_stats(qsvc_ctx* ctx, uint64_t* codeblocks, uint64_t* passes, uint64
 
 /* A/B switches of the library's kernel forms (qsvc_amd/csrc/tuning.h: "mq_pipe", "mq_lds_small", "mq_lanes", "mq_sort", "t1_parts",
  * "t1_devlist", "pyr_tile", "me_piece", "pred_run", "upd_run", "upd_scatter", "dwt_pk" (1 = the register-blocked DWT kernels, 2 = 5/3 by the
- * staged packed kernel, 0 = the general tile kernel), "defer_ib", "dec_lanes", and "sync_block": 1 = host waits query the stream and sleep,
+ * staged packed kernel, 3 = one tile per workgroup on every level, 0 = the general tile kernel), "defer_ib", "dec_lanes", and "sync_block": 1 = host waits query the stream and sleep,
  * 0 = the runtime's spinning waits).  A context starts from the QSVC_* environment variables as they
  * were when it was created (read once, there); results never depend on the switches. */
 int qsvc_set_tuning(qsvc_ctx* ctx, const char* name, int value);

@@ -240,7 +240,7 @@ def test_both_mq_kernel_forms_give_the_same_streams(eng):
     want = J.encode_plane(y, reversible=True, levels=4)
     defaults = {"mq_pipe": 1, "mq_lds_small": 0, "mq_lanes": 64, "mq_sort": 1, "dwt_pk": 1, "t1_devlist": 1}
     try:
-        for sw in ({}, {"mq_lds_small": 1}, {"mq_pipe": 0}, {"mq_pipe": 0, "mq_lanes": 16}, {"mq_sort": 0}, {"dwt_pk": 0}, {"dwt_pk": 2}, {"t1_devlist": 0}):
+        for sw in ({}, {"mq_lds_small": 1}, {"mq_pipe": 0}, {"mq_pipe": 0, "mq_lanes": 16}, {"mq_sort": 0}, {"dwt_pk": 0}, {"dwt_pk": 2}, {"dwt_pk": 3}, {"t1_devlist": 0}):
             for k, v in dict(defaults, **sw).items():
                 eng.set_tuning(k, v)
             assert eng.j2k_encode_plane(y, prm) == want, sw
