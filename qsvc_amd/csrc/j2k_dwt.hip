@@ -937,7 +937,7 @@ void launch_dwt_tiles(hipStream_t st, const PlaneDesc* d_planes, int nplanes, in
       if (pk && tuning().dwt_pk == 2) { if (l == 0) hipLaunchKernelGGL(k_dwt53_pk<true>, grid, block, 0, st, a); else hipLaunchKernelGGL(k_dwt53_pk<false>, grid, block, 0, st, a); }   // (the staged form, for comparison)
       else if (pk) {
         const int nt = d_tilemap ? first[l + 1] - first[l] : 0;
-        if (nt >= DWT_RB2_MIN_TILES && tuning().dwt_pk != 3) {   // two tiles per workgroup (QSVC_DWT_PK=3: always one)
+        if ((nt >= DWT_RB2_MIN_TILES && tuning().dwt_pk != 3) || (nt >= 1 && tuning().dwt_pk == 4)) {   // two tiles per workgroup (QSVC_DWT_PK=3: always one, 4: always two)
           const dim3 g2((nt + 1) / 2);
           if (l == 0) hipLaunchKernelGGL((k_dwt53_rb<true, 2>), g2, block, 0, st, a, nt); else hipLaunchKernelGGL((k_dwt53_rb<false, 2>), g2, block, 0, st, a, nt);
         } else {

@@ -20,7 +20,7 @@ struct Tuning {
   int pred_run = 1;       // QSVC_PRED_RUN     set: the general predict kernels
   int upd_run = 1;        // QSVC_UPD_RUN      set: the general update kernels
   int upd_scatter = 1;    // QSVC_UPD_SCATTER=0 the ordered gather by runs instead of the scatter tiles
-  int dwt_pk = 1;         // QSVC_DWT_PK       1: register-blocked kernels (k_dwt53_rb, k_dwt97_rb); 2: 5/3 by the staged packed kernel (k_dwt53_pk); 3: k_dwt53_rb with one tile per workgroup on every level; 0: the general tile kernel
+  int dwt_pk = 1;         // QSVC_DWT_PK       1: register-blocked kernels (k_dwt53_rb, k_dwt97_rb); 2: 5/3 by the staged packed kernel (k_dwt53_pk); 3 / 4: k_dwt53_rb with one / two tiles per workgroup on every level; 0: the general tile kernel
   int defer_ib = 1;       // QSVC_DEFER_IB=0   the I/B decision of every level taken at once (one host round trip per level)
   int dec_lanes = 1;      // QSVC_DEC_LANES     1, 2, 4, 6, 8 code-blocks per wave of the Tier-1 decoder
   int sync_block = 1;     // QSVC_SYNC_BLOCK=0 the runtime's own (spinning) waits instead of query + sleep (qsvc_ctx.h ctx_sync)
@@ -38,7 +38,7 @@ struct Tuning {
     if (getenv("QSVC_PRED_RUN")) t.pred_run = 0;
     if (getenv("QSVC_UPD_RUN")) t.upd_run = 0;
     if ((e = getenv("QSVC_UPD_SCATTER"))) t.upd_scatter = e[0] != '0';
-    if ((e = getenv("QSVC_DWT_PK"))) { const int v = atoi(e); t.dwt_pk = v < 0 || v > 3 ? 1 : v; }
+    if ((e = getenv("QSVC_DWT_PK"))) { const int v = atoi(e); t.dwt_pk = v < 0 || v > 4 ? 1 : v; }
     if ((e = getenv("QSVC_DEFER_IB"))) t.defer_ib = e[0] != '0';
     if ((e = getenv("QSVC_DEC_LANES"))) { const int v = atoi(e); t.dec_lanes = (v == 2 || v == 4 || v == 6 || v == 8) ? v : 1; }
     if ((e = getenv("QSVC_SYNC_BLOCK"))) t.sync_block = e[0] != '0';
@@ -52,7 +52,7 @@ struct Tuning {
       if (!strcmp(t.n, name)) {
         if (t.p == &mq_lanes && !(v == 4 || v == 8 || v == 16 || v == 32 || v == 64)) return false;
         if (t.p == &t1_parts && (v < 0 || v > 4)) return false;
-        if (t.p == &dwt_pk && (v < 0 || v > 3)) return false;
+        if (t.p == &dwt_pk && (v < 0 || v > 4)) return false;
         if (t.p == &dec_lanes && !(v == 1 || v == 2 || v == 4 || v == 6 || v == 8)) return false;
         *t.p = v;
         return true;

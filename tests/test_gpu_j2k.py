@@ -84,6 +84,34 @@ def test_irreversible_streams_register_blocked_dwt(eng, kind, W, H, levels, cblk
         eng.set_tuning("dwt_pk", 1)
 
 
+def test_reversible_dwt_two_tiles_per_workgroup(eng):
+    """k_dwt53_rb<.., 2> (two tiles of a level's list per workgroup, what levels of at least 6 144 tiles run): forced on every level
+    (dwt_pk = 4) for planes whose levels have odd and even tile counts, one tile, picture ends inside tiles; then a batch large enough
+    to take it by itself (8 pictures of 1080p: 6 256 tiles at level 1) against the one-tile form and the restatement."""
+    from qsvc_amd import hip
+    try:
+        eng.set_tuning("dwt_pk", 4)
+        for kind, W, H, levels, cblk in (("noise", 250, 190, 3, 64), ("pan_noise", 641, 363, 4, 64), ("edge", 133, 517, 3, 32), ("noise", 16, 16, 1, 16),
+                                         ("pan_noise", 352, 288, 5, 64), ("saturating", 1000, 72, 5, 64), ("pan_noise", 1920, 1080, 4, 64)):
+            y = _luma(kind, W, H, 13)
+            assert eng.j2k_encode_plane(y, hip.j2k_params(reversible=True, levels=levels, cblk=cblk)) == J.encode_plane(y, reversible=True, levels=levels, cblk=cblk), (W, H)
+    finally:
+        eng.set_tuning("dwt_pk", 1)
+    W, H = 1920, 1080
+    clip = make_clip("pan_noise", 8, W, H, 44)
+    eng.seq_config(W, H)
+    eng.put_frames(hip.LOW, 0, clip)
+    prm = hip.j2k_params(reversible=True, levels=4)
+    streams = eng.j2k_encode_frames(hip.LOW, 0, 0, 8, prm)
+    try:
+        eng.set_tuning("dwt_pk", 3)
+        assert eng.j2k_encode_frames(hip.LOW, 0, 0, 8, prm) == streams
+    finally:
+        eng.set_tuning("dwt_pk", 1)
+    assert streams[21] == J.encode_plane(clip[7][:W * H].reshape(H, W), reversible=True, levels=4)
+    assert streams[5] == J.encode_plane(clip[1][W * H + (W // 2) * (H // 2):].reshape(H // 2, W // 2), reversible=True, levels=4)
+
+
 def test_layers_slopes_and_options(eng):
     from qsvc_amd import hip
     y = _luma("pan", 352, 288, 42)
@@ -240,7 +268,7 @@ def test_both_mq_kernel_forms_give_the_same_streams(eng):
     want = J.encode_plane(y, reversible=True, levels=4)
     defaults = {"mq_pipe": 1, "mq_lds_small": 0, "mq_lanes": 64, "mq_sort": 1, "dwt_pk": 1, "t1_devlist": 1}
     try:
-        for sw in ({}, {"mq_lds_small": 1}, {"mq_pipe": 0}, {"mq_pipe": 0, "mq_lanes": 16}, {"mq_sort": 0}, {"dwt_pk": 0}, {"dwt_pk": 2}, {"dwt_pk": 3}, {"t1_devlist": 0}):
+        for sw in ({}, {"mq_lds_small": 1}, {"mq_pipe": 0}, {"mq_pipe": 0, "mq_lanes": 16}, {"mq_sort": 0}, {"dwt_pk": 0}, {"dwt_pk": 2}, {"dwt_pk": 3}, {"dwt_pk": 4}, {"t1_devlist": 0}):
             for k, v in dict(defaults, **sw).items():
                 eng.set_tuning(k, v)
             assert eng.j2k_encode_plane(y, prm) == want, sw
