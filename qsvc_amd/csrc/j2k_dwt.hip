@@ -594,10 +594,10 @@ __global__ void __launch_bounds__(256) k_dwt53_pk(DwtArgs a) {
 // pass and the output are k_dwt53_pk's.  One barrier instead of two, 8.8 instead of 19.9 KB of LDS.
 // NT tiles per workgroup (round 4, last step): the two tiles' loads are requested together, so a wave has twice the bytes in flight for
 // the same fixed latencies (its scalar set-up, one memory round trip, one barrier, the stores' issue) -- these kernels wait on round
-// trips at full occupancy, not on issue slots.  NT = 2 on levels of at least DWT_RB2_MIN_TILES tiles (below that a launch is one or two
-// rounds of workgroups and fewer, longer workgroups only lengthen it); the tiles are consecutive entries of the level's tile list and
+// trips at full occupancy, not on issue slots.  NT = 2 on levels of at least DWT_RB2_MIN_TILES tiles (below that a launch is one
+// round of workgroups and fewer, longer workgroups do not shorten it: 1080p levels 3 and 4 measured equal); the tiles are consecutive entries of the level's tile list and
 // need not be neighbours.
-#define DWT_RB2_MIN_TILES 6144
+#define DWT_RB2_MIN_TILES 2048
 struct Rb53Tile {
   PlaneDesc pd;
   DwtSb2 sb2;

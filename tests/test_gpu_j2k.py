@@ -85,9 +85,9 @@ def test_irreversible_streams_register_blocked_dwt(eng, kind, W, H, levels, cblk
 
 
 def test_reversible_dwt_two_tiles_per_workgroup(eng):
-    """k_dwt53_rb<.., 2> (two tiles of a level's list per workgroup, what levels of at least 6 144 tiles run): forced on every level
+    """k_dwt53_rb<.., 2> (two tiles of a level's list per workgroup, what levels of at least 2 048 tiles run): forced on every level
     (dwt_pk = 4) for planes whose levels have odd and even tile counts, one tile, picture ends inside tiles; then a batch large enough
-    to take it by itself (8 pictures of 1080p: 6 256 tiles at level 1) against the one-tile form and the restatement."""
+    to take it by itself (8 pictures of 1080p: 6 256 tiles at level 1, 1 664 at level 2) against the one-tile form and the restatement."""
     from qsvc_amd import hip
     try:
         eng.set_tuning("dwt_pk", 4)
